@@ -1,0 +1,110 @@
+"""Deterministic synthetic weights and inputs (no network, no checkpoints).
+
+The reference needs pretrained files that do not exist here
+(`models/registry.py:15` loads weights/dark53_imgnet.pth; `models/backbones.py:171`
+downloads EfficientNet weights), so every model in this repo, the oracle and the
+golden-vector generator are filled from this one generator.  A tensor is a pure
+function of its ``state_dict`` key and shape: numpy PCG64 seeded from SHA-256 of
+the key, so the reference model in the build container and the HIP model on the
+GPU box get bit-identical parameters without shipping them.
+
+Recipe: conv weights zero-mean normal with a
+variance-preserving gain, BN gamma~U(.5,1.5), beta~N(0,.1), mean~N(0,.1),
+var~U(.5,1.5); residual-branch BN gamma damped so 23 stacked DarkBlocks do not
+blow up; head convs calibrated so objectness/class logits are long-tailed
+(thousands of candidates >= 0.005, classes well spread) instead of the degenerate
+all-0.25 scores plain random init gives.
+"""
+import hashlib
+
+import numpy as np
+import torch
+
+# rms of the FPN output feeding each YOLO head conv, measured once with the
+# recipe below (oracle forward, 512x512 uniform input); used to set head gains.
+_YOLO_HEAD_FEATURE_RMS = {0: 1.14, 1: 1.61, 2: 2.64}
+
+
+def _rng(key: str) -> np.random.Generator:
+    seed = int.from_bytes(hashlib.sha256(key.encode()).digest()[:8], 'little')
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def _normal(key, shape, std=1.0, mean=0.0):
+    a = _rng(key).standard_normal(size=shape, dtype=np.float32)
+    return (a * np.float32(std) + np.float32(mean)).astype(np.float32)
+
+
+def _uniform(key, shape, lo, hi):
+    a = _rng(key).random(size=shape, dtype=np.float32)
+    return (a * np.float32(hi - lo) + np.float32(lo)).astype(np.float32)
+
+
+def _yolo_head(key, shape, n_cls=80):
+    """rpn.heads.conv_{i}.{weight,bias}: row o = a*(5+n_cls) + c  (models/rpns.py:27-33)."""
+    level = int(key.split('conv_')[1].split('.')[0])
+    rows = shape[0]
+    c = np.arange(rows) % (5 + n_cls)
+    # target logit std per row kind: xy 1.0, wh 0.35, conf 2.5, class 2.0
+    tgt = np.where(c < 2, 1.0, np.where(c < 4, 0.35, np.where(c == 4, 2.5, 2.0))).astype(np.float32)
+    if key.endswith('.bias'):
+        bias = np.where(c < 4, 0.0, np.where(c == 4, -5.0, -4.0)).astype(np.float32)
+        return bias + _normal(key, (rows,), std=0.05)
+    fan_in = shape[1] * shape[2] * shape[3]
+    rms = _YOLO_HEAD_FEATURE_RMS.get(level, 1.0)
+    w = _normal(key, shape)
+    return w * (tgt / (np.sqrt(fan_in) * rms)).reshape(-1, 1, 1, 1).astype(np.float32)
+
+
+def make_tensor(key: str, shape, dtype=torch.float32) -> torch.Tensor:
+    """The synthetic value of parameter/buffer `key`."""
+    shape = tuple(shape)
+    if key.endswith('num_batches_tracked'):
+        return torch.zeros(shape, dtype=torch.int64)
+    if key.startswith('rpn.heads.conv_'):
+        arr = _yolo_head(key, shape)
+    elif key.endswith('running_var'):
+        arr = _uniform(key, shape, 0.5, 1.5)
+    elif key.endswith('running_mean'):
+        arr = _normal(key, shape, std=0.1)
+    elif len(shape) == 4:                                   # conv weight, OIHW
+        fan_in = shape[1] * shape[2] * shape[3]
+        arr = _normal(key, shape, std=np.sqrt(1.664 / fan_in))
+    elif len(shape) == 1 and key.endswith('.weight'):       # BN gamma
+        damp = '.cbl_1.bn.' in key and key.startswith('backbone.')
+        arr = _uniform(key, shape, 0.1, 0.3) if damp else _uniform(key, shape, 0.5, 1.5)
+    elif len(shape) == 1 and key.endswith('.bias'):         # BN beta / conv bias
+        arr = _normal(key, shape, std=0.1)
+    else:
+        arr = _normal(key, shape, std=0.1)
+    return torch.from_numpy(np.ascontiguousarray(arr)).to(dtype)
+
+
+def make_state_dict(template) -> dict:
+    """template: mapping key -> tensor (only shape/dtype are used)."""
+    return {k: make_tensor(k, v.shape, v.dtype) for k, v in template.items()}
+
+
+def make_images(batch: int, size, seed: int = 0, kind: str = 'rects') -> torch.Tensor:
+    """Synthetic 'RGB_1' images in [0,1], NCHW float32 (utils/image_ops.py:165-188 identity case).
+
+    kind='uniform': iid U[0,1) pixels.  kind='rects' (default): random
+    coloured rectangles over a flat background plus 10% noise -- spatial structure, so head
+    logits vary over the grid and the NMS workload is not one class everywhere.
+    """
+    h, w = (size, size) if isinstance(size, int) else size
+    rng = np.random.Generator(np.random.PCG64(seed))
+    if kind == 'uniform':
+        return torch.from_numpy(rng.random((batch, 3, h, w), dtype=np.float32))
+    out = np.empty((batch, 3, h, w), dtype=np.float32)
+    for b in range(batch):
+        img = np.broadcast_to(rng.random((3, 1, 1), dtype=np.float32), (3, h, w)).copy()
+        for _ in range(48):
+            rh = int(rng.integers(8, max(9, h // 2)))
+            rw = int(rng.integers(8, max(9, w // 2)))
+            y0 = int(rng.integers(0, h - 4))
+            x0 = int(rng.integers(0, w - 4))
+            img[:, y0:y0 + rh, x0:x0 + rw] = rng.random((3, 1, 1), dtype=np.float32)
+        img += (rng.random((3, h, w), dtype=np.float32) - np.float32(0.5)) * np.float32(0.2)
+        out[b] = np.clip(img, 0.0, 1.0)
+    return torch.from_numpy(out)

@@ -1,0 +1,239 @@
+"""Golden-vector generator (build container only; needs /root/reference).
+
+    python -m oracle.gen_golden            # writes tests/golden/*.npz
+
+Imports the REAL reference (duanzhiihao/myDetection at /root/reference) through
+oracle/_refimport.py, runs it on seeded synthetic inputs/weights
+(mydetection_amd/synth.py) and stores inputs + outputs as small .npz fixtures.
+Only data is written -- never reference source.  The one behaviour that does not
+come from the reference is torchvision.ops.nms (absent third-party op; restated
+in oracle/nms_ref.c, parity unpinned there).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+from oracle import _refimport  # noqa: E402
+from mydetection_amd import synth  # noqa: E402
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def gen_yolov3(batch=1, size=512, name='yolov3_b1_512'):
+    model, cfg = _refimport.build_reference_model('yolov3_80')
+    x = synth.make_images(batch, size, seed=0)
+    stages = {}
+
+    def hook(key):
+        def f(_m, _i, out):
+            stages[key] = out
+        return f
+    model.backbone.register_forward_hook(hook('backbone'))
+    model.fpn.register_forward_hook(hook('fpn'))
+    model.rpn.register_forward_hook(hook('rpn'))
+    with torch.no_grad():
+        dts = model(x)
+    out = {'batch': batch, 'size': size, 'image_seed': 0}
+    rng = np.random.Generator(np.random.PCG64(1234))
+    # stage checksums + samples (full tensors are too big to commit)
+    for key in ('backbone', 'fpn'):
+        for lvl, f in enumerate(stages[key]):
+            f = _np(f)
+            out[f'{key}_{lvl}_shape'] = np.array(f.shape)
+            out[f'{key}_{lvl}_l2'] = np.float64(np.sqrt((f.astype(np.float64) ** 2).sum()))
+            out[f'{key}_{lvl}_sum'] = np.float64(f.astype(np.float64).sum())
+            flat = f.reshape(-1)
+            idx = rng.integers(0, flat.size, size=256)
+            out[f'{key}_{lvl}_idx'] = idx
+            out[f'{key}_{lvl}_val'] = flat[idx]
+    for lvl, raw in enumerate(stages['rpn']):
+        # raw['bbox'] is a permuted view of the head conv output [B, A*85, H, W]
+        nB, nA, nH, nW, _ = raw['bbox'].shape
+        full = torch.cat([raw['bbox'], raw['conf'], raw['class']], dim=-1)   # [B,A,H,W,85]
+        conv_out = _np(full.permute(0, 1, 4, 2, 3).reshape(nB, nA * 85, nH, nW))
+        if lvl == 2:                    # smallest level: keep whole head tensor (255*16*16 floats)
+            out['head_2_full'] = conv_out
+        flat = conv_out.reshape(-1)
+        idx = rng.integers(0, flat.size, size=512)
+        out[f'head_{lvl}_idx'] = idx
+        out[f'head_{lvl}_val'] = flat[idx]
+        out[f'head_{lvl}_shape'] = np.array(conv_out.shape)
+    for b, d in enumerate(dts):
+        out[f'bboxes_{b}'] = _np(d.bboxes)
+        out[f'cats_{b}'] = _np(d.cats)
+        out[f'scores_{b}'] = _np(d.scores)
+    # reference post_process at the AP-eval setting and at a setting that keeps <=512
+    for tag, conf, nms in (('ap', cfg['test.ap_conf_thres'], cfg['test.nms_thres']), ('mid', 0.05, 0.45),
+                           ('demo', cfg['test.default_conf_thres'], cfg['test.nms_thres'])):
+        for b in range(batch):
+            with torch.no_grad():
+                d = model(x[b:b + 1])[0].post_process(conf_thres=conf, nms_thres=nms)
+            out[f'pp_{tag}_conf'] = np.float64(conf)
+            out[f'pp_{tag}_nms'] = np.float64(nms)
+            out[f'pp_{tag}_bboxes_{b}'] = _np(d.bboxes)
+            out[f'pp_{tag}_cats_{b}'] = _np(d.cats)
+            out[f'pp_{tag}_scores_{b}'] = _np(d.scores)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(name, {k: (v.shape if hasattr(v, 'shape') else v) for k, v in out.items() if k.startswith('pp_ap')})
+
+
+def gen_detlayers():
+    import json
+    _refimport.install()
+    from models.registry import get_det_layer
+    out = {}
+    g = torch.Generator().manual_seed(7)
+
+    def randn(*shape, std=1.0, mean=0.0):
+        return torch.randn(*shape, generator=g) * std + mean
+
+    # YOLO: all three levels, B=2
+    cfg = json.load(open('/root/reference/configs/yolov3_80.json'))
+    cfg['model.fpn.out_strides'] = (8, 16, 32)
+    for lvl, hw in ((0, (6, 10)), (1, (5, 5)), (2, (3, 4))):
+        layer = get_det_layer(cfg)(level_i=lvl, cfg=cfg)
+        conv = randn(2, 255, *hw, std=1.5)
+        v = conv.view(2, 3, 85, *hw)
+        raw = {'bbox': v[:, :, 0:4].permute(0, 1, 3, 4, 2), 'conf': v[:, :, 4:5].permute(0, 1, 3, 4, 2),
+               'class': v[:, :, 5:].permute(0, 1, 3, 4, 2)}
+        img = (hw[0] * cfg['model.fpn.out_strides'][lvl], hw[1] * cfg['model.fpn.out_strides'][lvl])
+        p, _ = layer(raw, img, None)
+        out[f'yolo_{lvl}_in'] = _np(conv)
+        out[f'yolo_{lvl}_img'] = np.array(img)
+        for k in ('bbox', 'class_idx', 'score'):
+            out[f'yolo_{lvl}_{k}'] = _np(p[k])
+    # RetinaNet: levels 0 and 3, nA=9
+    cfg = json.load(open('/root/reference/configs/efficientdet-d1.json'))
+    cfg['model.fpn.out_strides'] = [8, 16, 32, 64, 128]
+    for lvl, hw in ((0, (8, 8)), (3, (2, 2))):
+        layer = get_det_layer(cfg)(level_i=lvl, cfg=cfg)
+        s = cfg['model.fpn.out_strides'][lvl]
+        raw = {'bbox': randn(2, 9, *hw, 4, std=0.5), 'class': randn(2, 9, *hw, 80, std=2.0, mean=-2.0)}
+        img = (hw[0] * s, hw[1] * s)
+        p, _ = layer(raw, img, None)
+        out[f'retina_{lvl}_bbox_in'] = _np(raw['bbox'])
+        out[f'retina_{lvl}_class_in'] = _np(raw['class'])
+        out[f'retina_{lvl}_img'] = np.array(img)
+        out[f'retina_{lvl}_anchor_wh'] = _np(layer.anchor_wh)
+        for k in ('bbox', 'class_idx', 'score'):
+            out[f'retina_{lvl}_{k}'] = _np(p[k])
+    # FCOS2_ATSS: levels 0 and 2, nA=1
+    cfg = json.load(open('/root/reference/configs/d1_fcs2_atss.json'))
+    cfg['model.fpn.out_strides'] = [8, 16, 32, 64, 128]
+    for lvl, hw in ((0, (8, 6)), (2, (3, 3))):
+        layer = get_det_layer(cfg)(level_i=lvl, cfg=cfg)
+        s = cfg['model.fpn.out_strides'][lvl]
+        raw = {'bbox': randn(2, *hw, 4, std=0.8, mean=0.5), 'conf': randn(2, *hw, 1, std=2.0),
+               'class': randn(2, *hw, 80, std=2.0, mean=-2.0)}
+        img = (hw[0] * s, hw[1] * s)
+        p, _ = layer(raw, img, None)
+        for k in ('bbox', 'conf', 'class'):
+            out[f'fcos_{lvl}_{k}_in'] = _np(raw[k])
+        out[f'fcos_{lvl}_img'] = np.array(img)
+        for k in ('bbox', 'class_idx', 'score'):
+            out[f'fcos_{lvl}_{k}'] = _np(p[k])
+    np.savez_compressed(os.path.join(OUT, 'detlayers.npz'), **out)
+    print('detlayers', len(out))
+
+
+def _rand_candidates(rng, n, n_cls, img=512.0, score_scale=1.0):
+    cx = rng.random(n, dtype=np.float32) * np.float32(img)
+    cy = rng.random(n, dtype=np.float32) * np.float32(img)
+    w = (rng.random(n, dtype=np.float32) * np.float32(0.3) + np.float32(0.02)) * np.float32(img)
+    h = (rng.random(n, dtype=np.float32) * np.float32(0.3) + np.float32(0.02)) * np.float32(img)
+    b = np.stack([cx, cy, w, h], axis=1).astype(np.float32)
+    c = rng.integers(0, n_cls, size=n).astype(np.int64)
+    s = (rng.random(n, dtype=np.float32) ** 3 * np.float32(score_scale)).astype(np.float32)
+    return b, c, s
+
+
+def gen_postprocess():
+    _refimport.install()
+    from utils.structures import ImageObjects
+    rng = np.random.Generator(np.random.PCG64(99))
+    cases = {}
+    b, c, s = _rand_candidates(rng, 2000, 80)
+    cases['rand2000_under512'] = (b, c, s, 0.5, 0.45)          # ~400 pass
+    cases['rand2000_over512'] = (b, c, s, 0.05, 0.45)          # ~1200 pass -> topk
+    b, c, s = _rand_candidates(rng, 25200, 80)
+    cases['rand25200_over512'] = (b, c, s, 0.005, 0.45)
+    b, c, s = _rand_candidates(rng, 700, 1, img=128.0)
+    cases['single_class_dense'] = (b, c, s, 0.0, 0.5)          # 700 > 512, all one class, heavy overlap
+    b, c, s = _rand_candidates(rng, 300, 3, img=64.0)
+    cases['three_class_dense'] = (b, c, s, 0.1, 0.3)
+    b, c, s = _rand_candidates(rng, 50, 80)
+    cases['none_pass'] = (b, c, s, 2.0, 0.45)                   # empty after filter
+    cases['empty_input'] = (np.zeros((0, 4), np.float32), np.zeros(0, np.int64), np.zeros(0, np.float32), 0.5, 0.45)
+    # zero-area and identical boxes
+    b = np.array([[10, 10, 0, 0], [10, 10, 0, 0], [10, 10, 4, 4], [10, 10, 4, 4], [10, 10, 4, 4], [30, 30, 0, 5]],
+                 np.float32)
+    c = np.array([1, 1, 1, 1, 2, 2], np.int64)
+    s = np.array([0.9, 0.8, 0.7, 0.6, 0.95, 0.5], np.float32)
+    cases['degenerate_boxes'] = (b, c, s, 0.1, 0.45)
+    # IoU exactly at threshold: A=(cx1,cy1,w2,h2) area 4, B=(cx1,cy.5,w2,h1) area 2, inter 2 -> IoU 0.5
+    b = np.array([[1, 1, 2, 2], [1, 0.5, 2, 1]], np.float32)
+    c = np.array([0, 0], np.int64)
+    s = np.array([0.9, 0.8], np.float32)
+    cases['iou_eq_thr'] = (b, c, s, 0.1, 0.5)                                  # not suppressed (strict >)
+    cases['iou_gt_thr'] = (b, c, s, 0.1, float(np.nextafter(0.5, 0.0)))        # suppressed
+    cases['iou_lt_thr'] = (b, c, s, 0.1, float(np.nextafter(0.5, 1.0)))
+    # score exactly at the conf threshold passes (>=)
+    b, c, s = _rand_candidates(rng, 64, 5)
+    s[7] = np.float32(0.25)
+    cases['score_eq_conf'] = (b, c, s, 0.25, 0.45)
+    out = {'names': np.array(sorted(cases))}
+    for name, (b, c, s, conf, nms) in cases.items():
+        d = ImageObjects(torch.from_numpy(b.copy()), torch.from_numpy(c.copy()), None, torch.from_numpy(s.copy()),
+                         'cxcywh', (512, 512))
+        r = d.post_process(conf_thres=conf, nms_thres=nms)
+        out[f'{name}_in_bboxes'], out[f'{name}_in_cats'], out[f'{name}_in_scores'] = b, c, s
+        out[f'{name}_conf'], out[f'{name}_nms'] = np.float64(conf), np.float64(nms)
+        out[f'{name}_bboxes'], out[f'{name}_cats'], out[f'{name}_scores'] = _np(r.bboxes), _np(r.cats), _np(r.scores)
+    # bboxes_to_original_ (utils/structures.py:175-189)
+    d = ImageObjects(torch.from_numpy(cases['three_class_dense'][0].copy()),
+                     torch.from_numpy(cases['three_class_dense'][1].copy()), None,
+                     torch.from_numpy(cases['three_class_dense'][2].copy()), 'cxcywh', (64, 64))
+    pad_info = (1280, 720, 3, 5, 64, 36)
+    d.bboxes_to_original_(pad_info)
+    out['to_original_pad_info'] = np.array(pad_info)
+    out['to_original_bboxes'] = _np(d.bboxes)
+    np.savez_compressed(os.path.join(OUT, 'postprocess.npz'), **out)
+    print('postprocess', {n: out[f'{n}_bboxes'].shape[0] for n in cases})
+
+
+def gen_bbox_ops():
+    _refimport.install()
+    from utils.bbox_ops import bboxes_iou, cxcywh_to_x1y1x2y2
+    rng = np.random.Generator(np.random.PCG64(5))
+    a, _, _ = _rand_candidates(rng, 37, 1, img=100.0)
+    b, _, _ = _rand_candidates(rng, 53, 1, img=100.0)
+    out = {'a': a, 'b': b}
+    out['iou_cxcywh'] = _np(bboxes_iou(torch.from_numpy(a), torch.from_numpy(b), xyxy=False))
+    axy = _np(cxcywh_to_x1y1x2y2(torch.from_numpy(a)))
+    bxy = _np(cxcywh_to_x1y1x2y2(torch.from_numpy(b)))
+    out['a_xyxy'], out['b_xyxy'] = axy, bxy
+    out['iou_xyxy'] = _np(bboxes_iou(torch.from_numpy(axy), torch.from_numpy(bxy), xyxy=True))
+    np.savez_compressed(os.path.join(OUT, 'bbox_ops.npz'), **out)
+    print('bbox_ops ok')
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ['bbox_ops', 'postprocess', 'detlayers', 'yolov3']
+    if 'bbox_ops' in which:
+        gen_bbox_ops()
+    if 'postprocess' in which:
+        gen_postprocess()
+    if 'detlayers' in which:
+        gen_detlayers()
+    if 'yolov3' in which:
+        gen_yolov3(1, 512, 'yolov3_b1_512')
