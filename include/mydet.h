@@ -1,0 +1,142 @@
+/* mydet.h -- C ABI of libmydet_hip.so: the MI355X (gfx950) kernels behind the
+ * single-stage detection inference hot path of duanzhiihao/myDetection.
+ *
+ * The reference has no FFI seam (it is pure Python over ATen/torchvision); its
+ * seams are the Python plug-in factories models/registry.py:4-146 and
+ * api/detection.py:19-205.  Each entry point below replaces the third-party native
+ * op (ATen / torchvision) that a reference Python call site lands in; the call
+ * site is cited per function.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only.  All pointers are DEVICE pointers (HBM).
+ *  - `stream` is a hipStream_t passed as void*; 0 = the null stream.
+ *  - Every function only enqueues work on `stream`; it never allocates persistent
+ *    memory, never synchronises, and is graph-capturable.  The caller owns all
+ *    buffers, including scratch.
+ *  - Return value: 0 on success, otherwise a hipError_t, or a negative MYDET_E_*
+ *    code for argument errors detected on the host before any launch.
+ *  - Activations are float32, channels-last ("NHWC"): element (b,y,x,c) of a
+ *    tensor with pixel stride `ld` (in floats, ld >= C) lives at
+ *    ((b*H + y)*W + x)*ld + c.  A pixel stride larger than C lets a kernel read
+ *    or write a channel slice of a wider buffer (free concat / padding).
+ */
+#ifndef MYDET_H
+#define MYDET_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MYDET_ABI_VERSION 1
+
+#define MYDET_E_BADARG   (-1)   /* shape/stride/alignment precondition violated */
+#define MYDET_E_UNSUPP   (-2)   /* valid request this build has no kernel for   */
+
+/* activation codes for the conv epilogue */
+#define MYDET_ACT_NONE   0
+#define MYDET_ACT_LEAKY  1      /* LeakyReLU(0.1): models/modules.py:92        */
+#define MYDET_ACT_SWISH  2      /* x*sigmoid(x):  models/modules.py:41-43      */
+
+int mydet_abi_version(void);
+
+/* Dense convolution as implicit GEMM on FP32 MFMA (v_mfma_f32_32x32x2_f32), with the
+ * epilogue  y = act(acc*scale[n] + shift[n]) + residual  fused.
+ * Replaces the conv2d -> batch_norm -> leaky_relu (-> add) ATen chain of
+ *   ConvBnLeaky.forward  models/modules.py:94-95   (scale/shift = folded BN, eps 1e-5)
+ *   DarkBlock.forward    models/modules.py:69-73   (residual != NULL)
+ *   YOLOHead 1x1 convs   models/rpns.py:24-25      (scale NULL => 1, shift = bias)
+ * x  : [B,H,W,Cin] pixel stride ldx.   Cin % 4 == 0, ldx % 4 == 0, 16-byte aligned.
+ * w  : [Cout][KH][KW][Cin] contiguous (OHWI repack of the reference's OIHW weight).
+ * y  : [B,Ho,Wo,Cout] pixel stride ldy.  residual: same shape, pixel stride ldr, or NULL.
+ * Ho = (H + pad_t + pad_b - KH)/stride + 1 (likewise Wo); only pad_t/pad_l are
+ * needed by the kernel, Ho/Wo are passed explicitly (asymmetric "SAME" pads allowed).
+ */
+int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *w,
+                           const float *scale, const float *shift,
+                           const float *residual, int64_t ldr,
+                           float *y, int64_t ldy,
+                           int B, int H, int W, int Cin, int Cout,
+                           int KH, int KW, int stride, int pad_t, int pad_l,
+                           int Ho, int Wo, int act, void *stream);
+
+/* First-layer convolution (Cin == 3, 3x3) reading the image with arbitrary strides
+ * (NCHW as handed over by api/detection.py:160-166, or channels-last) and writing NHWC.
+ * Replaces netlist[0] of Darknet53 (models/backbones.py:14) and the EfficientNet stem.
+ * Cout must be 32.  Strides sxb/sxc/sxh/sxw in floats.
+ */
+int mydet_conv2d_stem_f32(const float *x, int64_t sxb, int64_t sxc, int64_t sxh, int64_t sxw,
+                          const float *w /* [Cout][3][3][3] OHWI */,
+                          const float *scale, const float *shift,
+                          float *y, int64_t ldy,
+                          int B, int H, int W, int Cout, int stride, int pad_t, int pad_l,
+                          int Ho, int Wo, int act, void *stream);
+
+/* y[b,yo,xo, 0:C1] = a[b, nearest(yo), nearest(xo), :]  ;  y[..., C1:C1+C2] = b[b,yo,xo,:]
+ * Replaces F.interpolate(mode='nearest') + torch.cat((pre, x), 1) of
+ * YOLOBranch.forward models/fpns.py:62-65.  C1, C2, strides multiples of 4.
+ * If C2 == 0 / b == NULL it is a plain nearest resize.
+ */
+int mydet_upsample_concat_f32(const float *a, int64_t lda, int Ha, int Wa, int C1,
+                              const float *b, int64_t ldb, int C2,
+                              float *y, int64_t ldy, int B, int Ho, int Wo, void *stream);
+
+/* Box decode of one pyramid level: raw head logits -> (bbox cxcywh, class_idx, score)
+ * for every candidate, written into the level's slice [n_off, n_off + A*H*W) of the
+ * per-image candidate arrays (models/general.py:74-76 concatenates levels along dim 1).
+ *   mode MYDET_DECODE_YOLO   YOLOLayer.forward        models/detlayers/yolov3.py:41-69
+ *   mode MYDET_DECODE_RETINA RetinaLayer.forward      models/detlayers/retinanet.py:63-82
+ *   mode MYDET_DECODE_FCOS   FCOS_ATSS_Layer.forward  models/detlayers/fcos2.py:222-251
+ * box : [B,H,W,*] pixel stride ldbox; anchor a's 4 box logits at a*box_astride + box_c0
+ * cls : [B,H,W,*] pixel stride ldcls; anchor a's C class logits at a*cls_astride + cls_c0,
+ *       its objectness/centerness logit (YOLO, FCOS) at a*cls_astride + conf_c0.
+ *       (YOLO head: box == cls, astride 5+C, box_c0 0, conf_c0 4, cls_c0 5.)
+ * anchors_wh: HOST pointer (the one exception to "device pointers only") to A pairs (w,h)
+ *       in pixels; the <= 16 pairs travel as kernel arguments so the launch stays
+ *       graph-capturable (YOLO, RETINA; ignored for FCOS, where A == 1).
+ * Candidate order inside a level is (a, y, x), x fastest.  N = candidates per image.
+ * Outputs: bbox [B,N,4] f32, class_idx [B,N] i64, score [B,N] f32.
+ * ldbox, ldcls multiples of 4; 16-byte aligned bases.
+ */
+#define MYDET_DECODE_YOLO   0
+#define MYDET_DECODE_RETINA 1
+#define MYDET_DECODE_FCOS   2
+int mydet_decode_f32(int mode,
+                     const float *box, int64_t ldbox, int box_astride, int box_c0,
+                     const float *cls, int64_t ldcls, int cls_astride, int cls_c0, int conf_c0,
+                     const float *anchors_wh, int A, int C,
+                     int B, int H, int W, float stride, int img_h, int img_w,
+                     float *bbox, int64_t *class_idx, float *score, int64_t N, int64_t n_off,
+                     void *stream);
+
+/* Batched confidence filter -> top-k -> class-aware greedy NMS, one image per workgroup.
+ * Replaces ImageObjects.post_process / non_max_suppression (utils/structures.py:92-173)
+ * and torchvision.ops.nms; the candidates never leave HBM.
+ *   keep score >= conf_thres (float32 compare); if more than `topk` (<=512) pass, keep the
+ *   topk highest (ties: lowest candidate index); per class ascending: greedy NMS on
+ *   x1y1x2y2 = (cx-w/2, cy-h/2, cx+w/2, cy+h/2), suppress when (double)IoU > nms_thres;
+ *   survivors ordered class ascending, score descending (ties: lowest index).
+ * In : bbox [B,N,4], class_idx [B,N] i64, score [B,N].   N < 2^17, classes < 2^15.
+ * Out: count [B] i32; out_bbox [B,topk,4]; out_class [B,topk] i64; out_score [B,topk];
+ *      out_index [B,topk] i32 = candidate index in [0,N) of each survivor (rows >= count
+ *      are zero-filled).
+ * scratch: B*N*8 bytes.
+ */
+int mydet_postprocess_f32(const float *bbox, const int64_t *class_idx, const float *score,
+                          int B, int64_t N, float conf_thres, double nms_thres, int topk,
+                          int32_t *count, float *out_bbox, int64_t *out_class, float *out_score,
+                          int32_t *out_index, void *scratch, void *stream);
+
+/* Pairwise IoU [Na,Nb]; utils/bbox_ops.py:6-49 (xyxy != 0: corner format, else cxcywh). */
+int mydet_bboxes_iou_f32(const float *a, int Na, const float *b, int Nb, int xyxy,
+                         float *iou, void *stream);
+
+/* In-place undo of resize/pad on cxcywh boxes; utils/structures.py:175-189. */
+int mydet_bboxes_to_original_f32(float *bbox, int64_t n, float ori_w, float ori_h,
+                                 float tl_x, float tl_y, float imw, float imh, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MYDET_H */

@@ -1,0 +1,63 @@
+"""ctypes binding of libmydet_hip.so (C ABI declared in include/mydet.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  If it is missing
+the import of any op fails loudly with instructions to build it.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libmydet_hip.so')
+
+c_int, c_i64, c_f32, c_f64, c_ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
+
+# name -> argtypes, exactly the prototypes of include/mydet.h
+SIGNATURES = {
+    'mydet_abi_version': [],
+    'mydet_conv2d_igemm_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64] + [c_int] * 13 + [c_ptr],
+    'mydet_conv2d_stem_f32': [c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64] + [c_int] * 10 + [c_ptr],
+    'mydet_upsample_concat_f32': [c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_int,
+                                  c_int, c_ptr],
+    'mydet_decode_f32': [c_int, c_ptr, c_i64, c_int, c_int, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_int, c_int,
+                         c_int, c_int, c_int, c_f32, c_int, c_int, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr],
+    'mydet_postprocess_f32': [c_ptr, c_ptr, c_ptr, c_int, c_i64, c_f32, c_f64, c_int, c_ptr, c_ptr, c_ptr, c_ptr,
+                              c_ptr, c_ptr, c_ptr],
+    'mydet_bboxes_iou_f32': [c_ptr, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr],
+    'mydet_bboxes_to_original_f32': [c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_ptr],
+}
+
+_lib = None
+
+
+class MissingHipLibrary(ImportError):
+    pass
+
+
+def lib():
+    """Load (once) and return the bound library; raise MissingHipLibrary if it was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MissingHipLibrary(
+                f'{LIB_PATH} not found. mydetection_amd has no CPU/PyTorch fallback: build the gfx950 '
+                'kernels first with  python -c "import __graft_entry__ as g; g.build()"  '
+                '(or make -C mydetection_amd/csrc).')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError here = ABI mismatch, also loud
+            fn.argtypes = argtypes
+            fn.restype = c_int
+        if handle.mydet_abi_version() != 1:
+            raise MissingHipLibrary('libmydet_hip.so ABI version mismatch; rebuild it')
+        _lib = handle
+    return _lib
+
+
+class MydetError(RuntimeError):
+    pass
+
+
+def check(code, what):
+    if code != 0:
+        kind = {-1: 'bad argument', -2: 'unsupported configuration'}.get(code, f'hipError {code}')
+        raise MydetError(f'{what} failed: {kind}')

@@ -1,0 +1,83 @@
+// First-layer 3x3 convolution, Cin = 3 -> Cout = 32, direct form on the vector ALU.
+//
+// K = 27 is too short for the MFMA tile and the layer is write-bound (each output
+// pixel stores 128 B and reads 108 B of image through L1/L2), so this is a plain
+// per-pixel kernel: a thread owns one output pixel, keeps its 27 taps in registers and
+// walks the 32 output channels; the 864 weights are wave-uniform and are fetched
+// through the scalar cache (s_load), the epilogue (folded BN + activation) is fused and
+// the 32 channels of the pixel are written as eight 16-byte stores (NHWC).
+// It reads the image through arbitrary strides, so the NCHW tensor built at
+// api/detection.py:160-163 is consumed as is (no layout pass).
+// Replaces Darknet53 netlist[0] (models/backbones.py:14) and the EfficientNet stem
+// (models/backbones.py:210, static-SAME pad 0/1 via pad_t/pad_l).
+#include "common.h"
+
+namespace {
+
+struct StemArgs {
+    const float *x, *w, *scale, *shift;
+    float *y;
+    int64_t sxb, sxc, sxh, sxw, ldy;
+    int H, W, stride, pad_t, pad_l, Ho, Wo, act;
+    int64_t M;
+};
+
+__global__ __launch_bounds__(256) void conv_stem_kernel(const StemArgs p) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= p.M) return;
+    const int ow = (int)(m % p.Wo);
+    const int64_t t = m / p.Wo;
+    const int oh = (int)(t % p.Ho);
+    const int64_t b = t / p.Ho;
+    float in[27];                                   // [kh][kw][c], matches the OHWI weight rows
+    const float *xb = p.x + b * p.sxb;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int ih = oh * p.stride - p.pad_t + kh;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int iw = ow * p.stride - p.pad_l + kw;
+            const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                in[(kh * 3 + kw) * 3 + c] = ok ? xb[c * p.sxc + (int64_t)ih * p.sxh + (int64_t)iw * p.sxw] : 0.0f;
+        }
+    }
+    float *yp = p.y + m * p.ldy;
+#pragma unroll
+    for (int n4 = 0; n4 < 8; ++n4) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n4 * 4 + j;
+            const float *wr = p.w + n * 27;         // uniform address -> scalar loads
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 27; ++k) acc = fmaf(in[k], wr[k], acc);
+            const float scl = p.scale ? p.scale[n] : 1.0f;
+            const float sft = p.shift ? p.shift[n] : 0.0f;
+            o[j] = mydet_act(acc * scl + sft, p.act);
+        }
+        *reinterpret_cast<f32x4 *>(yp + n4 * 4) = o;
+    }
+}
+
+}  // namespace
+
+extern "C" int mydet_conv2d_stem_f32(const float *x, int64_t sxb, int64_t sxc, int64_t sxh, int64_t sxw,
+                                     const float *w, const float *scale, const float *shift, float *y,
+                                     int64_t ldy, int B, int H, int W, int Cout, int stride, int pad_t,
+                                     int pad_l, int Ho, int Wo, int act, void *stream) {
+    if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || stride <= 0) return MYDET_E_BADARG;
+    if (Cout != 32) return MYDET_E_UNSUPP;
+    if ((ldy & 3) || ldy < Cout || ((uintptr_t)y & 15)) return MYDET_E_BADARG;
+    StemArgs a;
+    a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.y = y;
+    a.sxb = sxb; a.sxc = sxc; a.sxh = sxh; a.sxw = sxw; a.ldy = ldy;
+    a.H = H; a.W = W; a.stride = stride; a.pad_t = pad_t; a.pad_l = pad_l; a.Ho = Ho; a.Wo = Wo; a.act = act;
+    a.M = (int64_t)B * Ho * Wo;
+    const int64_t blocks = (a.M + 255) / 256;
+    if (blocks > 0x7fffffff) return MYDET_E_BADARG;
+    hipLaunchKernelGGL(conv_stem_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return mydet_launch_status();
+}

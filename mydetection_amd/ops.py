@@ -1,0 +1,191 @@
+"""Torch-tensor front end of the C ABI (include/mydet.h).
+
+PyTorch is plumbing here: tensors are HBM allocations plus the current HIP stream.
+Activations are logical NCHW tensors stored channels-last (physical [B,H,W,ld]) so
+module inputs/outputs have the reference's shapes while kernels see NHWC.
+Every function launches hand-written HIP kernels; no arithmetic falls back to ATen (a
+input in a foreign layout is re-laid out with one tensor copy before the launch).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_LEAKY, ACT_SWISH = 0, 1, 2
+DECODE_YOLO, DECODE_RETINA, DECODE_FCOS = 0, 1, 2
+TOPK = 512
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def require_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f'{what}: tensor is on {t.device}; mydetection_amd runs on MI355X only '
+                           '(there is no CPU path in this package)')
+
+
+def nhwc_ld(x):
+    """Pixel stride of a logical [B,C,H,W] tensor stored as [B,H,W,ld], or None if it is not."""
+    B, C, H, W = x.shape
+    sb, sc, sh, sw = x.stride()
+    if x.dtype != torch.float32 or (C > 1 and sc != 1):
+        return None
+    ld = sw if W > 1 else (sh if H > 1 else (sb if B > 1 else C))
+    if ld < C or ld % 4 or (W > 1 and sw != ld) or (H > 1 and sh != W * ld) or (B > 1 and sb != H * W * ld):
+        return None
+    if x.data_ptr() % 16:
+        return None
+    return ld
+
+
+def to_nhwc(x):
+    """Return (tensor, ld) with the tensor in a kernel-readable channels-last layout."""
+    ld = nhwc_ld(x)
+    if ld is not None:
+        return x, ld
+    B, C, H, W = x.shape
+    Cp = (C + 3) // 4 * 4
+    buf = x.new_zeros((B, H, W, Cp)) if Cp != C else x.new_empty((B, H, W, Cp))
+    buf[..., :C] = x.permute(0, 2, 3, 1)
+    return buf.permute(0, 3, 1, 2)[:, :C], Cp
+
+
+def empty_nhwc(B, C, H, W, device, ld=None):
+    ld = ld or (C + 3) // 4 * 4
+    buf = torch.empty((B, H, W, ld), dtype=torch.float32, device=device)
+    return buf.permute(0, 3, 1, 2)[:, :C], ld
+
+
+def conv_out_size(n, k, stride, pad_lo, pad_hi):
+    return (n + pad_lo + pad_hi - k) // stride + 1
+
+
+def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None, out_ld=None):
+    """y = act(conv(x)*scale + shift) + residual.  x logical [B,Cin,H,W]; pad=(top,left,bottom,right)."""
+    require_gpu(x, 'conv2d')
+    x, ldx = to_nhwc(x)
+    B, Cin, H, W = x.shape
+    Cout = w_ohwi.shape[0]
+    Ho = conv_out_size(H, k, stride, pad[0], pad[2])
+    Wo = conv_out_size(W, k, stride, pad[1], pad[3])
+    if out is None:
+        out, ldy = empty_nhwc(B, Cout, Ho, Wo, x.device, out_ld)
+    else:
+        ldy = nhwc_ld(out)
+        assert ldy is not None and out.shape == (B, Cout, Ho, Wo)
+    ldr = 0
+    if residual is not None:
+        residual, ldr = to_nhwc(residual)
+        assert residual.shape == out.shape
+    code = _lib.lib().mydet_conv2d_igemm_f32(
+        _ptr(x), ldx, _ptr(w_ohwi), _ptr(scale), _ptr(shift), _ptr(residual), ldr, _ptr(out), ldy,
+        B, H, W, Cin, Cout, k, k, stride, pad[0], pad[1], Ho, Wo, act, _stream())
+    _lib.check(code, 'mydet_conv2d_igemm_f32')
+    return out
+
+
+def conv2d_stem(x, w_ohwi, scale, shift, stride, pad, act):
+    """3->32 3x3 first layer; reads x with its own strides (NCHW or channels-last)."""
+    require_gpu(x, 'conv2d_stem')
+    assert x.dtype == torch.float32 and x.shape[1] == 3
+    B, _, H, W = x.shape
+    Cout = w_ohwi.shape[0]
+    Ho = conv_out_size(H, 3, stride, pad[0], pad[2])
+    Wo = conv_out_size(W, 3, stride, pad[1], pad[3])
+    out, ldy = empty_nhwc(B, Cout, Ho, Wo, x.device)
+    sb, sc, sh, sw = x.stride()
+    code = _lib.lib().mydet_conv2d_stem_f32(_ptr(x), sb, sc, sh, sw, _ptr(w_ohwi), _ptr(scale), _ptr(shift),
+                                            _ptr(out), ldy, B, H, W, Cout, stride, pad[0], pad[1], Ho, Wo, act,
+                                            _stream())
+    _lib.check(code, 'mydet_conv2d_stem_f32')
+    return out
+
+
+def upsample_concat(a, size, b=None):
+    """cat((nearest_resize(a, size), b), dim=1) in one pass."""
+    require_gpu(a, 'upsample_concat')
+    a, lda = to_nhwc(a)
+    B, C1, Ha, Wa = a.shape
+    Ho, Wo = size
+    C2, ldb = 0, 0
+    if b is not None:
+        b, ldb = to_nhwc(b)
+        C2 = b.shape[1]
+        assert b.shape[0] == B and tuple(b.shape[2:]) == (Ho, Wo)
+    out, ldy = empty_nhwc(B, C1 + C2, Ho, Wo, a.device)
+    code = _lib.lib().mydet_upsample_concat_f32(_ptr(a), lda, Ha, Wa, C1, _ptr(b), ldb, C2, _ptr(out), ldy, B, Ho,
+                                                Wo, _stream())
+    _lib.check(code, 'mydet_upsample_concat_f32')
+    return out
+
+
+def decode(mode, box, ldbox, box_astride, box_c0, cls, ldcls, cls_astride, cls_c0, conf_c0, anchors_wh, A, C,
+           B, H, W, stride, img_hw, bbox, class_idx, score, n_off):
+    """Decode one level into bbox[B,N,4] / class_idx[B,N] / score[B,N] at candidate offset n_off."""
+    require_gpu(box, 'decode')
+    N = bbox.shape[1]
+    anch = None
+    if anchors_wh is not None:
+        anch = np.ascontiguousarray(np.asarray(anchors_wh, dtype=np.float32).reshape(-1))
+        assert anch.size == 2 * A
+    code = _lib.lib().mydet_decode_f32(
+        mode, _ptr(box), ldbox, box_astride, box_c0, _ptr(cls), ldcls, cls_astride, cls_c0, conf_c0,
+        ctypes.c_void_p(anch.ctypes.data) if anch is not None else ctypes.c_void_p(0), A, C, B, H, W,
+        float(stride), int(img_hw[0]), int(img_hw[1]), _ptr(bbox), _ptr(class_idx), _ptr(score), N, n_off,
+        _stream())
+    _lib.check(code, 'mydet_decode_f32')
+
+
+def postprocess(bbox, class_idx, score, conf_thres, nms_thres, topk=TOPK):
+    """Batched filter/top-k/class-aware NMS.  bbox [B,N,4], class_idx [B,N] i64, score [B,N].
+
+    Returns dict of device tensors: count [B] i32, bbox [B,topk,4], class_idx [B,topk] i64,
+    score [B,topk], index [B,topk] i32.
+    """
+    require_gpu(bbox, 'postprocess')
+    assert bbox.dtype == torch.float32 and score.dtype == torch.float32 and class_idx.dtype == torch.int64
+    bbox, class_idx, score = bbox.contiguous(), class_idx.contiguous(), score.contiguous()
+    B, N = score.shape
+    dev = bbox.device
+    out = {
+        'count': torch.empty((B,), dtype=torch.int32, device=dev),
+        'bbox': torch.empty((B, topk, 4), dtype=torch.float32, device=dev),
+        'class_idx': torch.empty((B, topk), dtype=torch.int64, device=dev),
+        'score': torch.empty((B, topk), dtype=torch.float32, device=dev),
+        'index': torch.empty((B, topk), dtype=torch.int32, device=dev),
+    }
+    scratch = torch.empty((B, max(N, 1)), dtype=torch.int64, device=dev)
+    code = _lib.lib().mydet_postprocess_f32(_ptr(bbox), _ptr(class_idx), _ptr(score), B, N, float(conf_thres),
+                                            float(nms_thres), topk, _ptr(out['count']), _ptr(out['bbox']),
+                                            _ptr(out['class_idx']), _ptr(out['score']), _ptr(out['index']),
+                                            _ptr(scratch), _stream())
+    _lib.check(code, 'mydet_postprocess_f32')
+    return out
+
+
+def bboxes_iou(a, b, xyxy=False):
+    require_gpu(a, 'bboxes_iou')
+    a, b = a.contiguous().float(), b.contiguous().float()
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    code = _lib.lib().mydet_bboxes_iou_f32(_ptr(a), a.shape[0], _ptr(b), b.shape[0], 1 if xyxy else 0, _ptr(out),
+                                           _stream())
+    _lib.check(code, 'mydet_bboxes_iou_f32')
+    return out
+
+
+def bboxes_to_original_(bbox, pad_info):
+    require_gpu(bbox, 'bboxes_to_original_')
+    assert bbox.is_contiguous() and bbox.dtype == torch.float32 and bbox.shape[-1] == 4
+    ori_w, ori_h, tl_x, tl_y, imw, imh = [float(v) for v in pad_info]
+    code = _lib.lib().mydet_bboxes_to_original_f32(_ptr(bbox), bbox.shape[0], ori_w, ori_h, tl_x, tl_y, imw, imh,
+                                                   _stream())
+    _lib.check(code, 'mydet_bboxes_to_original_f32')
+    return bbox

@@ -1,0 +1,29 @@
+"""Box ops named by the hot path (reference: utils/bbox_ops.py:6-49, 309-316)."""
+import torch
+
+from .. import ops
+
+
+def bboxes_iou(bboxes_a, bboxes_b, xyxy=False):
+    """Pairwise IoU [N,K] on the GPU, same arithmetic as the reference (chainercv form:
+    intersection zeroed unless tl < br on both axes; no clamp, no epsilon)."""
+    if bboxes_a.dim() == 1:
+        bboxes_a = bboxes_a.unsqueeze(0)
+    assert bboxes_a.dim() == bboxes_b.dim() == 2
+    if bboxes_a.shape[1] != 4 or bboxes_b.shape[1] != 4:
+        raise IndexError()
+    if not bboxes_a.is_cuda:
+        if not torch.cuda.is_available():
+            raise RuntimeError('bboxes_iou runs on MI355X only; no GPU is visible')
+        bboxes_a, bboxes_b = bboxes_a.cuda(), bboxes_b.cuda()
+    return ops.bboxes_iou(bboxes_a, bboxes_b.to(bboxes_a.device), xyxy=xyxy)
+
+
+def cxcywh_to_x1y1x2y2(cxcywh: torch.tensor) -> torch.tensor:
+    assert cxcywh.shape[-1] >= 4
+    x1y1x2y2 = cxcywh.clone()
+    x1y1x2y2[..., 0] = (cxcywh[..., 0] - cxcywh[..., 2] / 2)
+    x1y1x2y2[..., 1] = (cxcywh[..., 1] - cxcywh[..., 3] / 2)
+    x1y1x2y2[..., 2] = (cxcywh[..., 0] + cxcywh[..., 2] / 2)
+    x1y1x2y2[..., 3] = (cxcywh[..., 1] + cxcywh[..., 3] / 2)
+    return x1y1x2y2

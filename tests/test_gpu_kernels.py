@@ -1,0 +1,236 @@
+"""GPU parity: each HIP kernel, called through the C ABI (mydetection_amd.ops -> ctypes), against
+the CPU oracle / committed golden vectors on the same seeded inputs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    from mydetection_amd import _lib
+    _lib.lib()                                   # fail loudly if the HIP library is missing
+    return torch.device('cuda:0')
+
+
+def _conv_case(dev, B, Cin, Cout, k, s, H, W, act, residual=False, bias_only=False, pad=None, seed=0):
+    from mydetection_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    scale = None if bias_only else torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g) * 0.1
+    pad = pad or ((k - 1) // 2,) * 4                      # (top, left, bottom, right)
+    xp = F.pad(x, (pad[1], pad[3], pad[0], pad[2]))
+    ref = F.conv2d(xp.double(), w.double(), None, s)
+    ref = ref * (scale.double().view(1, -1, 1, 1) if scale is not None else 1.0) + shift.double().view(1, -1, 1, 1)
+    if act == 1:
+        ref = F.leaky_relu(ref, 0.1)
+    elif act == 2:
+        ref = ref * torch.sigmoid(ref)
+    res = None
+    if residual:
+        res = torch.randn(ref.shape, generator=g)
+        ref = ref + res.double()
+    y = ops.conv2d(x.to(dev).contiguous(memory_format=torch.channels_last), w.permute(0, 2, 3, 1).contiguous().to(dev),
+                   scale.to(dev) if scale is not None else None, shift.to(dev), k, s, pad, act,
+                   residual=res.to(dev).contiguous(memory_format=torch.channels_last) if residual else None)
+    assert tuple(y.shape) == tuple(ref.shape)
+    err = (y.cpu().double() - ref).abs().max().item()
+    tol = 2e-5 * max(1.0, ref.abs().max().item())
+    assert err <= tol, f'conv mismatch {err} > {tol}'
+
+
+@pytest.mark.parametrize('case', [
+    dict(B=2, Cin=32, Cout=64, k=3, s=2, H=32, W=32, act=1),                   # stride-2 downsample
+    dict(B=2, Cin=64, Cout=32, k=1, s=1, H=16, W=24, act=1),                   # DarkBlock 1x1, BN=32 tile
+    dict(B=1, Cin=32, Cout=64, k=3, s=1, H=16, W=16, act=1, residual=True),    # DarkBlock 3x3 + residual
+    dict(B=2, Cin=128, Cout=256, k=3, s=1, H=20, W=20, act=1, residual=True),  # 128x128 / 128x64 tiles
+    dict(B=3, Cin=256, Cout=255, k=1, s=1, H=13, W=11, act=0, bias_only=True), # YOLO head: ragged M and N
+    dict(B=1, Cin=768, Cout=256, k=1, s=1, H=8, W=8, act=1),                   # FPN concat input, small M
+    dict(B=4, Cin=512, Cout=1024, k=3, s=1, H=10, W=10, act=1),                # deep K = 4608
+    dict(B=2, Cin=24, Cout=144, k=1, s=1, H=12, W=12, act=2),                  # generic-K path (Cin % 32 != 0), swish
+    dict(B=1, Cin=88, Cout=88, k=3, s=1, H=10, W=10, act=0, bias_only=True),   # generic-K 3x3
+    dict(B=1, Cin=32, Cout=32, k=3, s=2, H=16, W=16, act=2, pad=(0, 0, 1, 1)), # static-SAME asymmetric pad
+    dict(B=32, Cin=64, Cout=128, k=3, s=2, H=64, W=64, act=1),                 # big grid (XCD remap path)
+])
+def test_conv_igemm_vs_fp64(dev, case):
+    _conv_case(dev, **case)
+
+
+def test_conv_igemm_output_slice_and_padded_ld(dev):
+    """ldy > Cout (head padding) must leave the pad lanes untouched and slices view correctly."""
+    from mydetection_amd import ops
+    x = torch.randn(1, 64, 8, 8).to(dev).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(30, 64, 1, 1)
+    y = ops.conv2d(x, w.permute(0, 2, 3, 1).contiguous().to(dev), None, None, 1, 1, (0, 0, 0, 0), 0)
+    assert y.shape == (1, 30, 8, 8) and ops.nhwc_ld(y) == 32
+    ref = F.conv2d(x.cpu().double(), w.double())
+    assert (y.cpu().double() - ref).abs().max() < 1e-4
+
+
+def test_conv_stem(dev):
+    from mydetection_amd import ops
+    g = torch.Generator().manual_seed(1)
+    for layout in ('nchw', 'nhwc'):
+        for s, pad in ((1, (1, 1, 1, 1)), (2, (0, 0, 1, 1))):
+            x = torch.rand(2, 3, 34, 38, generator=g)
+            w = torch.randn(32, 3, 3, 3, generator=g) * 0.2
+            scale, shift = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.1
+            xp = F.pad(x, (pad[1], pad[3], pad[0], pad[2]))
+            ref = F.conv2d(xp.double(), w.double(), None, s) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+            ref = F.leaky_relu(ref, 0.1)
+            xd = x.to(dev)
+            if layout == 'nhwc':
+                xd = xd.contiguous(memory_format=torch.channels_last)
+            y = ops.conv2d_stem(xd, w.permute(0, 2, 3, 1).contiguous().to(dev), scale.to(dev), shift.to(dev), s, pad, 1)
+            assert (y.cpu().double() - ref).abs().max() < 1e-5
+
+
+def test_upsample_concat(dev):
+    from mydetection_amd import ops
+    a = torch.randn(2, 8, 5, 7)
+    b = torch.randn(2, 12, 10, 14)
+    y = ops.upsample_concat(a.to(dev), (10, 14), b.to(dev))
+    ref = torch.cat((F.interpolate(a, size=(10, 14), mode='nearest'), b), dim=1)
+    assert torch.equal(y.cpu(), ref)
+    y2 = ops.upsample_concat(a.to(dev), (9, 13))                  # non-integer scale, no concat
+    assert torch.equal(y2.cpu(), F.interpolate(a, size=(9, 13), mode='nearest'))
+
+
+def test_bboxes_iou_golden(dev, golden):
+    from mydetection_amd.utils.bbox_ops import bboxes_iou
+    g = golden('bbox_ops')
+    out = bboxes_iou(torch.from_numpy(g['a']).to(dev), torch.from_numpy(g['b']).to(dev), xyxy=False)
+    np.testing.assert_array_equal(out.cpu().numpy(), g['iou_cxcywh'])
+    out = bboxes_iou(torch.from_numpy(g['a_xyxy']).to(dev), torch.from_numpy(g['b_xyxy']).to(dev), xyxy=True)
+    np.testing.assert_array_equal(out.cpu().numpy(), g['iou_xyxy'])
+
+
+def _yolo_cfg():
+    from mydetection_amd.models.general import load_config
+    cfg = load_config('yolov3_80')
+    cfg['model.fpn.out_strides'] = (8, 16, 32)
+    cfg['model.fpn.out_channels'] = (256, 512, 1024)
+    return cfg
+
+
+def test_yolo_decode_golden(dev, golden):
+    """Reference det-layer outputs (imported reference, tests/golden/detlayers.npz); class ids exact,
+    boxes/scores to float32 round-off of exp/sigmoid."""
+    from mydetection_amd.models.registry import get_det_layer
+    g = golden('detlayers')
+    cfg = _yolo_cfg()
+    for lvl in (0, 1, 2):
+        conv = torch.from_numpy(g[f'yolo_{lvl}_in']).to(dev)
+        v = conv.view(conv.shape[0], 3, 85, *conv.shape[2:])
+        raw = {'bbox': v[:, :, 0:4].permute(0, 1, 3, 4, 2), 'conf': v[:, :, 4:5].permute(0, 1, 3, 4, 2),
+               'class': v[:, :, 5:].permute(0, 1, 3, 4, 2)}
+        layer = get_det_layer(cfg)(level_i=lvl, cfg=cfg)
+        p, loss = layer(raw, tuple(int(t) for t in g[f'yolo_{lvl}_img']), None)
+        assert loss is None
+        np.testing.assert_array_equal(p['class_idx'].cpu().numpy(), g[f'yolo_{lvl}_class_idx'])
+        np.testing.assert_allclose(p['score'].cpu().numpy(), g[f'yolo_{lvl}_score'], rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(p['bbox'].cpu().numpy(), g[f'yolo_{lvl}_bbox'], rtol=2e-6, atol=1e-6)
+
+
+def test_retina_fcos_decode_golden(dev, golden):
+    from mydetection_amd import ops
+    from mydetection_amd.models.detlayers._common import alloc_outputs, pack_pixel_major
+    g = golden('detlayers')
+    strides = [8, 16, 32, 64, 128]
+    for lvl in (0, 3):
+        bb_in = torch.from_numpy(g[f'retina_{lvl}_bbox_in']).to(dev)
+        cl_in = torch.from_numpy(g[f'retina_{lvl}_class_in']).to(dev)
+        B, A, H, W, _ = bb_in.shape
+        box, ldb, _ = pack_pixel_major([bb_in], A)
+        cls, ldc, _ = pack_pixel_major([cl_in], A)
+        out = alloc_outputs(B, A * H * W, dev)
+        ops.decode(ops.DECODE_RETINA, box, ldb, 4, 0, cls, ldc, 80, 0, 0, g[f'retina_{lvl}_anchor_wh'], A, 80, B, H, W,
+                   strides[lvl], tuple(int(t) for t in g[f'retina_{lvl}_img']), *out, 0)
+        np.testing.assert_array_equal(out[1].cpu().numpy(), g[f'retina_{lvl}_class_idx'])
+        np.testing.assert_allclose(out[2].cpu().numpy(), g[f'retina_{lvl}_score'], rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(out[0].cpu().numpy(), g[f'retina_{lvl}_bbox'], rtol=2e-6, atol=1e-6)
+    for lvl in (0, 2):
+        bb_in = torch.from_numpy(g[f'fcos_{lvl}_bbox_in']).to(dev)
+        cf_in = torch.from_numpy(g[f'fcos_{lvl}_conf_in']).to(dev)
+        cl_in = torch.from_numpy(g[f'fcos_{lvl}_class_in']).to(dev)
+        B, H, W, _ = bb_in.shape
+        box, ldb, _ = pack_pixel_major([bb_in], 1)
+        cls, ldc, per = pack_pixel_major([cf_in, cl_in], 1)          # conf at channel 0, classes 1..80
+        out = alloc_outputs(B, H * W, dev)
+        ops.decode(ops.DECODE_FCOS, box, ldb, 4, 0, cls, ldc, per, 1, 0, None, 1, 80, B, H, W, strides[lvl],
+                   tuple(int(t) for t in g[f'fcos_{lvl}_img']), *out, 0)
+        np.testing.assert_array_equal(out[1].cpu().numpy(), g[f'fcos_{lvl}_class_idx'])
+        np.testing.assert_allclose(out[2].cpu().numpy(), g[f'fcos_{lvl}_score'], rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(out[0].cpu().numpy(), g[f'fcos_{lvl}_bbox'], rtol=2e-6, atol=1e-5)
+
+
+def test_post_process_golden_bit_exact(dev, golden):
+    """Filter/top-k/NMS on the reference's exact candidates: kept boxes, classes, scores and their
+    order must be identical (integer/index work: bit-exact)."""
+    from mydetection_amd.utils.structures import ImageObjects
+    from oracle import postprocess as pp
+    g = golden('postprocess')
+    for name in g['names']:
+        b, c, s = g[f'{name}_in_bboxes'], g[f'{name}_in_cats'], g[f'{name}_in_scores']
+        conf, nms = float(g[f'{name}_conf']), float(g[f'{name}_nms'])
+        d = ImageObjects(torch.from_numpy(b).to(dev), torch.from_numpy(c).to(dev), None, torch.from_numpy(s).to(dev),
+                         'cxcywh', (512, 512))
+        r = d.post_process(conf, nms)
+        np.testing.assert_array_equal(r.cats.cpu().numpy(), g[f'{name}_cats'], err_msg=name)
+        np.testing.assert_array_equal(r.scores.cpu().numpy(), g[f'{name}_scores'], err_msg=name)
+        np.testing.assert_array_equal(r.bboxes.cpu().numpy(), g[f'{name}_bboxes'], err_msg=name)
+        # candidate indices vs the oracle
+        from mydetection_amd import ops
+        if len(s):
+            rec = ops.postprocess(d.bboxes[None], d.cats[None], d.scores[None], conf, nms)
+            k = int(rec['count'][0])
+            _, _, _, src = pp.post_process(b, c, s, conf, nms)
+            np.testing.assert_array_equal(rec['index'][0, :k].cpu().numpy().astype(np.int64), src, err_msg=name)
+            assert int(rec['index'][0, k:].abs().sum()) == 0
+
+
+def test_post_process_batched_random_vs_oracle(dev):
+    from mydetection_amd import ops
+    from oracle import postprocess as pp
+    rng = np.random.Generator(np.random.PCG64(11))
+    B, N = 6, 9000
+    b = np.empty((B, N, 4), np.float32)
+    b[..., :2] = rng.random((B, N, 2), dtype=np.float32) * 200
+    b[..., 2:] = rng.random((B, N, 2), dtype=np.float32) * 80 + 1
+    c = rng.integers(0, 7, size=(B, N)).astype(np.int64)
+    s = rng.random((B, N), dtype=np.float32)
+    s[1] *= 0.01                                   # image 1: almost nothing passes
+    s[2, 5:] = 0                                   # image 2: 5 candidates
+    s[3, 100:300] = s[3, 50]                       # image 3: 200-way score tie at the top-k boundary region
+    rec = ops.postprocess(torch.from_numpy(b).to(dev), torch.from_numpy(c).to(dev), torch.from_numpy(s).to(dev), 0.3, 0.4)
+    for i in range(B):
+        ob, oc, os_, src = pp.post_process(b[i], c[i], s[i], 0.3, 0.4)
+        k = int(rec['count'][i])
+        assert k == len(src)
+        np.testing.assert_array_equal(rec['index'][i, :k].cpu().numpy().astype(np.int64), src)
+        np.testing.assert_array_equal(rec['class_idx'][i, :k].cpu().numpy(), oc)
+        np.testing.assert_array_equal(rec['score'][i, :k].cpu().numpy(), os_)
+        np.testing.assert_array_equal(rec['bbox'][i, :k].cpu().numpy(), ob)
+
+
+def test_nms_standalone_and_to_original(dev, golden):
+    from mydetection_amd.utils.structures import ImageObjects
+    from oracle import postprocess as pp
+    g = golden('postprocess')
+    b, c, s = (g[f'three_class_dense_in_{k}'] for k in ('bboxes', 'cats', 'scores'))
+    d = ImageObjects(torch.from_numpy(b).to(dev), torch.from_numpy(c).to(dev), None, torch.from_numpy(s).to(dev))
+    r = d.nms(0.3)
+    keep = pp.class_aware_nms(b, c, s, 0.3)
+    np.testing.assert_array_equal(r.scores.cpu().numpy(), s[keep])
+    np.testing.assert_array_equal(r.cats.cpu().numpy(), c[keep])
+    d2 = ImageObjects(torch.from_numpy(b.copy()).to(dev), torch.from_numpy(c).to(dev), None, torch.from_numpy(s).to(dev),
+                      'cxcywh', (64, 64))
+    pad_info = tuple(int(v) for v in g['to_original_pad_info'])
+    d2.bboxes_to_original_(pad_info)
+    np.testing.assert_array_equal(d2.bboxes.cpu().numpy(), g['to_original_bboxes'])
+    assert d2.img_hw == (pad_info[1], pad_info[0])

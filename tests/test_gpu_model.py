@@ -1,0 +1,130 @@
+"""GPU parity of the assembled YOLOv3-80 path through the drop-in surface
+(models.general.name_to_model / registry factories / ImageObjects.post_process) against the golden
+vectors produced by the imported reference (batch 1, 512x512 = BASELINE configs[0]) and, at larger
+sizes, against the CPU oracle and size-independent properties."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-4, 1e-4        # north_star: boxes/scores within 1e-4 fp32 (allclose(1e-4, 1e-4))
+
+
+@pytest.fixture(scope='module')
+def model():
+    assert torch.cuda.is_available()
+    from mydetection_amd import synth
+    from mydetection_amd.models.general import name_to_model
+    m, cfg = name_to_model('yolov3_80')
+    m.load_state_dict(synth.make_state_dict(m.state_dict()), strict=True)
+    return m.eval().cuda(), cfg
+
+
+def test_stage_parity_vs_reference_golden(model, golden):
+    from mydetection_amd import synth
+    m, cfg = model
+    g = golden('yolov3_b1_512')
+    x = synth.make_images(int(g['batch']), int(g['size']), seed=int(g['image_seed'])).cuda()
+    with torch.no_grad():
+        c = m.backbone(x)
+        p = m.fpn(c)
+        raws = m.rpn(p)
+    for key, feats in (('backbone', c), ('fpn', p)):
+        for lvl, f in enumerate(feats):
+            assert tuple(g[f'{key}_{lvl}_shape']) == tuple(f.shape)
+            f = f.contiguous().cpu().numpy()                      # logical NCHW order
+            np.testing.assert_allclose(f.reshape(-1)[g[f'{key}_{lvl}_idx']], g[f'{key}_{lvl}_val'], rtol=RTOL, atol=ATOL)
+            np.testing.assert_allclose(np.sqrt((f.astype(np.float64) ** 2).sum()), g[f'{key}_{lvl}_l2'], rtol=1e-5)
+    for lvl, raw in enumerate(raws):
+        head = raw.packed[0].contiguous().cpu().numpy()          # [B,255,H,W]
+        assert tuple(g[f'head_{lvl}_shape']) == head.shape
+        np.testing.assert_allclose(head.reshape(-1)[g[f'head_{lvl}_idx']], g[f'head_{lvl}_val'], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(raws[2].packed[0].contiguous().cpu().numpy(), g['head_2_full'], rtol=RTOL, atol=ATOL)
+    # reference-shaped raw views
+    assert raws[0]['bbox'].shape == (1, 3, 64, 64, 4) and raws[0]['class'].shape == (1, 3, 64, 64, 80)
+
+
+def test_end_to_end_vs_reference_golden(model, golden):
+    from mydetection_amd import synth
+    m, cfg = model
+    g = golden('yolov3_b1_512')
+    x = synth.make_images(1, 512, seed=0).cuda()
+    with torch.no_grad():
+        dts = m(x)
+    assert len(dts) == 1
+    d = dts[0]
+    assert d.bboxes.shape == (16128, 4) and d.cats.dtype == torch.int64
+    cats, scores, boxes = d.cats.cpu().numpy(), d.scores.cpu().numpy(), d.bboxes.cpu().numpy()
+    np.testing.assert_allclose(scores, g['scores_0'], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(boxes, g['bboxes_0'], rtol=RTOL, atol=ATOL)
+    # class ids: exact wherever the reference's top-2 class logits are not within round-off of each other
+    mism = np.nonzero(cats != g['cats_0'])[0]
+    assert len(mism) <= 2, f'{len(mism)} class-id mismatches'
+    # post-processing at the three reference settings
+    for tag in ('ap', 'mid', 'demo'):
+        r = d.post_process(float(g[f'pp_{tag}_conf']), float(g[f'pp_{tag}_nms']))
+        ref_c, ref_s, ref_b = g[f'pp_{tag}_cats_0'], g[f'pp_{tag}_scores_0'], g[f'pp_{tag}_bboxes_0']
+        assert len(r) == len(ref_c), f'{tag}: {len(r)} vs {len(ref_c)} detections'
+        np.testing.assert_array_equal(r.cats.cpu().numpy(), ref_c)
+        np.testing.assert_allclose(r.scores.cpu().numpy(), ref_s, rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(r.bboxes.cpu().numpy(), ref_b, rtol=RTOL, atol=ATOL)
+
+
+def test_batch_consistency_and_post_process_vs_oracle(model):
+    """Batch of 3 at 256x320: every image equals its single-image run bit for bit (no cross-image
+    coupling), and post-processing of the GPU candidates equals the oracle's on the same candidates."""
+    from mydetection_amd import synth
+    from mydetection_amd.utils.structures import batched_post_process
+    from oracle import postprocess as pp
+    m, cfg = model
+    x = synth.make_images(3, (256, 320), seed=3).cuda()
+    with torch.no_grad():
+        bb, ci, sc = m.forward_candidates(x)
+        for i in range(3):
+            b1, c1, s1 = m.forward_candidates(x[i:i + 1])
+            assert torch.equal(b1[0], bb[i]) and torch.equal(c1[0], ci[i]) and torch.equal(s1[0], sc[i])
+    rec = batched_post_process(bb, ci, sc, 0.005, 0.45)
+    for i in range(3):
+        ob, oc, os_, src = pp.post_process(bb[i].cpu().numpy(), ci[i].cpu().numpy(), sc[i].cpu().numpy(), 0.005, 0.45)
+        k = int(rec['count'][i])
+        assert k == len(src)
+        np.testing.assert_array_equal(rec['index'][i, :k].cpu().numpy().astype(np.int64), src)
+        np.testing.assert_array_equal(rec['class_idx'][i, :k].cpu().numpy(), oc)
+        np.testing.assert_array_equal(rec['bbox'][i, :k].cpu().numpy(), ob)
+
+
+def test_forward_vs_oracle_640_batch2(model):
+    """640x640 (the benchmark resolution), batch 2, against the CPU oracle forward."""
+    from mydetection_amd import synth
+    from oracle import yolov3 as oy
+    m, cfg = model
+    x = synth.make_images(2, 640, seed=5)
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    with torch.no_grad():
+        ob, oc, os_ = oy.forward(x, sd)
+        bb, ci, sc = m.forward_candidates(x.cuda())
+    assert bb.shape == (2, 25200, 4)
+    np.testing.assert_allclose(sc.cpu().numpy(), os_.numpy(), rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(bb.cpu().numpy(), ob.numpy(), rtol=RTOL, atol=ATOL)
+    assert (ci.cpu() != oc).sum().item() <= 4
+
+
+def test_detector_api(model, tmp_path):
+    """api.detection.Detector on a PIL image: plumbing (preprocess, forward, post_process, box rescale, json)."""
+    import PIL.Image
+    from mydetection_amd import synth
+    from mydetection_amd.api import Detector
+    m, cfg = model
+    det = Detector(model_and_cfg=(m, cfg))
+    img = (synth.make_images(1, (300, 400), seed=9)[0].permute(1, 2, 0).numpy() * 255).astype(np.uint8)
+    path = tmp_path / '17.png'
+    PIL.Image.fromarray(img).save(path)
+    dts = det.detect_one(img_path=str(path), input_size=320, conf_thres=0.005)
+    assert dts.img_hw == (300, 400)
+    js = dts.to_json(img_id=17)
+    assert len(js) == len(dts) > 0
+    assert set(js[0]) == {'image_id', 'category_id', 'bbox', 'score'}
+    with pytest.raises(Exception):
+        det.detect_one(pil_img=PIL.Image.fromarray(img), preprocessing='bogus')
