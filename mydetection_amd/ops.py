@@ -22,6 +22,33 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class KernelTimer:
+    """Optional per-launch timing with HIP events recorded on the launch stream (bench.py uses it to
+    price the dominant kernel inside the timed region).  Disabled (None) by default: zero overhead."""
+
+    def __init__(self):
+        self.spans = {}
+
+    def start(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()                      # torch's current stream == the stream handed to the C ABI
+        return ev
+
+    def stop(self, name, start_ev, work=0.0):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.spans.setdefault(name, []).append((start_ev, ev, work))
+
+    def summary(self):
+        """name -> (launches, total_ms, total_work); call after torch.cuda.synchronize()."""
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b, _ in v), sum(w for _, _, w in v))
+                for k, v in self.spans.items()}
+
+
+TIMER = None        # set to a KernelTimer() to record
+TIMER_DETAIL = False  # name conv launches by shape (tools/profile_layers.py)
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
@@ -85,9 +112,13 @@ def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None
     if residual is not None:
         residual, ldr = to_nhwc(residual)
         assert residual.shape == out.shape
+    t0 = TIMER.start() if TIMER else None
     code = _lib.lib().mydet_conv2d_igemm_f32(
         _ptr(x), ldx, _ptr(w_ohwi), _ptr(scale), _ptr(shift), _ptr(residual), ldr, _ptr(out), ldy,
         B, H, W, Cin, Cout, k, k, stride, pad[0], pad[1], Ho, Wo, act, _stream())
+    if t0:
+        name = f'conv_igemm {Cin}->{Cout} k{k}s{stride} {H}x{W}' if TIMER_DETAIL else 'conv_igemm'
+        TIMER.stop(name, t0, 2.0 * B * Ho * Wo * Cout * k * k * Cin)
     _lib.check(code, 'mydet_conv2d_igemm_f32')
     return out
 
@@ -102,9 +133,12 @@ def conv2d_stem(x, w_ohwi, scale, shift, stride, pad, act):
     Wo = conv_out_size(W, 3, stride, pad[1], pad[3])
     out, ldy = empty_nhwc(B, Cout, Ho, Wo, x.device)
     sb, sc, sh, sw = x.stride()
+    t0 = TIMER.start() if TIMER else None
     code = _lib.lib().mydet_conv2d_stem_f32(_ptr(x), sb, sc, sh, sw, _ptr(w_ohwi), _ptr(scale), _ptr(shift),
                                             _ptr(out), ldy, B, H, W, Cout, stride, pad[0], pad[1], Ho, Wo, act,
                                             _stream())
+    if t0:
+        TIMER.stop('conv_stem', t0, 4.0 * B * (3 * H * W + Cout * Ho * Wo))        # bytes moved
     _lib.check(code, 'mydet_conv2d_stem_f32')
     return out
 
@@ -121,8 +155,11 @@ def upsample_concat(a, size, b=None):
         C2 = b.shape[1]
         assert b.shape[0] == B and tuple(b.shape[2:]) == (Ho, Wo)
     out, ldy = empty_nhwc(B, C1 + C2, Ho, Wo, a.device)
+    t0 = TIMER.start() if TIMER else None
     code = _lib.lib().mydet_upsample_concat_f32(_ptr(a), lda, Ha, Wa, C1, _ptr(b), ldb, C2, _ptr(out), ldy, B, Ho,
                                                 Wo, _stream())
+    if t0:
+        TIMER.stop('upsample_concat', t0, 4.0 * B * (C1 * Ha * Wa + C2 * Ho * Wo + (C1 + C2) * Ho * Wo))
     _lib.check(code, 'mydet_upsample_concat_f32')
     return out
 
@@ -136,11 +173,15 @@ def decode(mode, box, ldbox, box_astride, box_c0, cls, ldcls, cls_astride, cls_c
     if anchors_wh is not None:
         anch = np.ascontiguousarray(np.asarray(anchors_wh, dtype=np.float32).reshape(-1))
         assert anch.size == 2 * A
+    t0 = TIMER.start() if TIMER else None
     code = _lib.lib().mydet_decode_f32(
         mode, _ptr(box), ldbox, box_astride, box_c0, _ptr(cls), ldcls, cls_astride, cls_c0, conf_c0,
         ctypes.c_void_p(anch.ctypes.data) if anch is not None else ctypes.c_void_p(0), A, C, B, H, W,
         float(stride), int(img_hw[0]), int(img_hw[1]), _ptr(bbox), _ptr(class_idx), _ptr(score), N, n_off,
         _stream())
+    if t0:      # algorithmic bytes: every head logit once + 28 B per candidate
+        per_pix = A * (C + 4 + (0 if mode == DECODE_RETINA else 1))
+        TIMER.stop('decode', t0, 4.0 * B * H * W * per_pix + 28.0 * B * A * H * W)
     _lib.check(code, 'mydet_decode_f32')
 
 
@@ -163,10 +204,13 @@ def postprocess(bbox, class_idx, score, conf_thres, nms_thres, topk=TOPK):
         'index': torch.empty((B, topk), dtype=torch.int32, device=dev),
     }
     scratch = torch.empty((B, max(N, 1)), dtype=torch.int64, device=dev)
+    t0 = TIMER.start() if TIMER else None
     code = _lib.lib().mydet_postprocess_f32(_ptr(bbox), _ptr(class_idx), _ptr(score), B, N, float(conf_thres),
                                             float(nms_thres), topk, _ptr(out['count']), _ptr(out['bbox']),
                                             _ptr(out['class_idx']), _ptr(out['score']), _ptr(out['index']),
                                             _ptr(scratch), _stream())
+    if t0:
+        TIMER.stop('postprocess', t0, float(B))
     _lib.check(code, 'mydet_postprocess_f32')
     return out
 

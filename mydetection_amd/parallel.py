@@ -1,0 +1,63 @@
+"""Data-parallel inference over the GPUs of one node (no reference counterpart: the reference is
+single-process, single-device).
+
+Images are independent (`post_process` is per image, utils/structures.py:92), so a batch is split
+into contiguous shards, one process per GPU runs backbone -> NMS locally, and the only exchange is
+ONE all-gather (RCCL over xGMI; `nccl` backend) of fixed-size detection records:
+    per image  count:i32 | 512 x (cx,cy,w,h:f32) | 512 x score:f32 | 512 x class:i32 | 512 x index:i32
+  = 3585 words = 14 340 B.  32 images/GPU -> 459 KB per rank: latency-bound, one collective, no reduce.
+"""
+import torch
+import torch.distributed as dist
+
+TOPK = 512
+WORDS = 1 + TOPK * 4 + TOPK * 3
+
+
+def shard_range(total, rank, world):
+    """Contiguous shard [lo, hi) of `total` images for `rank`; sizes differ by at most one."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pack_records(rec):
+    """dict of tensors (ops.postprocess output) -> int32 [B, WORDS] wire buffer."""
+    B = rec['count'].shape[0]
+    buf = torch.empty((B, WORDS), dtype=torch.int32, device=rec['count'].device)
+    buf[:, 0] = rec['count']
+    o = 1
+    buf[:, o:o + TOPK * 4] = rec['bbox'].reshape(B, TOPK * 4).view(torch.int32); o += TOPK * 4
+    buf[:, o:o + TOPK] = rec['score'].view(torch.int32); o += TOPK
+    buf[:, o:o + TOPK] = rec['class_idx'].to(torch.int32); o += TOPK
+    buf[:, o:o + TOPK] = rec['index']
+    return buf
+
+
+def unpack_records(buf):
+    B = buf.shape[0]
+    o = 1
+    bbox = buf[:, o:o + TOPK * 4].contiguous().view(torch.float32).reshape(B, TOPK, 4); o += TOPK * 4
+    score = buf[:, o:o + TOPK].contiguous().view(torch.float32); o += TOPK
+    cls = buf[:, o:o + TOPK].to(torch.int64); o += TOPK
+    index = buf[:, o:o + TOPK].contiguous()
+    return {'count': buf[:, 0].contiguous(), 'bbox': bbox, 'class_idx': cls, 'score': score, 'index': index}
+
+
+def gather_detections(rec, group=None):
+    """All ranks end up with the records of the whole batch in rank order (equal shard sizes)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return rec
+    buf = pack_records(rec)
+    world = dist.get_world_size(group)
+    out = torch.empty((world * buf.shape[0], WORDS), dtype=torch.int32, device=buf.device)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    return unpack_records(out)
+
+
+def records_to_objects(rec, img_hw=None, bb_format='cxcywh'):
+    """Fixed-size records -> List[ImageObjects] (one host sync for the counts)."""
+    from .utils.structures import ImageObjects
+    counts = rec['count'].cpu().tolist()
+    return [ImageObjects(rec['bbox'][b, :k], rec['class_idx'][b, :k], None, rec['score'][b, :k], bb_format, img_hw)
+            for b, k in enumerate(counts)]

@@ -1,0 +1,41 @@
+"""Per-layer timing of the YOLOv3-80 conv launches (HIP events), batch 32 640x640 by default.
+    python tools/profile_layers.py [--batch 32] [--size 640] [--reps 5]
+Prints one line per distinct conv shape: launches, ms per launch, TFLOP/s, fraction of FP32 MFMA peak."""
+import argparse
+import contextlib
+import io
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mydetection_amd import ops, synth                                    # noqa: E402
+from mydetection_amd.models.general import name_to_model                 # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--batch', type=int, default=32)
+ap.add_argument('--size', type=int, default=640)
+ap.add_argument('--reps', type=int, default=5)
+a = ap.parse_args()
+with contextlib.redirect_stdout(io.StringIO()):
+    model, cfg = name_to_model('yolov3_80')
+model.load_state_dict(synth.make_state_dict(model.state_dict()))
+model = model.eval().cuda()
+x = synth.make_images(a.batch, a.size, seed=0).cuda()
+with torch.no_grad():
+    for _ in range(2):
+        model.forward_candidates(x)
+    torch.cuda.synchronize()
+    ops.TIMER, ops.TIMER_DETAIL = ops.KernelTimer(), True
+    for _ in range(a.reps):
+        model.forward_candidates(x)
+    torch.cuda.synchronize()
+summ = ops.TIMER.summary()
+tot_ms = sum(v[1] for v in summ.values()) / a.reps
+print(f'{"kernel":44s} {"n/step":>6s} {"ms/launch":>10s} {"ms/step":>8s} {"%step":>6s} {"TFLOP/s":>8s} {"%peak":>6s}')
+for k, (n, ms, work) in sorted(summ.items(), key=lambda kv: -kv[1][1]):
+    per = ms / n
+    tf = work / n / (per * 1e-3) / 1e12 if k.startswith('conv_igemm') else float('nan')
+    print(f'{k:44s} {n / a.reps:6.0f} {per:10.4f} {ms / a.reps:8.3f} {100 * ms / a.reps / tot_ms:6.1f} {tf:8.1f} {100 * tf / 157.3:6.1f}')
+print(f'total kernel ms/step {tot_ms:.3f}')
