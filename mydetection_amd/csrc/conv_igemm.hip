@@ -8,10 +8,16 @@
 // One 256-thread workgroup (4 waves) owns a BM x BN output tile; each wave a
 // (BM/WM) x (BN/WN) sub-tile built from 32x32 v_mfma_f32_32x32x2_f32 blocks, i.e. exact
 // float32 products and a k-ordered float32 fma chain (no reduced-precision path exists
-// on gfx950).  K is walked in steps of 32: the A and B slabs are staged global ->
-// registers -> LDS (rows padded to 36 floats so ds_read_b128 fragment reads and
-// ds_write_b128 staging writes are bank-conflict free), two LDS buffers, one barrier
-// per step, next slab's global loads in flight under the current slab's MFMAs.
+// on gfx950).  K is walked in slabs of 32.
+//
+// Staging: global -> registers -> LDS with 16-byte accesses.  All global reads are
+// buffer loads through wave-uniform descriptors with per-lane byte offsets: padding
+// taps / rows past M get offset 0xFFFFFFFF and the hardware range check returns zeros,
+// so the K loop has NO data-dependent branches -- one basic block in which the compiler
+// interleaves address VALU, buffer loads, LDS traffic and the 64 MFMAs per wave.
+// Tap validity of the <= 32 taps is a per-row bitmask built once.  LDS rows are padded to
+// 36 floats: fragment ds_read_b128 and staging ds_write_b128 are bank-conflict free.
+// Two LDS buffers, one barrier per slab; the next slab's loads fly under the MFMAs.
 // Each lane reads 4 consecutive k of its row with one ds_read_b128; lane half h owns
 // k = 8*kc + 4*h + t at MFMA step t -- a permutation of k applied to A and B alike.
 //
@@ -23,16 +29,78 @@ namespace {
 
 constexpr int BK = 32;          // k per LDS slab
 constexpr int LDS_LD = BK + 4;  // padded row (floats)
+constexpr unsigned OOB = 0xFFFFFFFFu;
 
 struct ConvArgs {
     const float *x, *w, *scale, *shift, *res;
     float *y;
     int64_t ldx, ldr, ldy;
-    int H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, act;
+    int B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, act;
     int M, K, ntiles, nblk;
 };
 
-template <int BM, int BN, int WM, int WN, bool CIN32>
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *base, int64_t bytes) {
+    const uint64_t a = (uint64_t)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const int64_t capped = bytes > 0x7FFFFFF0ll ? 0x7FFFFFF0ll : bytes;
+    const int n = __builtin_amdgcn_readfirstlane((int)capped);
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, n, 0x00020000);
+}
+
+// Epilogue: lane = output channel, register = output pixel.  Stores (and residual loads) are
+// buffer ops whose per-lane offset is fixed and whose row term is a scalar: one v_add per element.
+// Ragged tiles route out-of-range elements to offset 0xFFFFFFFF, which the range check drops.
+template <int ACT, bool RES, bool FULL, int TM, int TN>
+__device__ __forceinline__ void epilogue(const ConvArgs &p, f32x16 (&acc)[TM][TN], int m_base, int n_base,
+                                         int fr, int fh) {
+    const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y, (int64_t)p.M * p.ldy * 4);
+    const __amdgpu_buffer_rsrc_t rr = make_rsrc(RES ? p.res : p.y, (int64_t)p.M * (RES ? p.ldr : p.ldy) * 4);
+    const unsigned ldy4 = (unsigned)p.ldy * 4u, ldr4 = (unsigned)p.ldr * 4u;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n_base + j * 32 + fr;
+        const bool nok = FULL || n < p.Cout;
+        const int nc = nok ? n : 0;
+        const float scl = p.scale ? p.scale[nc] : 1.0f;
+        const float sft = p.shift ? p.shift[nc] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mrow = m_base + i * 32 + 4 * fh;          // + (r&3) + 8*(r>>2)
+            const unsigned ybase = (unsigned)mrow * ldy4 + (unsigned)n * 4u;
+            const unsigned rbase = (unsigned)mrow * ldr4 + (unsigned)n * 4u;
+            float rv[16];
+            if (RES) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    const bool ok = FULL || (nok && mrow + dr < p.M);
+                    rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                          rr, ok ? rbase + (unsigned)dr * ldr4 : OOB, 0, 0));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dr = (r & 3) + 8 * (r >> 2);
+                float v = acc[i][j][r] * scl + sft;
+                if (ACT == MYDET_ACT_LEAKY) v = v > 0.0f ? v : v * 0.1f;
+                if (ACT == MYDET_ACT_SWISH) v = v * mydet_sigmoid(v);
+                if (RES) v += rv[r];
+                const bool ok = FULL || (nok && mrow + dr < p.M);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr,
+                                                      ok ? ybase + (unsigned)dr * ldy4 : OOB, 0, 0);
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool CIN32, int ACT, bool RES>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int AI = BM / 32, BI = BN / 32;      // 16-byte chunks each thread stages per slab
@@ -46,62 +114,76 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     const int m0 = (lid / p.ntiles) * BM;
     const int n0 = (lid % p.ntiles) * BN;
 
+    // ---- descriptors: A window starts at the image holding the tile's first row
+    const int hwo = p.Ho * p.Wo;
+    const int b0 = m0 / hwo;
+    const int64_t img = (int64_t)p.H * p.W * p.ldx;
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x + b0 * img, (p.B - b0) * img * 4);
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, (int64_t)p.Cout * p.K * 4);
+
     // ---- staging role: chunk (4 floats) `sc` of rows sr + 32*i
     const int sc = tid & 7, sr = tid >> 3;
-    const float *aptr[AI];
-    int ih0[AI], iw0[AI];
+    const int ntaps = p.KH * p.KW;
+    int aoff[AI];                                   // byte offset of tap (0,0), channel 4*sc, from the window base
+    unsigned amask[AI];                             // bit t: tap t of this row is inside the image
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
         const int m = m0 + sr + 32 * i;
-        const int mm = m < p.M ? m : 0;
+        const int mm = m < p.M ? m : p.M - 1;
         const int ow = mm % p.Wo, t = mm / p.Wo;
         const int oh = t % p.Ho, b = t / p.Ho;
-        ih0[i] = m < p.M ? oh * p.stride - p.pad_t : -(1 << 28);
-        iw0[i] = ow * p.stride - p.pad_l;
-        aptr[i] = p.x + ((int64_t)(b * p.H + oh * p.stride - p.pad_t) * p.W + iw0[i]) * p.ldx;
+        const int ih0 = oh * p.stride - p.pad_t, iw0 = ow * p.stride - p.pad_l;
+        aoff[i] = (int)((((int64_t)(b - b0) * p.H + ih0) * p.W + iw0) * p.ldx + sc * 4) * 4;
+        unsigned mask = 0;
+        for (int tp = 0; tp < ntaps; ++tp) {
+            const int kh = tp / p.KW, kw = tp - kh * p.KW;
+            if ((unsigned)(ih0 + kh) < (unsigned)p.H && (unsigned)(iw0 + kw) < (unsigned)p.W) mask |= 1u << tp;
+        }
+        amask[i] = m < p.M ? mask : 0u;
     }
-    const float *bptr[BI];
-    bool bok[BI];
+    unsigned boff[BI];
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-        const int n = n0 + sr + 32 * i;
-        bok[i] = n < p.Cout;
-        bptr[i] = p.w + (int64_t)(bok[i] ? n : 0) * p.K + sc * 4;
+        int n = n0 + sr + 32 * i;
+        n = n < p.Cout ? n : p.Cout - 1;            // rows past Cout compute garbage that is never stored
+        boff[i] = (unsigned)(n * p.K + sc * 4) * 4u;
     }
 
     f32x4 areg[AI], breg[BI];
     const int nk = (p.K + BK - 1) / BK;
-    int kh = 0, kw = 0, c0 = 0;                      // CIN32 path: tap and channel base of the slab
+    int tap = 0, c0 = 0, tapoff = 0;                 // CIN32 path: uniform tap / channel base / byte offset
 
     auto load_slab = [&](int kt) {
-        int kkh, kkw, cc;
-        bool kok = true;
         if (CIN32) {
-            kkh = kh; kkw = kw; cc = c0 + sc * 4;
+            const unsigned uoff = (unsigned)(tapoff + c0 * 4);
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                const bool ok = (amask[i] >> tap) & 1u;
+                areg[i] = buf_load16(xr, ok ? (unsigned)aoff[i] + uoff : OOB);
+            }
+            c0 += BK;
+            if (c0 == p.Cin) {                        // uniform: next tap
+                c0 = 0;
+                ++tap;
+                const int kh = tap / p.KW, kw = tap - kh * p.KW;
+                tapoff = (int)(((int64_t)kh * p.W + kw) * p.ldx) * 4;
+            }
         } else {
             const int k = kt * BK + sc * 4;          // Cin % 4 == 0: a chunk never straddles taps
-            kok = k < p.K;
-            const int tap = k / p.Cin;
-            cc = k - tap * p.Cin;
-            kkh = tap / p.KW; kkw = tap - kkh * p.KW;
-        }
-        const int64_t tapoff = ((int64_t)kkh * p.W + kkw) * p.ldx + cc;
+            const int tp = k / p.Cin;
+            const int cc = k - tp * p.Cin;
+            const int kh = tp / p.KW, kw = tp - kh * p.KW;
+            const unsigned uoff = (unsigned)((int)(((int64_t)kh * p.W + kw) * p.ldx + cc - sc * 4) * 4);   // aoff holds +4*sc
+            const bool kok = k < p.K;
 #pragma unroll
-        for (int i = 0; i < AI; ++i) {
-            const bool ok = kok && (unsigned)(ih0[i] + kkh) < (unsigned)p.H &&
-                            (unsigned)(iw0[i] + kkw) < (unsigned)p.W;
-            areg[i] = ok ? *reinterpret_cast<const f32x4 *>(aptr[i] + tapoff) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < AI; ++i) {
+                const bool ok = kok && ((amask[i] >> (tp & 31)) & 1u);
+                areg[i] = buf_load16(xr, ok ? (unsigned)aoff[i] + uoff : OOB);
+            }
         }
+        const unsigned koff = (unsigned)kt * (BK * 4);
 #pragma unroll
-        for (int i = 0; i < BI; ++i) {
-            const bool ok = kok && bok[i];
-            breg[i] = ok ? *reinterpret_cast<const f32x4 *>(bptr[i] + (int64_t)kt * BK)
-                         : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        if (CIN32) {                                  // advance (uniform, scalar)
-            c0 += BK;
-            if (c0 == p.Cin) { c0 = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
-        }
+        for (int i = 0; i < BI; ++i) breg[i] = buf_load16(wr, boff[i] + koff);
     };
     auto store_slab = [&](int buf) {
         float *a = As + buf * BM * LDS_LD, *b = Bs + buf * BN * LDS_LD;
@@ -133,7 +215,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_slab(kt + 1);
+        // Unconditional prefetch: past the last slab the taps are masked off (A) and the
+        // weight rows run into the next row or the range check (B) -- harmless, never consumed.
+        load_slab(kt + 1);
         const float *a = As + buf * BM * LDS_LD + a_off;
         const float *b = Bs + buf * BN * LDS_LD + b_off;
 #pragma unroll
@@ -151,29 +235,43 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_slab(buf ^ 1);
+        store_slab(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: lane = output channel, register = output pixel
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + fr;
-        const bool nok = n < p.Cout;
-        const float scl = (nok && p.scale) ? p.scale[n] : 1.0f;
-        const float sft = (nok && p.shift) ? p.shift[n] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (nok && m < p.M) {
-                    float v = mydet_act(acc[i][j][r] * scl + sft, p.act);
-                    if (p.res) v += p.res[(int64_t)m * p.ldr + n];
-                    p.y[(int64_t)m * p.ldy + n] = v;
-                }
-            }
-        }
+    const int m_base = m0 + wm * TM * 32, n_base = n0 + wn * TN * 32;
+    if ((m0 + BM <= p.M) && (n0 + BN <= p.Cout))
+        epilogue<ACT, RES, true, TM, TN>(p, acc, m_base, n_base, fr, fh);
+    else
+        epilogue<ACT, RES, false, TM, TN>(p, acc, m_base, n_base, fr, fh);
+}
+
+template <int BM, int BN, int WM, int WN, bool CIN32, int ACT, bool RES>
+int launch_inst(const ConvArgs &a, size_t lds, hipStream_t stream) {
+    auto kern = &conv_igemm_kernel<BM, BN, WM, WN, CIN32, ACT, RES>;
+    static bool attr_set = false;                  // > 64 KiB of dynamic LDS needs the opt-in once
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(256), lds, stream, a);
+    return mydet_launch_status();
+}
+
+template <int BM, int BN, int WM, int WN, bool CIN32>
+int launch_act(const ConvArgs &a, size_t lds, hipStream_t stream) {
+    const bool res = a.res != nullptr;
+    switch (a.act) {
+        case MYDET_ACT_LEAKY:
+            return res ? launch_inst<BM, BN, WM, WN, CIN32, MYDET_ACT_LEAKY, true>(a, lds, stream)
+                       : launch_inst<BM, BN, WM, WN, CIN32, MYDET_ACT_LEAKY, false>(a, lds, stream);
+        case MYDET_ACT_SWISH:
+            return res ? launch_inst<BM, BN, WM, WN, CIN32, MYDET_ACT_SWISH, true>(a, lds, stream)
+                       : launch_inst<BM, BN, WM, WN, CIN32, MYDET_ACT_SWISH, false>(a, lds, stream);
+        default:
+            return res ? launch_inst<BM, BN, WM, WN, CIN32, MYDET_ACT_NONE, true>(a, lds, stream)
+                       : launch_inst<BM, BN, WM, WN, CIN32, MYDET_ACT_NONE, false>(a, lds, stream);
     }
 }
 
@@ -184,20 +282,8 @@ int launch(const ConvArgs &a0, hipStream_t stream) {
     a.ntiles = (a.Cout + BN - 1) / BN;
     a.nblk = mtiles * a.ntiles;
     const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
-    const bool cin32 = (a.Cin % 32) == 0;
-    static bool attr_set = false;                  // > 64 KiB of dynamic LDS needs the opt-in once
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_kernel<BM, BN, WM, WN, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_kernel<BM, BN, WM, WN, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    if (cin32)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true>), dim3(a.nblk), dim3(256), lds, stream, a);
-    else
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false>), dim3(a.nblk), dim3(256), lds, stream, a);
-    return mydet_launch_status();
+    if ((a.Cin % 32) == 0) return launch_act<BM, BN, WM, WN, true>(a, lds, stream);
+    return launch_act<BM, BN, WM, WN, false>(a, lds, stream);
 }
 
 }  // namespace
@@ -213,10 +299,18 @@ extern "C" int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return MYDET_E_BADARG;
     const int64_t M64 = (int64_t)B * Ho * Wo;
     if (M64 > (int64_t)1 << 30 || (int64_t)KH * KW * Cin > (int64_t)1 << 30) return MYDET_E_BADARG;
+    // 32-bit byte offsets inside a block's window (the images its 128 rows touch, +1) and the weights
+    const int64_t img_bytes = (int64_t)H * W * ldx * 4;
+    const int64_t span_imgs = 128 / ((int64_t)Ho * Wo) + 2;
+    if ((int64_t)M64 * ldy * 4 >= 0x7FFFFFF0ll || (residual && (int64_t)M64 * ldr * 4 >= 0x7FFFFFF0ll))
+        return MYDET_E_UNSUPP;
+    if (act < 0 || act > 2) return MYDET_E_BADARG;
+    if (KH * KW > 31 || img_bytes * span_imgs >= 0x7FFFFFF0ll || (int64_t)Cout * KH * KW * Cin * 4 >= 0x7FFFFFF0ll)
+        return MYDET_E_UNSUPP;
     ConvArgs a;
     a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
     a.ldx = ldx; a.ldr = ldr; a.ldy = ldy;
-    a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride;
     a.pad_t = pad_t; a.pad_l = pad_l; a.Ho = Ho; a.Wo = Wo; a.act = act;
     a.M = (int)M64; a.K = KH * KW * Cin; a.ntiles = 0; a.nblk = 0;
     hipStream_t s = (hipStream_t)stream;
