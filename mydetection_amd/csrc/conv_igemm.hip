@@ -23,12 +23,12 @@
 //
 // Replaces the ATen conv2d/batch_norm/leaky_relu chain under models/modules.py:94-95,
 // the residual add of models/modules.py:69-73 and the head convs models/rpns.py:24-25.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
 
-constexpr int BK = 32;          // k per LDS slab
-constexpr int LDS_LD = BK + 4;  // padded row (floats)
 constexpr unsigned OOB = 0xFFFFFFFFu;
 
 struct ConvArgs {
@@ -100,11 +100,15 @@ __device__ __forceinline__ void epilogue(const ConvArgs &p, f32x16 (&acc)[TM][TN
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool CIN32, int ACT, bool RES>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
+template <int BM, int BN, int WM, int WN, int BK, bool CIN32, int ACT, bool RES>
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs p) {
+    constexpr int NT = WM * WN * 64;                // threads: one wave per (wm, wn)
+    constexpr int LDS_LD = BK + 4;                 // padded LDS row (floats)
+    constexpr int CH = BK / 4;                      // 16-byte chunks per slab row
+    constexpr int RP = NT / CH;                     // rows staged per pass of the workgroup
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    constexpr int AI = BM / 32, BI = BN / 32;      // 16-byte chunks each thread stages per slab
-    static_assert(WM * WN == 4, "4 waves");
+    constexpr int AI = BM / RP, BI = BN / RP;      // 16-byte chunks each thread stages per slab
+    static_assert(BM % RP == 0 && BN % RP == 0, "tile rows must fill whole staging passes");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                               // [2][BM][LDS_LD]
     float *Bs = smem + 2 * BM * LDS_LD;             // [2][BN][LDS_LD]
@@ -121,14 +125,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x + b0 * img, (p.B - b0) * img * 4);
     const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, (int64_t)p.Cout * p.K * 4);
 
-    // ---- staging role: chunk (4 floats) `sc` of rows sr + 32*i
-    const int sc = tid & 7, sr = tid >> 3;
+    // ---- staging role: chunk (4 floats) `sc` of rows sr + RP*i
+    const int sc = tid % CH, sr = tid / CH;
     const int ntaps = p.KH * p.KW;
     int aoff[AI];                                   // byte offset of tap (0,0), channel 4*sc, from the window base
     unsigned amask[AI];                             // bit t: tap t of this row is inside the image
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-        const int m = m0 + sr + 32 * i;
+        const int m = m0 + sr + RP * i;
         const int mm = m < p.M ? m : p.M - 1;
         const int ow = mm % p.Wo, t = mm / p.Wo;
         const int oh = t % p.Ho, b = t / p.Ho;
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     unsigned boff[BI];
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-        int n = n0 + sr + 32 * i;
+        int n = n0 + sr + RP * i;
         n = n < p.Cout ? n : p.Cout - 1;            // rows past Cout compute garbage that is never stored
         boff[i] = (unsigned)(n * p.K + sc * 4) * 4u;
     }
@@ -189,10 +193,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         float *a = As + buf * BM * LDS_LD, *b = Bs + buf * BN * LDS_LD;
 #pragma unroll
         for (int i = 0; i < AI; ++i)
-            *reinterpret_cast<f32x4 *>(a + (sr + 32 * i) * LDS_LD + sc * 4) = areg[i];
+            *reinterpret_cast<f32x4 *>(a + (sr + RP * i) * LDS_LD + sc * 4) = areg[i];
 #pragma unroll
         for (int i = 0; i < BI; ++i)
-            *reinterpret_cast<f32x4 *>(b + (sr + 32 * i) * LDS_LD + sc * 4) = breg[i];
+            *reinterpret_cast<f32x4 *>(b + (sr + RP * i) * LDS_LD + sc * 4) = breg[i];
     };
 
     // ---- compute role
@@ -246,44 +250,66 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         epilogue<ACT, RES, false, TM, TN>(p, acc, m_base, n_base, fr, fh);
 }
 
-template <int BM, int BN, int WM, int WN, bool CIN32, int ACT, bool RES>
+template <int BM, int BN, int WM, int WN, int BK, bool CIN32, int ACT, bool RES>
 int launch_inst(const ConvArgs &a, size_t lds, hipStream_t stream) {
-    auto kern = &conv_igemm_kernel<BM, BN, WM, WN, CIN32, ACT, RES>;
+    auto kern = &conv_igemm_kernel<BM, BN, WM, WN, BK, CIN32, ACT, RES>;
     static bool attr_set = false;                  // > 64 KiB of dynamic LDS needs the opt-in once
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(WM * WN * 64), lds, stream, a);
     return mydet_launch_status();
 }
 
-template <int BM, int BN, int WM, int WN, bool CIN32>
+template <int BM, int BN, int WM, int WN, int BK, bool CIN32>
 int launch_act(const ConvArgs &a, size_t lds, hipStream_t stream) {
     const bool res = a.res != nullptr;
     switch (a.act) {
         case MYDET_ACT_LEAKY:
-            return res ? launch_inst<BM, BN, WM, WN, CIN32, MYDET_ACT_LEAKY, true>(a, lds, stream)
-                       : launch_inst<BM, BN, WM, WN, CIN32, MYDET_ACT_LEAKY, false>(a, lds, stream);
+            return res ? launch_inst<BM, BN, WM, WN, BK, CIN32, MYDET_ACT_LEAKY, true>(a, lds, stream)
+                       : launch_inst<BM, BN, WM, WN, BK, CIN32, MYDET_ACT_LEAKY, false>(a, lds, stream);
         case MYDET_ACT_SWISH:
-            return res ? launch_inst<BM, BN, WM, WN, CIN32, MYDET_ACT_SWISH, true>(a, lds, stream)
-                       : launch_inst<BM, BN, WM, WN, CIN32, MYDET_ACT_SWISH, false>(a, lds, stream);
+            return res ? launch_inst<BM, BN, WM, WN, BK, CIN32, MYDET_ACT_SWISH, true>(a, lds, stream)
+                       : launch_inst<BM, BN, WM, WN, BK, CIN32, MYDET_ACT_SWISH, false>(a, lds, stream);
         default:
-            return res ? launch_inst<BM, BN, WM, WN, CIN32, MYDET_ACT_NONE, true>(a, lds, stream)
-                       : launch_inst<BM, BN, WM, WN, CIN32, MYDET_ACT_NONE, false>(a, lds, stream);
+            return res ? launch_inst<BM, BN, WM, WN, BK, CIN32, MYDET_ACT_NONE, true>(a, lds, stream)
+                       : launch_inst<BM, BN, WM, WN, BK, CIN32, MYDET_ACT_NONE, false>(a, lds, stream);
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK>
 int launch(const ConvArgs &a0, hipStream_t stream) {
     ConvArgs a = a0;
     const int mtiles = (a.M + BM - 1) / BM;
     a.ntiles = (a.Cout + BN - 1) / BN;
     a.nblk = mtiles * a.ntiles;
-    const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
-    if ((a.Cin % 32) == 0) return launch_act<BM, BN, WM, WN, true>(a, lds, stream);
-    return launch_act<BM, BN, WM, WN, false>(a, lds, stream);
+    const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
+    if ((a.Cin % BK) == 0) return launch_act<BM, BN, WM, WN, BK, true>(a, lds, stream);
+    return launch_act<BM, BN, WM, WN, BK, false>(a, lds, stream);
+}
+
+// Tile configurations (id -> BM x BN, wave grid, BK).  MYDET_CONV_CFG=<id> forces one (tuning only).
+int launch_cfg(int id, const ConvArgs &a, hipStream_t s) {
+    switch (id) {
+        case 0: return launch<128, 128, 2, 2, 32>(a, s);
+        case 1: return launch<128, 64, 2, 2, 32>(a, s);
+        case 2: return launch<128, 32, 4, 1, 32>(a, s);
+        case 3: return launch<64, 64, 2, 2, 32>(a, s);
+        case 6: return launch<128, 64, 2, 2, 16>(a, s);
+        case 8: return launch<128, 128, 2, 4, 32>(a, s);     // 8 waves, wave tile 64x32
+        default: return MYDET_E_BADARG;
+    }
+}
+
+int forced_cfg() {
+    static int v = -2;
+    if (v == -2) {
+        const char *e = getenv("MYDET_CONV_CFG");
+        v = e ? atoi(e) : -1;
+    }
+    return v;
 }
 
 }  // namespace
@@ -301,7 +327,7 @@ extern "C" int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *
     if (M64 > (int64_t)1 << 30 || (int64_t)KH * KW * Cin > (int64_t)1 << 30) return MYDET_E_BADARG;
     // 32-bit byte offsets inside a block's window (the images its 128 rows touch, +1) and the weights
     const int64_t img_bytes = (int64_t)H * W * ldx * 4;
-    const int64_t span_imgs = 128 / ((int64_t)Ho * Wo) + 2;
+    const int64_t span_imgs = 256 / ((int64_t)Ho * Wo) + 2;      // tiles are at most 256 rows
     if ((int64_t)M64 * ldy * 4 >= 0x7FFFFFF0ll || (residual && (int64_t)M64 * ldr * 4 >= 0x7FFFFFF0ll))
         return MYDET_E_UNSUPP;
     if (act < 0 || act > 2) return MYDET_E_BADARG;
@@ -314,13 +340,15 @@ extern "C" int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *
     a.pad_t = pad_t; a.pad_l = pad_l; a.Ho = Ho; a.Wo = Wo; a.act = act;
     a.M = (int)M64; a.K = KH * KW * Cin; a.ntiles = 0; a.nblk = 0;
     hipStream_t s = (hipStream_t)stream;
-    // Tile choice: widest N tile the layer fills; fall back to smaller tiles when the
-    // grid would leave most of the 256 CUs idle.
+    if (forced_cfg() >= 0) return launch_cfg(forced_cfg(), a, s);
+    // Tile choice, from the per-shape sweep in profiles/ (tools/sweep_conv_cfg.sh):
+    //   narrow outputs take a narrow N tile; short-K layers (1x1 convs, prologue/epilogue-bound) and
+    //   grids under ~4 blocks per CU do best with 64x64 tiles at 4 workgroups/CU; the long-K 3x3
+    //   layers with big grids take 128x128 tiles on 8 waves (wave tile 64x32, 4 waves per SIMD).
     const int64_t blocks128 = ((M64 + 127) / 128) * ((Cout + 127) / 128);
-    if (Cout <= 32) return launch<128, 32, 4, 1>(a, s);
-    if (Cout <= 64) return launch<128, 64, 2, 2>(a, s);
-    if (blocks128 >= 384) return launch<128, 128, 2, 2>(a, s);
-    const int64_t blocks64n = ((M64 + 127) / 128) * ((Cout + 63) / 64);
-    if (blocks64n >= 256) return launch<128, 64, 2, 2>(a, s);
-    return launch<64, 64, 2, 2>(a, s);
+    const int K = KH * KW * Cin;
+    if (Cout <= 32) return launch_cfg(2, a, s);
+    if (Cout <= 64) return launch_cfg(KH * KW > 1 ? 6 : 1, a, s);
+    if (K <= 1024 || blocks128 < 1024) return launch_cfg(3, a, s);
+    return launch_cfg(8, a, s);
 }

@@ -5,7 +5,8 @@
 // per-pixel kernel: a thread owns one output pixel, keeps its 27 taps in registers and
 // walks the 32 output channels; the 864 weights are wave-uniform and are fetched
 // through the scalar cache (s_load), the epilogue (folded BN + activation) is fused and
-// the 32 channels of the pixel are written as eight 16-byte stores (NHWC).
+// the wave's 64x32 outputs are transposed through a wave-private LDS strip so that every store
+// instruction writes whole 128-byte lines (NHWC).
 // It reads the image through arbitrary strides, so the NCHW tensor built at
 // api/detection.py:160-163 is consumed as is (no layout pass).
 // Replaces Darknet53 netlist[0] (models/backbones.py:14) and the EfficientNet stem
@@ -22,43 +23,58 @@ struct StemArgs {
     int64_t M;
 };
 
+constexpr int ST_LD = 36;          // LDS row per pixel: 32 channels + pad (16-byte aligned, conflict-free b128)
+
 __global__ __launch_bounds__(256) void conv_stem_kernel(const StemArgs p) {
-    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (m >= p.M) return;
-    const int ow = (int)(m % p.Wo);
-    const int64_t t = m / p.Wo;
-    const int oh = (int)(t % p.Ho);
-    const int64_t b = t / p.Ho;
-    float in[27];                                   // [kh][kw][c], matches the OHWI weight rows
-    const float *xb = p.x + b * p.sxb;
+    __shared__ __attribute__((aligned(16))) float tile[4][64 * ST_LD];     // one strip per wave
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t mw = (int64_t)blockIdx.x * 256 + wave * 64;               // first pixel of this wave
+    const int64_t m = mw + lane;
+    float *strip = tile[wave];
+    if (m < p.M) {
+        const int ow = (int)(m % p.Wo);
+        const int64_t t = m / p.Wo;
+        const int oh = (int)(t % p.Ho);
+        const int64_t b = t / p.Ho;
+        float in[27];                               // [kh][kw][c], matches the OHWI weight rows
+        const float *xb = p.x + b * p.sxb;
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-        const int ih = oh * p.stride - p.pad_t + kh;
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * p.stride - p.pad_t + kh;
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const int iw = ow * p.stride - p.pad_l + kw;
-            const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow * p.stride - p.pad_l + kw;
+                const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
-                in[(kh * 3 + kw) * 3 + c] = ok ? xb[c * p.sxc + (int64_t)ih * p.sxh + (int64_t)iw * p.sxw] : 0.0f;
+                for (int c = 0; c < 3; ++c)
+                    in[(kh * 3 + kw) * 3 + c] = ok ? xb[c * p.sxc + (int64_t)ih * p.sxh + (int64_t)iw * p.sxw] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int n4 = 0; n4 < 8; ++n4) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n4 * 4 + j;
+                const float *wr = p.w + n * 27;     // uniform address -> scalar loads
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 27; ++k) acc = fmaf(in[k], wr[k], acc);
+                const float scl = p.scale ? p.scale[n] : 1.0f;
+                const float sft = p.shift ? p.shift[n] : 0.0f;
+                o[j] = mydet_act(acc * scl + sft, p.act);
+            }
+            *reinterpret_cast<f32x4 *>(strip + lane * ST_LD + n4 * 4) = o;
         }
     }
-    float *yp = p.y + m * p.ldy;
+    __builtin_amdgcn_wave_barrier();
+    // transposed write-out: 8 consecutive lanes emit one pixel's 128-byte line
 #pragma unroll
-    for (int n4 = 0; n4 < 8; ++n4) {
-        f32x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n4 * 4 + j;
-            const float *wr = p.w + n * 27;         // uniform address -> scalar loads
-            float acc = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 27; ++k) acc = fmaf(in[k], wr[k], acc);
-            const float scl = p.scale ? p.scale[n] : 1.0f;
-            const float sft = p.shift ? p.shift[n] : 0.0f;
-            o[j] = mydet_act(acc * scl + sft, p.act);
-        }
-        *reinterpret_cast<f32x4 *>(yp + n4 * 4) = o;
+    for (int j = 0; j < 8; ++j) {
+        const int q = lane + 64 * j, px = q >> 3, part = q & 7;
+        if (mw + px < p.M)
+            *reinterpret_cast<f32x4 *>(p.y + (mw + px) * p.ldy + part * 4) =
+                *reinterpret_cast<const f32x4 *>(strip + px * ST_LD + part * 4);
     }
 }
 

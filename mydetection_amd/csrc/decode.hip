@@ -5,8 +5,8 @@
 // pulled with 16-byte lane loads into a wave-private LDS strip, then for each anchor
 // the 64 lanes take the class logits (<= 2 per lane for 80 classes), apply the
 // logistic, and a 6-step butterfly picks max / first-argmax exactly as torch.max does
-// on the sigmoid values; lane 0 finishes the box arithmetic in the reference's
-// operation order (compiled with -ffp-contract=off so no product is fused into a sum).
+// on the sigmoid values; lane a then finishes anchor a's box arithmetic (all anchors of the
+// pixel in one pass) in the reference's operation order (compiled with -ffp-contract=off so no product is fused into a sum).
 //
 //   YOLO   models/detlayers/yolov3.py:41-69    cx=(s(tx)+x)*stride, w=exp(tw)*aw, score=s(conf)*max s(cls)
 //   RETINA models/detlayers/retinanet.py:63-82 cx=acx+tx*aw, w=exp(tw)*aw, clamp [1,max(H,W)], score=max s(cls)
@@ -36,6 +36,11 @@ struct DecodeArgs {
 
 __global__ __launch_bounds__(64 * WAVES) void decode_kernel(const DecodeArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float s_aw[MAX_A], s_ah[MAX_A];          // anchors, indexed per lane below
+#pragma unroll
+    for (int a = 0; a < MAX_A; ++a)
+        if (threadIdx.x == a) { s_aw[a] = p.aw[a]; s_ah[a] = p.ah[a]; }
+    __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int strip = p.cls_span + (p.same ? 0 : p.box_span);
     float *lc = smem + wave * strip;
@@ -58,6 +63,9 @@ __global__ __launch_bounds__(64 * WAVES) void decode_kernel(const DecodeArgs p) 
         const int rem = (int)(pix - (int64_t)b * hw);
         const int gy = rem / p.W, gx = rem - gy * p.W;
 
+        // class max / first-argmax per anchor; lane a keeps anchor a's result
+        float mybest = 0.0f;
+        int mybi = 0;
         for (int a = 0; a < p.A; ++a) {
             const float *cl = lc + a * p.cls_astride + p.cls_c0;
             float best = -1.0f;
@@ -73,46 +81,50 @@ __global__ __launch_bounds__(64 * WAVES) void decode_kernel(const DecodeArgs p) 
                 const int oi = __shfl_xor(bi, off);
                 if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
             }
-            if (lane == 0) {
-                const float *t = lb + a * p.box_astride + p.box_c0;
-                const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
-                f32x4 o;
-                float sc;
-                if (p.mode == MYDET_DECODE_YOLO) {
-                    o[0] = (mydet_sigmoid(t0) + (float)gx) * p.stride;
-                    o[1] = (mydet_sigmoid(t1) + (float)gy) * p.stride;
-                    o[2] = expf(t2) * p.aw[a];
-                    o[3] = expf(t3) * p.ah[a];
-                    sc = mydet_sigmoid(lc[a * p.cls_astride + p.conf_c0]) * best;
-                } else if (p.mode == MYDET_DECODE_RETINA) {
-                    const float acx = p.stride * 0.5f + (float)gx * p.stride;
-                    const float acy = p.stride * 0.5f + (float)gy * p.stride;
-                    o[0] = acx + t0 * p.aw[a];
-                    o[1] = acy + t1 * p.ah[a];
-                    o[2] = expf(t2) * p.aw[a];
-                    o[3] = expf(t3) * p.ah[a];
+            if (lane == a) { mybest = best; mybi = bi; }
+        }
+        // box arithmetic: lane a finishes anchor a (all anchors of the pixel in one pass)
+        if (lane < p.A) {
+            const int a = lane;
+            const float *t = lb + a * p.box_astride + p.box_c0;
+            const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
+            const float aw = s_aw[a], ah = s_ah[a];
+            f32x4 o;
+            float sc;
+            if (p.mode == MYDET_DECODE_YOLO) {
+                o[0] = (mydet_sigmoid(t0) + (float)gx) * p.stride;
+                o[1] = (mydet_sigmoid(t1) + (float)gy) * p.stride;
+                o[2] = expf(t2) * aw;
+                o[3] = expf(t3) * ah;
+                sc = mydet_sigmoid(lc[a * p.cls_astride + p.conf_c0]) * mybest;
+            } else if (p.mode == MYDET_DECODE_RETINA) {
+                const float acx = p.stride * 0.5f + (float)gx * p.stride;
+                const float acy = p.stride * 0.5f + (float)gy * p.stride;
+                o[0] = acx + t0 * aw;
+                o[1] = acy + t1 * ah;
+                o[2] = expf(t2) * aw;
+                o[3] = expf(t3) * ah;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = fminf(fmaxf(o[j], 1.0f), fmaxhw);
-                    sc = best;
-                } else {
-                    const float cx = (float)gx * p.stride + p.stride * 0.5f;
-                    const float cy = (float)gy * p.stride + p.stride * 0.5f;
-                    const float fw = (float)p.img_w, fh = (float)p.img_h;
-                    const float x1 = fminf(fmaxf(cx - expf(t0) * p.stride, 0.0f), fw);
-                    const float y1 = fminf(fmaxf(cy - expf(t1) * p.stride, 0.0f), fh);
-                    const float x2 = fminf(fmaxf(cx + expf(t2) * p.stride, 0.0f), fw);
-                    const float y2 = fminf(fmaxf(cy + expf(t3) * p.stride, 0.0f), fh);
-                    o[0] = (x1 + x2) / 2.0f;
-                    o[1] = (y1 + y2) / 2.0f;
-                    o[2] = x2 - x1;
-                    o[3] = y2 - y1;
-                    sc = sqrtf(mydet_sigmoid(lc[a * p.cls_astride + p.conf_c0]) * best);
-                }
-                const int64_t n = (int64_t)b * p.N + p.n_off + ((int64_t)a * p.H + gy) * p.W + gx;
-                *reinterpret_cast<f32x4 *>(p.bbox + n * 4) = o;
-                p.cidx[n] = (int64_t)bi;
-                p.score[n] = sc;
+                for (int j = 0; j < 4; ++j) o[j] = fminf(fmaxf(o[j], 1.0f), fmaxhw);
+                sc = mybest;
+            } else {
+                const float cx = (float)gx * p.stride + p.stride * 0.5f;
+                const float cy = (float)gy * p.stride + p.stride * 0.5f;
+                const float fw = (float)p.img_w, fh = (float)p.img_h;
+                const float x1 = fminf(fmaxf(cx - expf(t0) * p.stride, 0.0f), fw);
+                const float y1 = fminf(fmaxf(cy - expf(t1) * p.stride, 0.0f), fh);
+                const float x2 = fminf(fmaxf(cx + expf(t2) * p.stride, 0.0f), fw);
+                const float y2 = fminf(fmaxf(cy + expf(t3) * p.stride, 0.0f), fh);
+                o[0] = (x1 + x2) / 2.0f;
+                o[1] = (y1 + y2) / 2.0f;
+                o[2] = x2 - x1;
+                o[3] = y2 - y1;
+                sc = sqrtf(mydet_sigmoid(lc[a * p.cls_astride + p.conf_c0]) * mybest);
             }
+            const int64_t n = (int64_t)b * p.N + p.n_off + ((int64_t)a * p.H + gy) * p.W + gx;
+            *reinterpret_cast<f32x4 *>(p.bbox + n * 4) = o;
+            p.cidx[n] = (int64_t)mybi;
+            p.score[n] = sc;
         }
         __builtin_amdgcn_wave_barrier();
     }
