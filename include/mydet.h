@@ -52,10 +52,17 @@ int mydet_abi_version(void);
  * y  : [B,Ho,Wo,Cout] pixel stride ldy.  residual: same shape, pixel stride ldr, or NULL.
  * Ho = (H + pad_t + pad_b - KH)/stride + 1 (likewise Wo); only pad_t/pad_l are
  * needed by the kernel, Ho/Wo are passed explicitly (asymmetric "SAME" pads allowed).
+ * a_gate: NULL, or [B][Cin] per-image channel multipliers applied to x while it is staged
+ *   (1x1 stride-1 convs without activation only): the squeeze-excite scale
+ *   `torch.sigmoid(x_squeezed) * x` feeding `_project_conv`, external/efficientnet/model.py:83-85,
+ *   without a pass over the expanded tensor.
+ * Also covers: MBConv expand/project convs (external/efficientnet/model.py:75,85), BiFPN
+ * input projections (models/fpns.py:446-448), SeparableConv2d.pointwise (models/modules.py:20),
+ * C6/C7 convs (models/backbones.py:183-200), dense cls_last conv (models/rpns.py:155-158).
  */
 int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *w,
                            const float *scale, const float *shift,
-                           const float *residual, int64_t ldr,
+                           const float *residual, int64_t ldr, const float *a_gate,
                            float *y, int64_t ldy,
                            int B, int H, int W, int Cin, int Cout,
                            int KH, int KW, int stride, int pad_t, int pad_l,
@@ -72,6 +79,35 @@ int mydet_conv2d_stem_f32(const float *x, int64_t sxb, int64_t sxc, int64_t sxh,
                           float *y, int64_t ldy,
                           int B, int H, int W, int Cout, int stride, int pad_t, int pad_l,
                           int Ho, int Wo, int act, void *stream);
+
+/* Depthwise K x K convolution (K = 3 or 5), y = act(conv*scale + shift) (scale/shift NULL => plain conv).
+ * Replaces `_depthwise_conv` + `_bn1` + swish (external/efficientnet/model.py:77) and
+ * SeparableConv2d.depthwise (models/modules.py:12-13,19).  w: [K][K][C] (repack of [C,1,K,K]).
+ */
+int mydet_dwconv_f32(const float *x, int64_t ldx, const float *w, const float *scale, const float *shift,
+                     float *y, int64_t ldy, int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l,
+                     int Ho, int Wo, int act, void *stream);
+
+/* Squeeze-excite gate: gate[b][c] = sigmoid(W2 . swish(W1 . mean_hw(x[b,:,:,c]) + b1) + b2).
+ * Replaces adaptive_avg_pool2d + _se_reduce + swish + _se_expand + sigmoid
+ * (external/efficientnet/model.py:80-83).  w1 [Cse][C], w2 [C][Cse].  scratch: B*S*C floats,
+ * S (1..4096) = number of pixel slices the average is split over (deterministic two-stage sum).
+ */
+int mydet_se_gate_f32(const float *x, int64_t ldx, int B, int H, int W, int C, const float *w1, const float *b1,
+                      int Cse, const float *w2, const float *b2, float *gate, float *scratch, int S, void *stream);
+
+/* 3x3 stride-2 pad-1 max pool (-inf padding): nn.MaxPool2d(3, 2, 1) models/backbones.py:186,188,
+ * tnf.max_pool2d models/fpns.py:405-416. */
+int mydet_maxpool3s2_f32(const float *x, int64_t ldx, float *y, int64_t ldy, int B, int H, int W, int C,
+                         int Ho, int Wo, void *stream);
+
+/* BiFPN node input: y = swish(sum_i w_i * in_i), w = relu(weights) / (sum(relu(weights)) + 1e-4)
+ * (LinearFusion.forward models/fpns.py:433-438, the part before spconv_bn).  n = 2 or 3 inputs of C
+ * channels; mode_i: 0 = [B,H,W] map, 1 = [B,H/2,W/2] map read through nearest 2x upsampling
+ * (upsample2x, models/fpns.py:442-444), 2 = [B,2H,2W] map read through max_pool2d(3,2,1). */
+int mydet_bifpn_fuse_f32(int n, const float *in0, int64_t ld0, int mode0, const float *in1, int64_t ld1, int mode1,
+                         const float *in2, int64_t ld2, int mode2, const float *weights, float *y, int64_t ldy,
+                         int B, int H, int W, int C, void *stream);
 
 /* y[b,yo,xo, 0:C1] = a[b, nearest(yo), nearest(xo), :]  ;  y[..., C1:C1+C2] = b[b,yo,xo,:]
  * Replaces F.interpolate(mode='nearest') + torch.cat((pre, x), 1) of

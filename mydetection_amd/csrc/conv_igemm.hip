@@ -32,7 +32,7 @@ namespace {
 constexpr unsigned OOB = 0xFFFFFFFFu;
 
 struct ConvArgs {
-    const float *x, *w, *scale, *shift, *res;
+    const float *x, *w, *scale, *shift, *res, *gate;
     float *y;
     int64_t ldx, ldr, ldy;
     int B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, act;
@@ -100,7 +100,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs &p, f32x16 (&acc)[TM][TN
     }
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool CIN32, int ACT, bool RES>
+template <int BM, int BN, int WM, int WN, int BK, bool CIN32, int ACT, bool RES, bool GATE>
 __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs p) {
     constexpr int NT = WM * WN * 64;                // threads: one wave per (wm, wn)
     constexpr int LDS_LD = BK + 4;                 // padded LDS row (floats)
@@ -124,12 +124,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     const int64_t img = (int64_t)p.H * p.W * p.ldx;
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x + b0 * img, (p.B - b0) * img * 4);
     const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, (int64_t)p.Cout * p.K * 4);
+    // SE gate (1x1 convs only): A[m][k] is multiplied by gate[image(m)][k] while it is staged
+    const __amdgpu_buffer_rsrc_t gr = make_rsrc(GATE ? p.gate : p.w, (int64_t)p.B * p.Cin * 4);
 
     // ---- staging role: chunk (4 floats) `sc` of rows sr + RP*i
     const int sc = tid % CH, sr = tid / CH;
     const int ntaps = p.KH * p.KW;
     int aoff[AI];                                   // byte offset of tap (0,0), channel 4*sc, from the window base
     unsigned amask[AI];                             // bit t: tap t of this row is inside the image
+    unsigned gbase[AI];                             // GATE: byte offset of the row's image in gate[B][Cin]
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
         const int m = m0 + sr + RP * i;
@@ -144,6 +147,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
             if ((unsigned)(ih0 + kh) < (unsigned)p.H && (unsigned)(iw0 + kw) < (unsigned)p.W) mask |= 1u << tp;
         }
         amask[i] = m < p.M ? mask : 0u;
+        if (GATE) gbase[i] = (unsigned)(b * p.Cin) * 4u;
     }
     unsigned boff[BI];
 #pragma unroll
@@ -164,6 +168,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
             for (int i = 0; i < AI; ++i) {
                 const bool ok = (amask[i] >> tap) & 1u;
                 areg[i] = buf_load16(xr, ok ? (unsigned)aoff[i] + uoff : OOB);
+                if (GATE) areg[i] *= buf_load16(gr, gbase[i] + (unsigned)(c0 + sc * 4) * 4u);
             }
             c0 += BK;
             if (c0 == p.Cin) {                        // uniform: next tap
@@ -183,6 +188,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
             for (int i = 0; i < AI; ++i) {
                 const bool ok = kok && ((amask[i] >> (tp & 31)) & 1u);
                 areg[i] = buf_load16(xr, ok ? (unsigned)aoff[i] + uoff : OOB);
+                if (GATE) areg[i] *= buf_load16(gr, kok ? gbase[i] + (unsigned)cc * 4u : OOB);
             }
         }
         const unsigned koff = (unsigned)kt * (BK * 4);
@@ -250,9 +256,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
         epilogue<ACT, RES, false, TM, TN>(p, acc, m_base, n_base, fr, fh);
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool CIN32, int ACT, bool RES>
+template <int BM, int BN, int WM, int WN, int BK, bool CIN32, int ACT, bool RES, bool GATE = false>
 int launch_inst(const ConvArgs &a, size_t lds, hipStream_t stream) {
-    auto kern = &conv_igemm_kernel<BM, BN, WM, WN, BK, CIN32, ACT, RES>;
+    auto kern = &conv_igemm_kernel<BM, BN, WM, WN, BK, CIN32, ACT, RES, GATE>;
     static bool attr_set = false;                  // > 64 KiB of dynamic LDS needs the opt-in once
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -266,6 +272,9 @@ int launch_inst(const ConvArgs &a, size_t lds, hipStream_t stream) {
 template <int BM, int BN, int WM, int WN, int BK, bool CIN32>
 int launch_act(const ConvArgs &a, size_t lds, hipStream_t stream) {
     const bool res = a.res != nullptr;
+    if (a.gate)         // only the MBConv project conv is gated: no activation (checked by the caller)
+        return res ? launch_inst<BM, BN, WM, WN, BK, CIN32, MYDET_ACT_NONE, true, true>(a, lds, stream)
+                   : launch_inst<BM, BN, WM, WN, BK, CIN32, MYDET_ACT_NONE, false, true>(a, lds, stream);
     switch (a.act) {
         case MYDET_ACT_LEAKY:
             return res ? launch_inst<BM, BN, WM, WN, BK, CIN32, MYDET_ACT_LEAKY, true>(a, lds, stream)
@@ -315,7 +324,8 @@ int forced_cfg() {
 }  // namespace
 
 extern "C" int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *w, const float *scale,
-                                      const float *shift, const float *residual, int64_t ldr, float *y,
+                                      const float *shift, const float *residual, int64_t ldr, const float *a_gate,
+                                      float *y,
                                       int64_t ldy, int B, int H, int W, int Cin, int Cout, int KH, int KW,
                                       int stride, int pad_t, int pad_l, int Ho, int Wo, int act, void *stream) {
     if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 ||
@@ -334,7 +344,9 @@ extern "C" int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *
     if (KH * KW > 31 || img_bytes * span_imgs >= 0x7FFFFFF0ll || (int64_t)Cout * KH * KW * Cin * 4 >= 0x7FFFFFF0ll)
         return MYDET_E_UNSUPP;
     ConvArgs a;
-    a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+    if (a_gate && (KH != 1 || KW != 1 || stride != 1 || act != MYDET_ACT_NONE || ((uintptr_t)a_gate & 15)))
+        return MYDET_E_UNSUPP;
+    a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.res = residual; a.gate = a_gate; a.y = y;
     a.ldx = ldx; a.ldr = ldr; a.ldy = ldy;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride;
     a.pad_t = pad_t; a.pad_l = pad_l; a.Ho = Ho; a.Wo = Wo; a.act = act;

@@ -1,0 +1,314 @@
+// HBM-bound kernels of the EfficientNet / BiFPN / EfDetHead family (NHWC, 16-byte lanes).
+//
+//   dwconv          depthwise k x k (k = 3, 5), stride 1/2, asymmetric "static SAME" pads, optional folded
+//                   BN + swish epilogue.  external/efficientnet/model.py:77 (_depthwise_conv),
+//                   models/modules.py:12-19 (SeparableConv2d.depthwise)
+//   squeeze_partial per-image channel sums over a slice of pixels (stage 1 of the SE global average pool)
+//   se_gate         stage 2 + both SE 1x1 convs: gate = sigmoid(W2 . swish(W1 . mean + b1) + b2)
+//                   external/efficientnet/model.py:80-83
+//   maxpool3s2      3x3 stride-2 pad-1 max pool (-inf padding)  models/backbones.py:186,188; models/fpns.py:405-416
+//   bifpn_fuse      y = swish(sum_i w_i * in_i), w = relu(weights)/(sum + 1e-4), where an input may be read
+//                   through nearest 2x upsampling or the 3x3/2 max pool on the fly  models/fpns.py:398-418,433-439
+// Each thread moves one float4 of channels; every tensor byte is read and written once per kernel.
+// Built with -ffp-contract=off so the fusion / gate arithmetic rounds like the reference's separate ops.
+#include "common.h"
+
+namespace {
+
+// --------------------------------------------------------------------------------------------- depthwise
+struct DwArgs {
+    const float *x, *w, *scale, *shift;
+    float *y;
+    int64_t ldx, ldy, total;
+    int C, H, W, Ho, Wo, stride, pad_t, pad_l, act;
+};
+
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_kernel(const DwArgs p) {
+    const int Q = p.C >> 2;
+    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < p.total; it += (int64_t)gridDim.x * 256) {
+        const int q = (int)(it % Q);
+        const int64_t pix = it / Q;
+        const int ow = (int)(pix % p.Wo);
+        const int64_t t = pix / p.Wo;
+        const int oh = (int)(t % p.Ho);
+        const int64_t b = t / p.Ho;
+        const int ih0 = oh * p.stride - p.pad_t, iw0 = ow * p.stride - p.pad_l;
+        const float *xb = p.x + (b * p.H * p.W) * p.ldx + q * 4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+            const int ih = ih0 + kh;
+            if ((unsigned)ih >= (unsigned)p.H) continue;
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                const int iw = iw0 + kw;
+                if ((unsigned)iw >= (unsigned)p.W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(xb + ((int64_t)ih * p.W + iw) * p.ldx);
+                const f32x4 wv = *reinterpret_cast<const f32x4 *>(p.w + (kh * K + kw) * p.C + q * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = fmaf(v[j], wv[j], acc[j]);
+            }
+        }
+        if (p.scale) {
+            const f32x4 sc = *reinterpret_cast<const f32x4 *>(p.scale + q * 4);
+            const f32x4 sh = *reinterpret_cast<const f32x4 *>(p.shift + q * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = acc[j] * sc[j] + sh[j];
+        }
+        if (p.act == MYDET_ACT_SWISH) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = acc[j] * mydet_sigmoid(acc[j]);
+        } else if (p.act == MYDET_ACT_LEAKY) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = acc[j] > 0.f ? acc[j] : acc[j] * 0.1f;
+        }
+        *reinterpret_cast<f32x4 *>(p.y + pix * p.ldy + q * 4) = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------ SE squeeze + gate
+// stage 1: partial[b][s][c] = sum over pixels of slice s of image b
+__global__ __launch_bounds__(256) void squeeze_partial_kernel(const float *x, int64_t ldx, int C, int HW, int S,
+                                                              float *partial) {
+    __shared__ f32x4 red[256];
+    const int Q = C >> 2;
+    const int b = blockIdx.y, s = blockIdx.x;
+    const int per = (HW + S - 1) / S;
+    const int p0 = s * per, p1 = min(HW, p0 + per);
+    const float *xb = x + (int64_t)b * HW * ldx;
+    for (int qb = 0; qb < Q; qb += 256) {               // channel-quad groups of 256 when Q > 256
+        const int nq = min(Q - qb, 256);
+        const int ph_n = nq < 256 ? 256 / nq : 1;
+        const int q = threadIdx.x % nq, ph = threadIdx.x / nq;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (ph < ph_n)
+            for (int px = p0 + ph; px < p1; px += ph_n) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(xb + (int64_t)px * ldx + (qb + q) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] += v[j];
+            }
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        if (threadIdx.x < nq) {
+            f32x4 tot = red[threadIdx.x];
+            for (int k = 1; k < ph_n; ++k) {
+                const f32x4 o = red[threadIdx.x + k * nq];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tot[j] += o[j];
+            }
+            *reinterpret_cast<f32x4 *>(partial + ((int64_t)b * S + s) * C + (qb + threadIdx.x) * 4) = tot;
+        }
+        __syncthreads();
+    }
+}
+
+// stage 2: one workgroup per image
+__global__ __launch_bounds__(256) void se_gate_kernel(const float *partial, int S, int C, int HW, const float *w1,
+                                                      const float *b1, int Cse, const float *w2, const float *b2,
+                                                      float *gate) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *mean = sm;                 // [C]
+    float *hid = sm + C;              // [Cse]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float inv = 1.0f / (float)HW;
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int k = 0; k < S; ++k) s += partial[((int64_t)b * S + k) * C + c];
+        mean[c] = s * inv;
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int o = wave; o < Cse; o += 4) {             // reduce conv: wave per output channel
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s = fmaf(w1[(int64_t)o * C + c], mean[c], s);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) {
+            s += b1[o];
+            hid[o] = s * mydet_sigmoid(s);
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {              // expand conv + sigmoid
+        float s = 0.f;
+        for (int k = 0; k < Cse; ++k) s = fmaf(w2[(int64_t)c * Cse + k], hid[k], s);
+        gate[(int64_t)b * C + c] = mydet_sigmoid(s + b2[c]);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------- max pool
+__global__ __launch_bounds__(256) void maxpool3s2_kernel(const float *x, int64_t ldx, float *y, int64_t ldy, int C,
+                                                         int H, int W, int Ho, int Wo, int64_t total) {
+    const int Q = C >> 2;
+    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+        const int q = (int)(it % Q);
+        const int64_t pix = it / Q;
+        const int ow = (int)(pix % Wo);
+        const int64_t t = pix / Wo;
+        const int oh = (int)(t % Ho);
+        const int64_t b = t / Ho;
+        const float ninf = -__builtin_inff();
+        f32x4 m = {ninf, ninf, ninf, ninf};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * 2 - 1 + kh;
+            if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow * 2 - 1 + kw;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(x + ((b * H + ih) * W + iw) * ldx + q * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], v[j]);
+            }
+        }
+        *reinterpret_cast<f32x4 *>(y + pix * ldy + q * 4) = m;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- BiFPN fusion
+struct FuseArgs {
+    const float *in[3];
+    int64_t ld[3];
+    int mode[3];              // 0 same size, 1 nearest 2x upsample of a half-size map, 2 3x3/2 max pool of a double-size map
+    int n;
+    const float *weights;     // raw (pre-relu) fusion weights [n]
+    float *y;
+    int64_t ldy, total;
+    int C, H, W;
+};
+
+__device__ __forceinline__ f32x4 fuse_read(const FuseArgs &p, int i, int64_t b, int oh, int ow, int q) {
+    const float *x = p.in[i];
+    const int64_t ld = p.ld[i];
+    if (p.mode[i] == 0) return *reinterpret_cast<const f32x4 *>(x + ((b * p.H + oh) * p.W + ow) * ld + q * 4);
+    if (p.mode[i] == 1) {
+        const int Hs = p.H >> 1, Ws = p.W >> 1;
+        return *reinterpret_cast<const f32x4 *>(x + ((b * Hs + (oh >> 1)) * Ws + (ow >> 1)) * ld + q * 4);
+    }
+    const int Hb = p.H * 2, Wb = p.W * 2;
+    const float ninf = -__builtin_inff();
+    f32x4 m = {ninf, ninf, ninf, ninf};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int ih = oh * 2 - 1 + kh;
+        if ((unsigned)ih >= (unsigned)Hb) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int iw = ow * 2 - 1 + kw;
+            if ((unsigned)iw >= (unsigned)Wb) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(x + ((b * Hb + ih) * Wb + iw) * ld + q * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], v[j]);
+        }
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(256) void bifpn_fuse_kernel(const FuseArgs p) {
+    // w = relu(weights); w = w / (sum(w) + 0.0001)      (models/fpns.py:435-436)
+    float w0 = fmaxf(p.weights[0], 0.0f), w1 = fmaxf(p.weights[1], 0.0f);
+    float w2 = p.n > 2 ? fmaxf(p.weights[2], 0.0f) : 0.0f;
+    float sum = w0 + w1;
+    if (p.n > 2) sum += w2;
+    sum += 0.0001f;
+    w0 = w0 / sum; w1 = w1 / sum; w2 = w2 / sum;
+    const int Q = p.C >> 2;
+    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < p.total; it += (int64_t)gridDim.x * 256) {
+        const int q = (int)(it % Q);
+        const int64_t pix = it / Q;
+        const int ow = (int)(pix % p.W);
+        const int64_t t = pix / p.W;
+        const int oh = (int)(t % p.H);
+        const int64_t b = t / p.H;
+        f32x4 acc;                                     // python sum(): 0 + w0*x0 + w1*x1 (+ w2*x2)
+        const f32x4 v0 = fuse_read(p, 0, b, oh, ow, q), v1 = fuse_read(p, 1, b, oh, ow, q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = w0 * v0[j] + w1 * v1[j];
+        if (p.n > 2) {
+            const f32x4 v2 = fuse_read(p, 2, b, oh, ow, q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = acc[j] + w2 * v2[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = acc[j] * mydet_sigmoid(acc[j]);
+        *reinterpret_cast<f32x4 *>(p.y + pix * p.ldy + q * 4) = acc;
+    }
+}
+
+inline unsigned grid_for(int64_t total) {
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    return (unsigned)(blocks < 1 ? 1 : blocks);
+}
+
+inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+extern "C" int mydet_dwconv_f32(const float *x, int64_t ldx, const float *w, const float *scale, const float *shift,
+                                float *y, int64_t ldy, int B, int H, int W, int C, int K, int stride, int pad_t,
+                                int pad_l, int Ho, int Wo, int act, void *stream) {
+    if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || stride <= 0) return MYDET_E_BADARG;
+    if ((C & 3) || (ldx & 3) || (ldy & 3) || ldx < C || ldy < C || !al16(x) || !al16(w) || !al16(y)) return MYDET_E_BADARG;
+    if ((scale == nullptr) != (shift == nullptr) || (scale && (!al16(scale) || !al16(shift)))) return MYDET_E_BADARG;
+    if (K != 3 && K != 5) return MYDET_E_UNSUPP;
+    DwArgs p;
+    p.x = x; p.w = w; p.scale = scale; p.shift = shift; p.y = y; p.ldx = ldx; p.ldy = ldy;
+    p.C = C; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l; p.act = act;
+    p.total = (int64_t)B * Ho * Wo * (C >> 2);
+    if (K == 3) hipLaunchKernelGGL(dwconv_kernel<3>, dim3(grid_for(p.total)), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(dwconv_kernel<5>, dim3(grid_for(p.total)), dim3(256), 0, (hipStream_t)stream, p);
+    return mydet_launch_status();
+}
+
+extern "C" int mydet_se_gate_f32(const float *x, int64_t ldx, int B, int H, int W, int C, const float *w1,
+                                 const float *b1, int Cse, const float *w2, const float *b2, float *gate,
+                                 float *scratch, int S, void *stream) {
+    if (!x || !w1 || !b1 || !w2 || !b2 || !gate || !scratch || B <= 0 || H <= 0 || W <= 0 || C <= 0 || Cse <= 0)
+        return MYDET_E_BADARG;
+    if ((C & 3) || (ldx & 3) || ldx < C || !al16(x) || !al16(scratch) || S <= 0 || S > 4096) return MYDET_E_BADARG;
+    const size_t lds = (size_t)(C + Cse) * sizeof(float);
+    if (lds > 64 * 1024) return MYDET_E_UNSUPP;
+    hipLaunchKernelGGL(squeeze_partial_kernel, dim3(S, B), dim3(256), 0, (hipStream_t)stream, x, ldx, C, H * W, S,
+                       scratch);
+    int rc = mydet_launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, scratch, S, C, H * W, w1, b1, Cse,
+                       w2, b2, gate);
+    return mydet_launch_status();
+}
+
+extern "C" int mydet_maxpool3s2_f32(const float *x, int64_t ldx, float *y, int64_t ldy, int B, int H, int W, int C,
+                                    int Ho, int Wo, void *stream) {
+    if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return MYDET_E_BADARG;
+    if ((C & 3) || (ldx & 3) || (ldy & 3) || ldx < C || ldy < C || !al16(x) || !al16(y)) return MYDET_E_BADARG;
+    if (Ho != (H + 2 - 3) / 2 + 1 || Wo != (W + 2 - 3) / 2 + 1) return MYDET_E_BADARG;
+    const int64_t total = (int64_t)B * Ho * Wo * (C >> 2);
+    hipLaunchKernelGGL(maxpool3s2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, C, H,
+                       W, Ho, Wo, total);
+    return mydet_launch_status();
+}
+
+extern "C" int mydet_bifpn_fuse_f32(int n, const float *in0, int64_t ld0, int mode0, const float *in1, int64_t ld1,
+                                    int mode1, const float *in2, int64_t ld2, int mode2, const float *weights, float *y,
+                                    int64_t ldy, int B, int H, int W, int C, void *stream) {
+    if (n < 2 || n > 3 || !in0 || !in1 || (n == 3 && !in2) || !weights || !y) return MYDET_E_BADARG;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || (ldy & 3) || ldy < C || !al16(y)) return MYDET_E_BADARG;
+    FuseArgs p;
+    const float *ins[3] = {in0, in1, in2};
+    const int64_t lds[3] = {ld0, ld1, ld2};
+    const int modes[3] = {mode0, mode1, mode2};
+    for (int i = 0; i < 3; ++i) {
+        p.in[i] = ins[i]; p.ld[i] = lds[i]; p.mode[i] = modes[i];
+        if (i < n) {
+            if (modes[i] < 0 || modes[i] > 2 || (lds[i] & 3) || lds[i] < C || !al16(ins[i])) return MYDET_E_BADARG;
+            if (modes[i] == 1 && ((H & 1) || (W & 1))) return MYDET_E_BADARG;
+        }
+    }
+    p.n = n; p.weights = weights; p.y = y; p.ldy = ldy; p.C = C; p.H = H; p.W = W;
+    p.total = (int64_t)B * H * W * (C >> 2);
+    hipLaunchKernelGGL(bifpn_fuse_kernel, dim3(grid_for(p.total)), dim3(256), 0, (hipStream_t)stream, p);
+    return mydet_launch_status();
+}

@@ -1,7 +1,8 @@
 """Backbones of the hot path (reference: models/backbones.py)."""
 import torch.nn as nn
 
-from .modules import ConvBnLeaky, DarkBlock
+from .. import ops
+from .modules import ConvBn, ConvBnLeaky, DarkBlock
 
 
 class Darknet53(nn.Module):
@@ -30,3 +31,73 @@ class Darknet53(nn.Module):
             if i in (14, 23, 28):
                 feats.append(x)
         return feats
+
+
+class _PoolAfter(ConvBn):
+    """nn.Sequential(Conv2d, BatchNorm2d, MaxPool2d(3, 2, 1)): fused conv+BN launch, then the pool kernel."""
+    def __init__(self, in_ch, out_ch, k, padding):
+        super().__init__(in_ch, out_ch, k, padding)
+        self.add_module('2', nn.MaxPool2d(3, stride=2, padding=1))       # parameter-free; keeps the index layout
+
+    def forward(self, x):
+        return ops.maxpool3s2(ConvBn.forward(self, x))
+
+
+class _MaxPool(nn.Module):
+    def forward(self, x):
+        return ops.maxpool3s2(x)
+
+
+class EfNetBackbone(nn.Module):
+    '''
+    EfficientNet feature extractor + C6/C7 (reference: models/backbones.py:155-232).  Returns
+    [C3, C4, C5] or [C3, C4, C5, C6, C7]; a feature is tapped whenever the spatial size changes.
+    '''
+    valid_names = {'efficientnet-b0', 'efficientnet-b1', 'efficientnet-b2', 'efficientnet-b3', 'efficientnet-b4',
+                   'efficientnet-b5', 'efficientnet-b6'}
+
+    def __init__(self, cfg: dict):
+        super().__init__()
+        model_name = cfg['model.backbone.name']
+        assert model_name in self.valid_names, 'Unknown efficientnet model name'
+        from ..external.efficientnet.model import EfficientNet
+        efn = EfficientNet.from_name(model_name)
+        self.model = efn
+        efnet_chs = [efn._blocks_args[i].output_filters for i in [2, 4, 6]]
+        if cfg['model.backbone.num_levels'] == 3:
+            self.feature_chs = efnet_chs
+            self.feature_strides = (8, 16, 32)
+            self.C6C7 = False
+        elif cfg['model.backbone.num_levels'] == 5:
+            out_ch = cfg['model.backbone.C6C7_out_channels']
+            downsample_layer = cfg.get('model.efficientnet.C6C7_downsample', 'maxpool')
+            if downsample_layer == 'maxpool':
+                self.c5_to_c6 = _PoolAfter(efnet_chs[-1], out_ch, 1, 0)
+                self.c6_to_c7 = _MaxPool()
+            elif downsample_layer == 'conv':
+                self.c5_to_c6 = _PoolAfter(efnet_chs[-1], out_ch, 3, 1)
+                self.c6_to_c7 = _PoolAfter(out_ch, out_ch, 3, 1)
+            else:
+                raise NotImplementedError()
+            self.feature_chs = efnet_chs + [out_ch, out_ch]
+            self.feature_strides = (8, 16, 32, 64, 128)
+            self.C6C7 = True
+        else:
+            raise NotImplementedError()
+        self.enable_dropout = cfg['model.efficientnet.enable_dropout']     # drop-connect: identity at inference
+
+    def forward(self, x):
+        x = self.model.stem(x)
+        features = []
+        for block in self.model._blocks:
+            y = block(x)
+            if y.shape[-1] != x.shape[-1]:
+                features.append(x)
+            x = y
+        features.append(x)
+        C1, C2, C3, C4, C5 = features
+        if self.C6C7:
+            C6 = self.c5_to_c6(C5)
+            C7 = self.c6_to_c7(C6)
+            return [C3, C4, C5, C6, C7]
+        return [C3, C4, C5]

@@ -38,7 +38,7 @@ class YOLOLayer(nn.Module):
         assert self.n_cls > 0
         packed = getattr(raw, 'packed', None)
         if packed is not None:
-            head, ld, _, per = packed
+            head, ld, per, _ = packed['box']
         else:
             head, ld, per = pack_pixel_major([raw['bbox'], raw['conf'], raw['class']], nA)
         n = nA * nH * nW

@@ -1,8 +1,9 @@
 """Feature pyramids of the hot path (reference: models/fpns.py)."""
+import torch
 import torch.nn as nn
 
 from .. import ops
-from .modules import ConvBnLeaky
+from .modules import ConvBn, ConvBnLeaky, SpconvBn
 
 
 class YOLOv3FPN(nn.Module):
@@ -58,3 +59,90 @@ class YOLOBranch(nn.Module):
         feature = self.cbl_4(x)
         x = self.cbl_5(feature)
         return x, feature
+
+
+def get_bifpn(cfg: dict):
+    '''repeat_num stacked BiFPN layers; only the first projects the backbone channels (reference: models/fpns.py:294-312)'''
+    in_channels = cfg['model.backbone.out_channels']
+    out_ch = cfg['model.bifpn.out_ch']
+    repeat_num = cfg['model.bifpn.repeat_num']
+    fusion_method = cfg['model.bifpn.fusion_method']
+    assert repeat_num >= 1
+    if len(in_channels) != 5:
+        raise NotImplementedError()
+    fpn = [BiFPN5(out_ch, fusion_method=fusion_method, in_chs=in_channels)]
+    for _ in range(repeat_num - 1):
+        fpn.append(BiFPN5(out_ch, fusion_method=fusion_method))
+    return nn.Sequential(*fpn)
+
+
+def conv1x1_bn(in_ch, out_ch):
+    return ConvBn(in_ch, out_ch, 1, 0)
+
+
+def _identity(x):
+    return x
+
+
+class BiFPN5(nn.Module):
+    '''
+    One bidirectional pyramid layer over P3..P7 (reference: models/fpns.py:357-418).  The nearest-2x
+    upsampling of the top-down path and the max_pool2d(3,2,1) of the bottom-up path are never
+    materialised: the fusion kernel reads the coarser / finer map through them.
+    '''
+    def __init__(self, fpn_ch, fusion_method='linear', in_chs=None):
+        super().__init__()
+        if in_chs:
+            assert len(in_chs) == 5
+            assert in_chs[3] == in_chs[4] == fpn_ch
+            self.p3in_out = conv1x1_bn(in_chs[0], fpn_ch)
+            self.p4in_m = conv1x1_bn(in_chs[1], fpn_ch)
+            self.p4in_out = conv1x1_bn(in_chs[1], fpn_ch)
+            self.p5in_m = conv1x1_bn(in_chs[2], fpn_ch)
+            self.p5in_out = conv1x1_bn(in_chs[2], fpn_ch)
+        else:
+            self.p3in_out = self.p4in_m = self.p4in_out = self.p5in_m = self.p5in_out = _identity
+        if fusion_method != 'linear':
+            raise NotImplementedError()
+        self.fuse_6m = LinearFusion(num=2, channels=fpn_ch)
+        self.fuse_5m = LinearFusion(num=2, channels=fpn_ch)
+        self.fuse_4m = LinearFusion(num=2, channels=fpn_ch)
+        self.fuse_3out = LinearFusion(num=2, channels=fpn_ch)
+        self.fuse_4out = LinearFusion(num=3, channels=fpn_ch)
+        self.fuse_5out = LinearFusion(num=3, channels=fpn_ch)
+        self.fuse_6out = LinearFusion(num=3, channels=fpn_ch)
+        self.fuse_7out = LinearFusion(num=2, channels=fpn_ch)
+
+    def forward(self, features):
+        P3in, P4in, P5in, P6in, P7in = features
+        assert P3in.shape[2] == P4in.shape[2] * 2 == P5in.shape[2] * 4 == P6in.shape[2] * 8 == P7in.shape[2] * 16
+        up, down = ops.FUSE_UP2X, ops.FUSE_POOL
+        P6m = self.fuse_6m(P6in, (P7in, up))
+        P5m = self.fuse_5m(self.p5in_m(P5in), (P6m, up))
+        P4m = self.fuse_4m(self.p4in_m(P4in), (P5m, up))
+        P3out = self.fuse_3out(self.p3in_out(P3in), (P4m, up))
+        P4out = self.fuse_4out(self.p4in_out(P4in), P4m, (P3out, down))
+        P5out = self.fuse_5out(self.p5in_out(P5in), P5m, (P4out, down))
+        P6out = self.fuse_6out(P6in, P6m, (P5out, down))
+        P7out = self.fuse_7out(P7in, (P6out, down))
+        return [P3out, P4out, P5out, P6out, P7out]
+
+
+class LinearFusion(nn.Module):
+    '''
+    fused = sum(w_i * x_i), w = relu(weights) / (sum + 1e-4); out = BN(pointwise(depthwise(swish(fused))))
+    (reference: models/fpns.py:421-439).  A feature may be given as (tensor, ops.FUSE_UP2X | ops.FUSE_POOL)
+    to be read through nearest-2x upsampling / 3x3-stride-2 max pooling inside the fusion kernel.
+    '''
+    def __init__(self, num, channels):
+        super().__init__()
+        self.num = num
+        self.weights = nn.Parameter(torch.ones(num), requires_grad=True)
+        self.spconv_bn = SpconvBn(channels, swish=False)
+
+    def forward(self, *features):
+        assert isinstance(features, (list, tuple)) and len(features) == self.num
+        tensors = [f[0] if isinstance(f, tuple) else f for f in features]
+        modes = [f[1] if isinstance(f, tuple) else ops.FUSE_SAME for f in features]
+        fused = ops.bifpn_fuse(tensors, modes, self.weights.detach())
+        return self.spconv_bn(fused)

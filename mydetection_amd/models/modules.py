@@ -18,30 +18,42 @@ def _versions(*tensors):
     return tuple((t.data_ptr(), t._version) for t in tensors)
 
 
+def prepare_conv(owner, slot, conv, bn, depthwise=False):
+    """Kernel-ready parameters of `conv` (+ optional eval-mode `bn` folded into per-channel scale/shift):
+    (weights OHWI -- or [k,k,C] for a depthwise conv --, scale or None, shift or None).  Cached on `owner`
+    under `slot` and rebuilt when any source tensor is replaced or modified in place."""
+    tensors = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
+    if conv.bias is not None:
+        tensors.append(conv.bias)
+    key = _versions(*tensors)
+    cache = owner.__dict__.setdefault('_prep_cache', {})
+    hit = cache.get(slot)
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            w = conv.weight.detach().float()
+            if depthwise:
+                w = w.permute(2, 3, 0, 1).reshape(w.shape[2], w.shape[3], w.shape[0]).contiguous()   # [C,1,k,k] -> [k,k,C]
+            else:
+                w = w.permute(0, 2, 3, 1).contiguous()                                               # OIHW -> OHWI
+            if bn is not None:
+                inv = (bn.running_var.float() + bn.eps).sqrt().reciprocal()
+                scale = (bn.weight.float() * inv).contiguous()
+                shift = (bn.bias.float() - bn.running_mean.float() * scale).contiguous()
+                if conv.bias is not None:
+                    shift = (shift + conv.bias.float() * scale).contiguous()
+            else:
+                scale = None
+                shift = conv.bias.detach().float().contiguous() if conv.bias is not None else None
+        hit = (key, (w, scale, shift))
+        cache[slot] = hit
+    return hit[1]
+
+
 class FusedConvMixin:
     """Caches kernel-ready parameters (OHWI weights, per-channel scale/shift)."""
-    _prep = None
-    _prep_key = None
 
     def _prepared(self, conv, bn):
-        tensors = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None
-                                   else ([conv.bias] if conv.bias is not None else []))
-        key = _versions(*tensors)
-        if self._prep_key != key:
-            with torch.no_grad():
-                w = conv.weight.detach().permute(0, 2, 3, 1).contiguous().float()     # OIHW -> OHWI
-                if bn is not None:
-                    inv = (bn.running_var.float() + bn.eps).sqrt().reciprocal()
-                    scale = (bn.weight.float() * inv).contiguous()
-                    shift = (bn.bias.float() - bn.running_mean.float() * scale).contiguous()
-                    if conv.bias is not None:
-                        shift = (shift + conv.bias.float() * scale).contiguous()
-                else:
-                    scale = None
-                    shift = conv.bias.detach().float().contiguous() if conv.bias is not None else None
-            self._prep = (w, scale, shift)
-            self._prep_key = key
-        return self._prep
+        return prepare_conv(self, 'main', conv, bn)
 
 
 class ConvBnLeaky(nn.Module, FusedConvMixin):
@@ -79,3 +91,57 @@ class DarkBlock(nn.Module):
 
     def forward(self, x):
         return self.cbl_1(self.cbl_0(x), residual=x)
+
+
+class Swish(nn.Module):
+    """x * sigmoid(x) (reference: models/modules.py:41-43).  Parameter-free placeholder: every swish on the
+    hot path is fused into the producing kernel's epilogue."""
+    def forward(self, x):
+        raise NotImplementedError('Swish is fused into the producing conv kernel on the inference path')
+
+
+class SeparableConv2d(nn.Module):
+    '''
+    Depthwise (no bias) -> pointwise 1x1 (bias), two HIP launches (reference: models/modules.py:5-21).
+    `bn`/`act` let the caller fold a following BatchNorm2d / swish into the pointwise epilogue.
+    '''
+    def __init__(self, in_ch, out_ch, kernel_size, stride, padding):
+        super().__init__()
+        self.k, self.s, self.p = kernel_size, stride, padding
+        self.depthwise = nn.Conv2d(in_ch, in_ch, kernel_size, stride, padding=padding, groups=in_ch, bias=False)
+        self.pointwise = nn.Conv2d(in_ch, out_ch, 1, 1, padding=0)
+
+    def forward(self, x, bn=None, act=ops.ACT_NONE):
+        if self.training:
+            raise NotImplementedError('mydetection_amd implements the inference path only; call model.eval()')
+        wd, _, _ = prepare_conv(self, 'dw', self.depthwise, None, depthwise=True)
+        x = ops.dwconv(x, wd, None, None, self.k, self.s, (self.p,) * 4, ops.ACT_NONE)
+        wp, scale, shift = prepare_conv(self, ('pw', id(bn)), self.pointwise, bn)
+        return ops.conv2d(x, wp, scale, shift, 1, 1, (0, 0, 0, 0), act)
+
+
+class ConvBn(nn.Sequential):
+    """nn.Sequential(Conv2d(+bias), BatchNorm2d) evaluated as one fused conv launch
+    (reference: conv1x1_bn models/fpns.py:446-450; c5_to_c6 / c6_to_c7 convs models/backbones.py:183-200)."""
+    def __init__(self, in_ch, out_ch, k=1, padding=0, eps=0.001):
+        super().__init__(nn.Conv2d(in_ch, out_ch, k, stride=1, padding=padding),
+                         nn.BatchNorm2d(out_ch, eps=eps, momentum=0.01))
+        self.k, self.p = k, padding
+
+    def forward(self, x):
+        w, scale, shift = prepare_conv(self, 'main', self[0], self[1])
+        return ops.conv2d(x, w, scale, shift, self.k, 1, (self.p,) * 4, ops.ACT_NONE)
+
+
+class SpconvBn(nn.Sequential):
+    """nn.Sequential(SeparableConv2d, BatchNorm2d[, Swish]) with BN (+ swish) folded into the pointwise conv
+    (reference: LinearFusion.spconv_bn models/fpns.py:426-429; spconv3x3_bn_swish models/rpns.py:199-205)."""
+    def __init__(self, ch, swish):
+        mods = [SeparableConv2d(ch, ch, 3, 1, padding=1), nn.BatchNorm2d(ch, eps=0.001, momentum=0.01)]
+        if swish:
+            mods.append(Swish())
+        super().__init__(*mods)
+        self.act = ops.ACT_SWISH if swish else ops.ACT_NONE
+
+    def forward(self, x):
+        return self[0](x, bn=self[1], act=self.act)

@@ -29,6 +29,11 @@ def get_backbone(cfg: dict):
             print(f"Using backbone Darknet-53. No ImageNet weights at {path}; keeping initial weights.")
         out_feature_channels = (256, 512, 1024)
         out_strides = (8, 16, 32)
+    elif backbone_name.startswith('efficientnet'):
+        from .backbones import EfNetBackbone
+        backbone = EfNetBackbone(cfg)            # the reference downloads ImageNet weights here; none offline
+        out_feature_channels = backbone.feature_chs
+        out_strides = backbone.feature_strides
     else:
         raise Exception('Unknown backbone name')
 
@@ -47,6 +52,12 @@ def get_fpn(cfg: dict):
         fpn = YOLOv3FPN(cfg)
         out_feature_channels = cfg['model.backbone.out_channels']
         out_strides = cfg['model.backbone.out_strides']
+    elif fpn_name == 'bifpn':
+        from .fpns import get_bifpn
+        fpn = get_bifpn(cfg)
+        ch = cfg['model.bifpn.out_ch']
+        out_feature_channels = [ch for _ in cfg['model.backbone.out_channels']]
+        out_strides = cfg['model.backbone.out_strides']
     else:
         raise Exception('Unknown FPN name')
 
@@ -63,6 +74,9 @@ def get_rpn(cfg: dict):
     if rpn_name == 'yolov3':
         from .rpns import YOLOHead
         rpn = YOLOHead(cfg)
+    elif rpn_name == 'effrpn':
+        from .rpns import EfDetHead
+        rpn = EfDetHead(cfg)
     else:
         raise NotImplementedError()
     return rpn
@@ -76,5 +90,11 @@ def get_det_layer(cfg: dict):
     if det_layer_name == 'YOLO':
         from .detlayers.yolov3 import YOLOLayer
         return YOLOLayer
+    elif det_layer_name == 'RetinaNet':
+        from .detlayers.retinanet import RetinaLayer
+        return RetinaLayer
+    elif det_layer_name == 'FCOS2_ATSS':
+        from .detlayers.fcos2 import FCOS_ATSS_Layer
+        return FCOS_ATSS_Layer
     else:
         raise NotImplementedError()

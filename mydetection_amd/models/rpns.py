@@ -2,13 +2,17 @@
 import torch.nn as nn
 
 from .. import ops
-from .modules import FusedConvMixin
+import numpy as np
+import torch
+
+from .modules import FusedConvMixin, SeparableConv2d, SpconvBn, prepare_conv
 
 
 class RawPreds(dict):
     """The reference's raw-prediction dict ('bbox', 'conf', 'class' views) plus a handle on the
     pixel-major head tensor the views alias, so the decode kernel can read it in place."""
-    packed = None        # (tensor [B,ch,H,W] channels-last, ld, n_anchor, per-anchor channel count)
+    packed = None        # dict(box=(tensor, ld, astride, c0), cls=(tensor, ld, astride, c0, conf_c0)); tensors are
+                         # logical [B,ch,H,W] stored channels-last with pixel stride ld
 
 
 class _HeadConv(nn.Conv2d, FusedConvMixin):
@@ -51,6 +55,96 @@ class YOLOHead(nn.Module):
                 raw['bbox'] = preds[:, 0:nBp, :, :].permute(0, 2, 3, 1)
                 raw['conf'] = preds[:, nBp:nBp + 1, :, :].permute(0, 2, 3, 1)
                 raw['class'] = preds[:, nBp + 1:, :, :].permute(0, 2, 3, 1)
-            raw.packed = (preds, ops.nhwc_ld(preds), self.n_anch, per)
+            ld = ops.nhwc_ld(preds)
+            raw.packed = {'box': (preds, ld, per, 0), 'cls': (preds, ld, per, nBp + 1, nBp)}
+            all_level_preds.append(raw)
+        return all_level_preds
+
+
+def spconv3x3_bn_swish(inout_ch):
+    return SpconvBn(inout_ch, swish=True)
+
+
+class _LastConv(nn.Conv2d):
+    """Dense 3x3 `cls_last` conv (reference: models/rpns.py:155-158) as one implicit-GEMM launch."""
+    def forward(self, x):
+        w, scale, shift = prepare_conv(self, 'main', self, None)
+        return ops.conv2d(x, w, scale, shift, 3, 1, (1, 1, 1, 1), ops.ACT_NONE)
+
+
+class EfDetHead(nn.Module):
+    '''
+    Per-level class and box towers: repeat x (sepconv -> BN -> swish) then a last sepconv (or dense conv)
+    (reference: models/rpns.py:121-197).  Weights are not shared across levels.  Output dict per level:
+    'bbox' [B,A,H,W,4] (or [B,H,W,4] when A == 1), 'class' [...,n_cls], and 'conf' = class channel 0
+    when enable_conf.
+    '''
+    def __init__(self, cfg: dict):
+        super().__init__()
+        n_cls = cfg['general.num_class']
+        n_anch = cfg['model.effrpn.num_anchor_per_level']
+        feature_chs = cfg['model.fpn.out_channels']
+        repeat = cfg['model.effrpn.repeat_num']
+        bb_param = cfg.get('general.bbox_param', 4)
+        enable_conf = cfg['model.effrpn.enable_conf']
+        bbox_last_type = cfg.get('model.effrpn.bbox_last', 'default')
+        cls_last_type = cfg.get('model.effrpn.cls_last', 'spconv')
+        if bbox_last_type != 'default':
+            raise NotImplementedError()
+        self.class_nets = nn.ModuleList()
+        self.bbox_nets = nn.ModuleList()
+        cls_ch = n_anch * (1 + n_cls) if enable_conf else n_anch * n_cls
+        for ch in feature_chs:
+            bb_net = [spconv3x3_bn_swish(ch) for _ in range(repeat)]
+            bb_net.append(SeparableConv2d(ch, n_anch * bb_param, 3, 1, padding=1))
+            self.bbox_nets.append(nn.Sequential(*bb_net))
+            cls_net = [spconv3x3_bn_swish(ch) for _ in range(repeat)]
+            # final bias -log((1 - 0.01) / 0.01): initial confidences close to 0.01 (reference :150-158)
+            if cls_last_type == 'spconv':
+                cls_last = SeparableConv2d(ch, cls_ch, 3, 1, padding=1)
+                cls_last.pointwise.weight.data.normal_(mean=0, std=0.1)
+                cls_last.pointwise.bias.data.fill_(-np.log((1 - 0.01) / 0.01))
+            elif cls_last_type == 'conv':
+                cls_last = _LastConv(ch, cls_ch, 3, 1, padding=1)
+                cls_last.weight.data.normal_(mean=0, std=0.1)
+                cls_last.bias.data.fill_(-np.log((1 - 0.01) / 0.01))
+            else:
+                raise NotImplementedError()
+            cls_net.append(cls_last)
+            self.class_nets.append(nn.Sequential(*cls_net))
+        self.n_anch = n_anch
+        self.n_cls = n_cls
+        self.bb_param = bb_param
+        self.enable_conf = enable_conf
+
+    def forward(self, features: list):
+        all_level_preds = []
+        for i, x in enumerate(features):
+            cls_pred = self.class_nets[i](x)
+            bbox_pred = self.bbox_nets[i](x)
+            nB, _, nH, nW = bbox_pred.shape
+            nA = self.n_anch
+            per_cls = self.n_cls + 1 if self.enable_conf else self.n_cls
+            packed = {'box': (bbox_pred, ops.nhwc_ld(bbox_pred), self.bb_param, 0),
+                      'cls': (cls_pred, ops.nhwc_ld(cls_pred), per_cls, 1 if self.enable_conf else 0, 0)}
+            if nA >= 2:
+                bbox_v = bbox_pred.view(nB, nA, -1, nH, nW).permute(0, 1, 3, 4, 2)
+                cls_v = cls_pred.view(nB, nA, -1, nH, nW).permute(0, 1, 3, 4, 2)
+            elif nA == 1:
+                assert bbox_pred.shape[1] == 4
+                bbox_v = bbox_pred.permute(0, 2, 3, 1)
+                cls_v = cls_pred.permute(0, 2, 3, 1)
+            else:
+                raise Exception()
+            raw = RawPreds()
+            raw['bbox'] = bbox_v
+            if self.enable_conf:
+                assert cls_v.shape[-1] == self.n_cls + 1
+                raw['conf'] = cls_v[..., 0:1]
+                raw['class'] = cls_v[..., 1:]
+            else:
+                assert cls_v.shape[-1] == self.n_cls
+                raw['class'] = cls_v
+            raw.packed = packed
             all_level_preds.append(raw)
         return all_level_preds

@@ -95,8 +95,9 @@ def conv_out_size(n, k, stride, pad_lo, pad_hi):
     return (n + pad_lo + pad_hi - k) // stride + 1
 
 
-def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None, out_ld=None):
-    """y = act(conv(x)*scale + shift) + residual.  x logical [B,Cin,H,W]; pad=(top,left,bottom,right)."""
+def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None, out_ld=None, gate=None):
+    """y = act(conv(x * gate)*scale + shift) + residual.  x logical [B,Cin,H,W]; pad=(top,left,bottom,right);
+    gate: optional [B,Cin] per-image channel multipliers (squeeze-excite), 1x1 convs only."""
     require_gpu(x, 'conv2d')
     x, ldx = to_nhwc(x)
     B, Cin, H, W = x.shape
@@ -114,7 +115,7 @@ def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None
         assert residual.shape == out.shape
     t0 = TIMER.start() if TIMER else None
     code = _lib.lib().mydet_conv2d_igemm_f32(
-        _ptr(x), ldx, _ptr(w_ohwi), _ptr(scale), _ptr(shift), _ptr(residual), ldr, _ptr(out), ldy,
+        _ptr(x), ldx, _ptr(w_ohwi), _ptr(scale), _ptr(shift), _ptr(residual), ldr, _ptr(gate), _ptr(out), ldy,
         B, H, W, Cin, Cout, k, k, stride, pad[0], pad[1], Ho, Wo, act, _stream())
     if t0:
         name = f'conv_igemm {Cin}->{Cout} k{k}s{stride} {H}x{W}' if TIMER_DETAIL else 'conv_igemm'
@@ -140,6 +141,86 @@ def conv2d_stem(x, w_ohwi, scale, shift, stride, pad, act):
     if t0:
         TIMER.stop('conv_stem', t0, 4.0 * B * (3 * H * W + Cout * Ho * Wo))        # bytes moved
     _lib.check(code, 'mydet_conv2d_stem_f32')
+    return out
+
+
+def dwconv(x, w_kkc, scale, shift, k, stride, pad, act):
+    """Depthwise k x k conv, y = act(conv*scale + shift); w_kkc [k,k,C]; pad=(top,left,bottom,right)."""
+    require_gpu(x, 'dwconv')
+    x, ldx = to_nhwc(x)
+    B, C, H, W = x.shape
+    Ho = conv_out_size(H, k, stride, pad[0], pad[2])
+    Wo = conv_out_size(W, k, stride, pad[1], pad[3])
+    out, ldy = empty_nhwc(B, C, Ho, Wo, x.device)
+    t0 = TIMER.start() if TIMER else None
+    code = _lib.lib().mydet_dwconv_f32(_ptr(x), ldx, _ptr(w_kkc), _ptr(scale), _ptr(shift), _ptr(out), ldy, B, H, W, C,
+                                       k, stride, pad[0], pad[1], Ho, Wo, act, _stream())
+    if t0:
+        TIMER.stop('dwconv', t0, 4.0 * B * C * (H * W + Ho * Wo))
+    _lib.check(code, 'mydet_dwconv_f32')
+    return out
+
+
+def se_gate(x, w1, b1, w2, b2):
+    """Squeeze-excite gate [B,C] of x [B,C,H,W]: sigmoid(W2 . swish(W1 . mean_hw(x) + b1) + b2)."""
+    require_gpu(x, 'se_gate')
+    x, ldx = to_nhwc(x)
+    B, C, H, W = x.shape
+    Cse = w1.shape[0]
+    S = max(1, min(256, (H * W) // 256))
+    gate = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    scratch = torch.empty((B, S, C), dtype=torch.float32, device=x.device)
+    t0 = TIMER.start() if TIMER else None
+    code = _lib.lib().mydet_se_gate_f32(_ptr(x), ldx, B, H, W, C, _ptr(w1), _ptr(b1), Cse, _ptr(w2), _ptr(b2),
+                                        _ptr(gate), _ptr(scratch), S, _stream())
+    if t0:
+        TIMER.stop('se_gate', t0, 4.0 * B * C * H * W)
+    _lib.check(code, 'mydet_se_gate_f32')
+    return gate
+
+
+def maxpool3s2(x):
+    """max_pool2d(x, kernel_size=3, stride=2, padding=1)."""
+    require_gpu(x, 'maxpool3s2')
+    x, ldx = to_nhwc(x)
+    B, C, H, W = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out, ldy = empty_nhwc(B, C, Ho, Wo, x.device)
+    t0 = TIMER.start() if TIMER else None
+    code = _lib.lib().mydet_maxpool3s2_f32(_ptr(x), ldx, _ptr(out), ldy, B, H, W, C, Ho, Wo, _stream())
+    if t0:
+        TIMER.stop('maxpool', t0, 4.0 * B * C * (H * W + Ho * Wo))
+    _lib.check(code, 'mydet_maxpool3s2_f32')
+    return out
+
+
+FUSE_SAME, FUSE_UP2X, FUSE_POOL = 0, 1, 2
+
+
+def bifpn_fuse(inputs, modes, weights):
+    """swish(sum_i w_i * in_i) with w = relu(weights)/(sum+1e-4).  inputs: 2-3 tensors; modes[i] in
+    FUSE_SAME / FUSE_UP2X (half-size map, nearest 2x) / FUSE_POOL (double-size map, max-pool 3/2/1).
+    The output has the size of the FUSE_SAME input(s)."""
+    n = len(inputs)
+    require_gpu(inputs[0], 'bifpn_fuse')
+    prepared = [to_nhwc(t) for t in inputs]
+    ref = next(t for (t, _), m in zip(prepared, modes) if m == FUSE_SAME)
+    B, C, H, W = ref.shape
+    for (t, _), m in zip(prepared, modes):
+        exp = {FUSE_SAME: (H, W), FUSE_UP2X: (H // 2, W // 2), FUSE_POOL: (H * 2, W * 2)}[m]
+        assert tuple(t.shape) == (B, C) + exp, (tuple(t.shape), m, (B, C, H, W))
+    out, ldy = empty_nhwc(B, C, H, W, ref.device)
+    args = []
+    for i in range(3):
+        if i < n:
+            args += [_ptr(prepared[i][0]), prepared[i][1], int(modes[i])]
+        else:
+            args += [ctypes.c_void_p(0), 0, 0]
+    t0 = TIMER.start() if TIMER else None
+    code = _lib.lib().mydet_bifpn_fuse_f32(n, *args, _ptr(weights), _ptr(out), ldy, B, H, W, C, _stream())
+    if t0:
+        TIMER.stop('bifpn_fuse', t0, 4.0 * B * C * H * W * (n + 1))
+    _lib.check(code, 'mydet_bifpn_fuse_f32')
     return out
 
 

@@ -56,6 +56,37 @@ def _yolo_head(key, shape, n_cls=80):
     return w * (tgt / (np.sqrt(fan_in) * rms)).reshape(-1, 1, 1, 1).astype(np.float32)
 
 
+# rms of the tower output feeding the last conv of each EfDetHead branch (measured after BN
+# calibration, oracle forward at 512x512); used to set the final-layer gains.
+_EFDET_LAST_FEATURE_RMS = 0.6
+
+
+def _efdet_last(key, shape):
+    """Final layers of EfDetHead (models/rpns.py:139-160): rpn.{class,bbox}_nets.{lvl}.3[.pointwise].{weight,bias}.
+    Class/conf logits: std 1.5, bias -7 (long-tailed scores; the reference initialises the bias to -4.595);
+    box logits: std 0.5."""
+    is_cls = key.startswith('rpn.class_nets.')
+    tgt = 1.5 if is_cls else 0.5
+    if key.endswith('.bias'):
+        return np.float32(-7.0 if is_cls else 0.0) + _normal(key, shape, std=0.05)
+    fan_in = shape[1] * shape[2] * shape[3]
+    return _normal(key, shape, std=tgt / (np.sqrt(fan_in) * _EFDET_LAST_FEATURE_RMS))
+
+
+_CALIB_CACHE = {}
+
+
+def load_calibration(config_name):
+    """BN running statistics measured once on synthetic images (oracle/calibrate_bn.py), or {}.
+    Random running stats do not normalise anything, and through 23 MBConv blocks + 4 BiFPN layers the
+    activations run away; the EfficientDet-family configs therefore ship calibrated statistics."""
+    import os
+    if config_name not in _CALIB_CACHE:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'calib', f'{config_name}.npz')
+        _CALIB_CACHE[config_name] = dict(np.load(path)) if os.path.exists(path) else {}
+    return _CALIB_CACHE[config_name]
+
+
 def make_tensor(key: str, shape, dtype=torch.float32) -> torch.Tensor:
     """The synthetic value of parameter/buffer `key`."""
     shape = tuple(shape)
@@ -63,6 +94,11 @@ def make_tensor(key: str, shape, dtype=torch.float32) -> torch.Tensor:
         return torch.zeros(shape, dtype=torch.int64)
     if key.startswith('rpn.heads.conv_'):
         arr = _yolo_head(key, shape)
+    elif key.startswith(('rpn.class_nets.', 'rpn.bbox_nets.')) and '.3.' in key and (
+            'pointwise' in key or len(key.split('.')) == 5):
+        arr = _efdet_last(key, shape)
+    elif key.endswith('.weights'):                           # BiFPN fusion weights (models/fpns.py:425)
+        arr = _uniform(key, shape, 0.5, 1.5)
     elif key.endswith('running_var'):
         arr = _uniform(key, shape, 0.5, 1.5)
     elif key.endswith('running_mean'):
@@ -80,9 +116,17 @@ def make_tensor(key: str, shape, dtype=torch.float32) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(arr)).to(dtype)
 
 
-def make_state_dict(template) -> dict:
-    """template: mapping key -> tensor (only shape/dtype are used)."""
-    return {k: make_tensor(k, v.shape, v.dtype) for k, v in template.items()}
+def make_state_dict(template, config_name=None) -> dict:
+    """template: mapping key -> tensor (only shape/dtype are used).  With `config_name`, BN running
+    statistics come from mydetection_amd/calib/<config_name>.npz when that file exists."""
+    calib = load_calibration(config_name) if config_name else {}
+    out = {}
+    for k, v in template.items():
+        if k in calib:
+            out[k] = torch.from_numpy(np.ascontiguousarray(calib[k])).to(v.dtype)
+        else:
+            out[k] = make_tensor(k, v.shape, v.dtype)
+    return out
 
 
 def make_images(batch: int, size, seed: int = 0, kind: str = 'rects') -> torch.Tensor:
@@ -108,3 +152,15 @@ def make_images(batch: int, size, seed: int = 0, kind: str = 'rects') -> torch.T
         img += (rng.random((3, h, w), dtype=np.float32) - np.float32(0.5)) * np.float32(0.2)
         out[b] = np.clip(img, 0.0, 1.0)
     return torch.from_numpy(out)
+
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)       # utils/image_ops.py:177-180 ('RGB_1_norm')
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def make_normalized_images(batch: int, size, seed: int = 0, kind: str = 'rects') -> torch.Tensor:
+    """'RGB_1_norm' inputs (EfficientDet / FCOS configs): make_images normalised by the ImageNet mean/std."""
+    x = make_images(batch, size, seed, kind)
+    mean = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
+    return (x - mean) / std

@@ -94,6 +94,6 @@ def build_reference_model(config_name):
     with no_pretrained(), contextlib.redirect_stdout(io.StringIO()):
         from models.general import OneStageBBox
         model = OneStageBBox(cfg)
-    model.load_state_dict(synth.make_state_dict(model.state_dict()), strict=True)
+    model.load_state_dict(synth.make_state_dict(model.state_dict(), config_name), strict=True)
     model.eval()
     return model, cfg

@@ -85,6 +85,55 @@ def gen_yolov3(batch=1, size=512, name='yolov3_b1_512'):
     print(name, {k: (v.shape if hasattr(v, 'shape') else v) for k, v in out.items() if k.startswith('pp_ap')})
 
 
+MEAN = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)       # utils/image_ops.py:177-178
+STD = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+
+
+def gen_efficientdet(config, size=256, batch=1):
+    """efficientdet-d1 / d1_fcs2_atss: stage samples, all candidates, post-processed detections."""
+    model, cfg = _refimport.build_reference_model(config)
+    x = (synth.make_images(batch, size, seed=0) - MEAN) / STD
+    stages = {}
+
+    def hook(key):
+        def f(_m, _i, out):
+            stages[key] = out
+        return f
+    model.backbone.register_forward_hook(hook('backbone'))
+    model.fpn.register_forward_hook(hook('fpn'))
+    model.backbone.model._blocks[0].register_forward_hook(hook('block0'))
+    model.backbone.model._blocks[2].register_forward_hook(hook('block2'))
+    model.fpn[0].register_forward_hook(hook('bifpn0'))
+    with torch.no_grad():
+        dts = model(x)
+    out = {'batch': batch, 'size': size, 'image_seed': 0}
+    rng = np.random.Generator(np.random.PCG64(4321))
+    groups = {'backbone': stages['backbone'], 'fpn': stages['fpn'], 'bifpn0': stages['bifpn0'],
+              'block0': [stages['block0']], 'block2': [stages['block2']]}
+    for key, feats in groups.items():
+        for lvl, f in enumerate(feats):
+            f = _np(f)
+            out[f'{key}_{lvl}_shape'] = np.array(f.shape)
+            out[f'{key}_{lvl}_l2'] = np.float64(np.sqrt((f.astype(np.float64) ** 2).sum()))
+            flat = f.reshape(-1)
+            idx = rng.integers(0, flat.size, size=256)
+            out[f'{key}_{lvl}_idx'] = idx
+            out[f'{key}_{lvl}_val'] = flat[idx]
+    for b, d in enumerate(dts):
+        out[f'bboxes_{b}'], out[f'cats_{b}'], out[f'scores_{b}'] = _np(d.bboxes), _np(d.cats), _np(d.scores)
+    for tag, conf, nms in (('ap', 0.005, cfg['test.nms_thres']), ('mid', 0.05, cfg['test.nms_thres']),
+                           ('demo', cfg['test.default_conf_thres'], cfg['test.nms_thres'])):
+        for b in range(batch):
+            with torch.no_grad():
+                d = model(x[b:b + 1])[0].post_process(conf_thres=conf, nms_thres=nms)
+            out[f'pp_{tag}_conf'], out[f'pp_{tag}_nms'] = np.float64(conf), np.float64(nms)
+            out[f'pp_{tag}_bboxes_{b}'], out[f'pp_{tag}_cats_{b}'], out[f'pp_{tag}_scores_{b}'] = \
+                _np(d.bboxes), _np(d.cats), _np(d.scores)
+    name = config.replace('-', '_') + f'_b{batch}_{size}'
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(name, 'N', out['bboxes_0'].shape[0], 'dets', {t: out[f'pp_{t}_cats_0'].shape[0] for t in ('ap', 'mid', 'demo')})
+
+
 def gen_detlayers():
     import json
     _refimport.install()
@@ -228,7 +277,7 @@ def gen_bbox_ops():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['bbox_ops', 'postprocess', 'detlayers', 'yolov3']
+    which = sys.argv[1:] or ['bbox_ops', 'postprocess', 'detlayers', 'yolov3', 'efficientdet']
     if 'bbox_ops' in which:
         gen_bbox_ops()
     if 'postprocess' in which:
@@ -237,3 +286,6 @@ if __name__ == '__main__':
         gen_detlayers()
     if 'yolov3' in which:
         gen_yolov3(1, 512, 'yolov3_b1_512')
+    if 'efficientdet' in which:
+        gen_efficientdet('efficientdet-d1')
+        gen_efficientdet('d1_fcs2_atss')

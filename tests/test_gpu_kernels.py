@@ -234,3 +234,76 @@ def test_nms_standalone_and_to_original(dev, golden):
     d2.bboxes_to_original_(pad_info)
     np.testing.assert_array_equal(d2.bboxes.cpu().numpy(), g['to_original_bboxes'])
     assert d2.img_hw == (pad_info[1], pad_info[0])
+
+
+# ------------------------------------------------------------------ EfficientNet / BiFPN family kernels
+@pytest.mark.parametrize('k,s,pad,C,H,W,act', [(3, 1, (1, 1, 1, 1), 32, 20, 24, 2), (3, 2, (0, 0, 1, 1), 96, 16, 16, 2),
+                                              (5, 1, (2, 2, 2, 2), 144, 12, 10, 2), (5, 2, (1, 1, 2, 2), 240, 10, 10, 2),
+                                              (3, 1, (1, 1, 1, 1), 88, 5, 5, 0)])
+def test_dwconv(dev, k, s, pad, C, H, W, act):
+    from mydetection_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, C, H, W, generator=g)
+    w = torch.randn(C, 1, k, k, generator=g) * 0.3
+    bn = act != 0
+    scale = torch.rand(C, generator=g) + 0.5 if bn else None
+    shift = torch.randn(C, generator=g) * 0.1 if bn else None
+    ref = F.conv2d(F.pad(x, (pad[1], pad[3], pad[0], pad[2])).double(), w.double(), None, s, 0, 1, C)
+    if bn:
+        ref = ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    if act == 2:
+        ref = ref * torch.sigmoid(ref)
+    y = ops.dwconv(x.to(dev), w.permute(2, 3, 0, 1).reshape(k, k, C).contiguous().to(dev),
+                   scale.to(dev) if bn else None, shift.to(dev) if bn else None, k, s, pad, act)
+    assert y.shape == ref.shape
+    assert (y.cpu().double() - ref).abs().max() < 2e-5
+
+
+def test_se_gate_and_gated_conv(dev):
+    from mydetection_amd import ops
+    g = torch.Generator().manual_seed(4)
+    for C, Cse, H, W, Cout in ((96, 4, 40, 40, 24), (1152, 48, 5, 5, 192), (16, 4, 33, 17, 16)):
+        x = torch.randn(3, C, H, W, generator=g)
+        w1, b1 = torch.randn(Cse, C, generator=g) * 0.1, torch.randn(Cse, generator=g) * 0.1
+        w2, b2 = torch.randn(C, Cse, generator=g) * 0.3, torch.randn(C, generator=g) * 0.1
+        m = x.double().mean(dim=(2, 3))
+        h = m @ w1.double().t() + b1.double()
+        h = h * torch.sigmoid(h)
+        gate_ref = torch.sigmoid(h @ w2.double().t() + b2.double())
+        xd = x.to(dev).contiguous(memory_format=torch.channels_last)
+        gate = ops.se_gate(xd, w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev))
+        assert (gate.cpu().double() - gate_ref).abs().max() < 1e-5
+        # project conv with the gate applied while staging A, + residual when shapes allow
+        wp = torch.randn(Cout, C, 1, 1, generator=g) / C ** 0.5
+        scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+        res = torch.randn(3, Cout, H, W, generator=g)
+        ref = F.conv2d(x.double() * gate_ref.view(3, C, 1, 1), wp.double()) * scale.double().view(1, -1, 1, 1) \
+            + shift.double().view(1, -1, 1, 1) + res.double()
+        y = ops.conv2d(xd, wp.permute(0, 2, 3, 1).contiguous().to(dev), scale.to(dev), shift.to(dev), 1, 1, (0, 0, 0, 0), 0,
+                       residual=res.to(dev).contiguous(memory_format=torch.channels_last), gate=gate)
+        assert (y.cpu().double() - ref).abs().max() < 3e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_maxpool_and_bifpn_fuse(dev):
+    from mydetection_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 88, 10, 10, generator=g)
+    y = ops.maxpool3s2(x.to(dev))
+    assert torch.equal(y.cpu(), F.max_pool2d(x, 3, 2, 1))
+    x2 = torch.randn(2, 24, 7, 9, generator=g)                       # odd sizes
+    assert torch.equal(ops.maxpool3s2(x2.to(dev)).cpu(), F.max_pool2d(x2, 3, 2, 1))
+    swish = lambda t: t * torch.sigmoid(t)                           # noqa: E731
+    a, b_half, c_dbl = torch.randn(2, 88, 8, 8, generator=g), torch.randn(2, 88, 4, 4, generator=g), torch.randn(2, 88, 16, 16, generator=g)
+    for wts in (torch.tensor([0.7, 1.2]), torch.tensor([-0.5, 1.0])):
+        w = F.relu(wts)
+        w = w / (w.sum() + 0.0001)
+        ref = swish(sum([wi * f for wi, f in zip(w, [a, F.interpolate(b_half, scale_factor=(2, 2), mode='nearest')])]))
+        out = ops.bifpn_fuse([a.to(dev), b_half.to(dev)], [ops.FUSE_SAME, ops.FUSE_UP2X], wts.to(dev))
+        np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=2e-6, atol=1e-7)
+    wts = torch.tensor([0.9, 0.4, 1.3])
+    w = F.relu(wts)
+    w = w / (w.sum() + 0.0001)
+    a2 = torch.randn(2, 88, 8, 8, generator=g)
+    ref = swish(sum([wi * f for wi, f in zip(w, [a, a2, F.max_pool2d(c_dbl, 3, 2, 1)])]))
+    out = ops.bifpn_fuse([a.to(dev), a2.to(dev), c_dbl.to(dev)], [ops.FUSE_SAME, ops.FUSE_SAME, ops.FUSE_POOL], wts.to(dev))
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=2e-6, atol=1e-7)

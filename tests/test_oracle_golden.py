@@ -127,3 +127,33 @@ def test_yolov3_post_process_matches_reference(yolov3_oracle_run):
         np.testing.assert_array_equal(c, g[f'pp_{tag}_cats_0'])
         np.testing.assert_allclose(s, g[f'pp_{tag}_scores_0'], rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(b, g[f'pp_{tag}_bboxes_0'], rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize('config', ['efficientdet-d1', 'd1_fcs2_atss'])
+def test_efficientdet_family_matches_reference(golden, config):
+    """Oracle restatement of EfficientNet-B1 + BiFPN + EfDetHead + decode vs the imported reference."""
+    from mydetection_amd.models.general import state_dict_template
+    from oracle import efficientdet as oe
+    g = golden(config.replace('-', '_') + '_b1_256')
+    sd = synth.make_state_dict(state_dict_template(config), config)
+    x = synth.make_normalized_images(int(g['batch']), int(g['size']), seed=int(g['image_seed']))
+    torch.set_num_threads(8)
+    atss = config == 'd1_fcs2_atss'
+    with torch.no_grad():
+        c = oe.backbone(x, sd, c6c7='conv' if atss else 'maxpool')
+        p0 = oe.bifpn5(c, sd, 'fpn.0')
+        p = oe.bifpn(c, sd)
+        bb, ci, sc = oe.forward(x, sd, config)
+    for key, feats in (('backbone', c), ('bifpn0', p0), ('fpn', p)):
+        for lvl, f in enumerate(feats):
+            f = f.numpy()
+            assert tuple(g[f'{key}_{lvl}_shape']) == f.shape
+            np.testing.assert_allclose(f.reshape(-1)[g[f'{key}_{lvl}_idx']], g[f'{key}_{lvl}_val'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_array_equal(ci[0].numpy(), g['cats_0'])
+    np.testing.assert_allclose(sc[0].numpy(), g['scores_0'], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(bb[0].numpy(), g['bboxes_0'], rtol=1e-4, atol=1e-3)
+    for tag in ('ap', 'mid', 'demo'):
+        b, cc, s, _ = pp.post_process(bb[0].numpy(), ci[0].numpy(), sc[0].numpy(), float(g[f'pp_{tag}_conf']),
+                                      float(g[f'pp_{tag}_nms']))
+        np.testing.assert_array_equal(cc, g[f'pp_{tag}_cats_0'])
+        np.testing.assert_allclose(s, g[f'pp_{tag}_scores_0'], rtol=1e-4, atol=1e-7)
