@@ -80,21 +80,29 @@ int mydet_conv2d_stem_f32(const float *x, int64_t sxb, int64_t sxc, int64_t sxh,
                           int B, int H, int W, int Cout, int stride, int pad_t, int pad_l,
                           int Ho, int Wo, int act, void *stream);
 
-/* Depthwise K x K convolution (K = 3 or 5), y = act(conv*scale + shift) (scale/shift NULL => plain conv).
- * Replaces `_depthwise_conv` + `_bn1` + swish (external/efficientnet/model.py:77) and
+/* Depthwise K x K convolution (K = 3 or 5, stride 1 or 2), y = act(conv*scale + shift) (scale/shift NULL =>
+ * plain conv).  Replaces `_depthwise_conv` + `_bn1` + swish (external/efficientnet/model.py:77) and
  * SeparableConv2d.depthwise (models/modules.py:12-13,19).  w: [K][K][C] (repack of [C,1,K,K]).
+ * se_partial != NULL: the launch also writes per-image channel sums of y split over S pixel slices,
+ * se_partial[B][S+1][C] (slices 0..S-1; slice S is scratch for mydet_se_gate_f32) -- the squeeze of the following squeeze-excite (adaptive_avg_pool2d,
+ * external/efficientnet/model.py:81) without another pass over y; deterministic (no atomics).
  */
 int mydet_dwconv_f32(const float *x, int64_t ldx, const float *w, const float *scale, const float *shift,
                      float *y, int64_t ldy, int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l,
-                     int Ho, int Wo, int act, void *stream);
+                     int Ho, int Wo, int act, float *se_partial, int S, void *stream);
 
-/* Squeeze-excite gate: gate[b][c] = sigmoid(W2 . swish(W1 . mean_hw(x[b,:,:,c]) + b1) + b2).
- * Replaces adaptive_avg_pool2d + _se_reduce + swish + _se_expand + sigmoid
- * (external/efficientnet/model.py:80-83).  w1 [Cse][C], w2 [C][Cse].  scratch: B*S*C floats,
- * S (1..4096) = number of pixel slices the average is split over (deterministic two-stage sum).
+/* Per-image channel sums of x split over S pixel slices: partial[B][S+1][C], slices 0..S-1 (standalone squeeze). */
+int mydet_channel_sums_f32(const float *x, int64_t ldx, int B, int H, int W, int C, float *partial, int S,
+                           void *stream);
+
+/* Squeeze-excite gate from the partial sums partial[B][S+1][C]: mean = sum_{s<S} partial[b][s][:] / HW (stored
+ * in slice S);
+ * gate[b][c] = sigmoid(W2 . swish(W1 . mean + b1) + b2).  Replaces adaptive_avg_pool2d + _se_reduce + swish +
+ * _se_expand + sigmoid (external/efficientnet/model.py:80-83).  w1 [Cse][C]; w2t [Cse][C] = _se_expand weight
+ * transposed.
  */
-int mydet_se_gate_f32(const float *x, int64_t ldx, int B, int H, int W, int C, const float *w1, const float *b1,
-                      int Cse, const float *w2, const float *b2, float *gate, float *scratch, int S, void *stream);
+int mydet_se_gate_f32(float *partial, int S, int B, int HW, int C, const float *w1, const float *b1, int Cse,
+                      const float *w2t, const float *b2, float *gate, void *stream);
 
 /* 3x3 stride-2 pad-1 max pool (-inf padding): nn.MaxPool2d(3, 2, 1) models/backbones.py:186,188,
  * tnf.max_pool2d models/fpns.py:405-416. */

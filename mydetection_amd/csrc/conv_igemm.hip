@@ -359,6 +359,9 @@ extern "C" int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *
     //   layers with big grids take 128x128 tiles on 8 waves (wave tile 64x32, 4 waves per SIMD).
     const int64_t blocks128 = ((M64 + 127) / 128) * ((Cout + 127) / 128);
     const int K = KH * KW * Cin;
+    // short generic-K pointwise convs (EfficientNet expand/project, BiFPN, heads): BK = 16 wastes no staging on
+    // K = 16/24/40/88... and five 30 KB workgroups fit a CU
+    if ((Cin % 32) != 0 && K <= 256) return launch_cfg(6, a, s);
     if (Cout <= 32) return launch_cfg(2, a, s);
     if (Cout <= 64) return launch_cfg(KH * KW > 1 ? 6 : 1, a, s);
     if (K <= 1024 || blocks128 < 1024) return launch_cfg(3, a, s);

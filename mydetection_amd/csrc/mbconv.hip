@@ -18,57 +18,127 @@ namespace {
 // --------------------------------------------------------------------------------------------- depthwise
 struct DwArgs {
     const float *x, *w, *scale, *shift;
-    float *y;
+    float *y, *partial;       // partial != NULL: also emit per-slice channel sums [B][S][C] (SE squeeze)
     int64_t ldx, ldy, total;
-    int C, H, W, Ho, Wo, stride, pad_t, pad_l, act;
+    int C, H, W, Ho, Wo, pad_t, pad_l, act, S;
 };
 
-template <int K>
+// TW consecutive outputs of one row for one channel quad: each input column and each weight is loaded once
+// for the whole strip ((TW-1)*ST + K columns instead of TW*K).
+template <int K, int ST, int TW>
+__device__ __forceinline__ void dw_strip(const DwArgs &p, const float *xq, const float *wq, int oh, int ow0,
+                                         f32x4 (&acc)[TW]) {
+    constexpr int NC = (TW - 1) * ST + K;
+#pragma unroll
+    for (int t = 0; t < TW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ih0 = oh * ST - p.pad_t, iw0 = ow0 * ST - p.pad_l;
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh) {
+        const int ih = ih0 + kh;
+        if ((unsigned)ih >= (unsigned)p.H) continue;
+        const float *row = xq + (int64_t)ih * p.W * p.ldx;
+        f32x4 col[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int iw = iw0 + c;
+            col[c] = (unsigned)iw < (unsigned)p.W ? *reinterpret_cast<const f32x4 *>(row + (int64_t)iw * p.ldx)
+                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) {
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(wq + (kh * K + kw) * p.C);
+#pragma unroll
+            for (int t = 0; t < TW; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t][j] = fmaf(col[t * ST + kw][j], wv[j], acc[t][j]);
+        }
+    }
+}
+
+__device__ __forceinline__ f32x4 dw_epilogue(const DwArgs &p, f32x4 v, int q) {
+    if (p.scale) {
+        const f32x4 sc = *reinterpret_cast<const f32x4 *>(p.scale + q * 4);
+        const f32x4 sh = *reinterpret_cast<const f32x4 *>(p.shift + q * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] * sc[j] + sh[j];
+    }
+    if (p.act == MYDET_ACT_SWISH) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] * mydet_sigmoid(v[j]);
+    } else if (p.act == MYDET_ACT_LEAKY) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * 0.1f;
+    }
+    return v;
+}
+
+// plain form: flat grid-stride over (strip, quad) items
+template <int K, int ST, int TW>
 __global__ __launch_bounds__(256) void dwconv_kernel(const DwArgs p) {
-    const int Q = p.C >> 2;
+    const int Q = p.C >> 2, WG = p.Wo / TW;
     for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < p.total; it += (int64_t)gridDim.x * 256) {
         const int q = (int)(it % Q);
-        const int64_t pix = it / Q;
-        const int ow = (int)(pix % p.Wo);
-        const int64_t t = pix / p.Wo;
+        const int64_t g = it / Q;
+        const int owg = (int)(g % WG);
+        const int64_t t = g / WG;
         const int oh = (int)(t % p.Ho);
         const int64_t b = t / p.Ho;
-        const int ih0 = oh * p.stride - p.pad_t, iw0 = ow * p.stride - p.pad_l;
-        const float *xb = p.x + (b * p.H * p.W) * p.ldx + q * 4;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[TW];
+        dw_strip<K, ST, TW>(p, p.x + (b * p.H * p.W) * p.ldx + q * 4, p.w + q * 4, oh, owg * TW, acc);
+        float *yp = p.y + ((b * p.Ho + oh) * p.Wo + owg * TW) * p.ldy + q * 4;
 #pragma unroll
-        for (int kh = 0; kh < K; ++kh) {
-            const int ih = ih0 + kh;
-            if ((unsigned)ih >= (unsigned)p.H) continue;
+        for (int tt = 0; tt < TW; ++tt) *reinterpret_cast<f32x4 *>(yp + tt * p.ldy) = dw_epilogue(p, acc[tt], q);
+    }
+}
+
+// squeeze-fused form: workgroup (s, b) owns slice s of image b's strips, all channels; besides y it writes
+// partial[b][s][c] = sum of its outputs (deterministic: fixed thread->strip map, fixed reduction order).
+template <int K, int ST, int TW>
+__global__ __launch_bounds__(256) void dwconv_sum_kernel(const DwArgs p) {
+    __shared__ f32x4 red[256];
+    const int Q = p.C >> 2, WG = p.Wo / TW;
+    const int b = blockIdx.y, s = blockIdx.x;
+    const int NG = p.Ho * WG;
+    const int per = (NG + p.S - 1) / p.S;
+    const int g0 = s * per, g1 = min(NG, g0 + per);
+    const float *xb = p.x + ((int64_t)b * p.H * p.W) * p.ldx;
+    float *yb = p.y + ((int64_t)b * p.Ho * p.Wo) * p.ldy;
+    for (int qb = 0; qb < Q; qb += 256) {
+        const int nq = min(Q - qb, 256);
+        const int ph_n = 256 / nq;                       // >= 1
+        const int q = qb + threadIdx.x % nq, ph = threadIdx.x / nq;
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        if (ph < ph_n)
+            for (int g = g0 + ph; g < g1; g += ph_n) {
+                const int oh = g / WG, owg = g - oh * WG;
+                f32x4 acc[TW];
+                dw_strip<K, ST, TW>(p, xb + q * 4, p.w + q * 4, oh, owg * TW, acc);
+                float *yp = yb + ((int64_t)oh * p.Wo + owg * TW) * p.ldy + q * 4;
 #pragma unroll
-            for (int kw = 0; kw < K; ++kw) {
-                const int iw = iw0 + kw;
-                if ((unsigned)iw >= (unsigned)p.W) continue;
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(xb + ((int64_t)ih * p.W + iw) * p.ldx);
-                const f32x4 wv = *reinterpret_cast<const f32x4 *>(p.w + (kh * K + kw) * p.C + q * 4);
+                for (int tt = 0; tt < TW; ++tt) {
+                    const f32x4 v = dw_epilogue(p, acc[tt], q);
+                    *reinterpret_cast<f32x4 *>(yp + tt * p.ldy) = v;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = fmaf(v[j], wv[j], acc[j]);
+                    for (int j = 0; j < 4; ++j) sum[j] += v[j];
+                }
             }
-        }
-        if (p.scale) {
-            const f32x4 sc = *reinterpret_cast<const f32x4 *>(p.scale + q * 4);
-            const f32x4 sh = *reinterpret_cast<const f32x4 *>(p.shift + q * 4);
+        red[threadIdx.x] = sum;
+        __syncthreads();
+        if (threadIdx.x < nq) {
+            f32x4 tot = red[threadIdx.x];
+            for (int k = 1; k < ph_n; ++k) {
+                const f32x4 o = red[threadIdx.x + k * nq];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = acc[j] * sc[j] + sh[j];
+                for (int j = 0; j < 4; ++j) tot[j] += o[j];
+            }
+            *reinterpret_cast<f32x4 *>(p.partial + ((int64_t)b * (p.S + 1) + s) * p.C + (qb + threadIdx.x) * 4) = tot;
         }
-        if (p.act == MYDET_ACT_SWISH) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = acc[j] * mydet_sigmoid(acc[j]);
-        } else if (p.act == MYDET_ACT_LEAKY) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = acc[j] > 0.f ? acc[j] : acc[j] * 0.1f;
-        }
-        *reinterpret_cast<f32x4 *>(p.y + pix * p.ldy + q * 4) = acc;
+        __syncthreads();
     }
 }
 
 // ------------------------------------------------------------------------------------ SE squeeze + gate
-// stage 1: partial[b][s][c] = sum over pixels of slice s of image b
+// standalone stage 1: partial[b][s][c] = sum over pixels of slice s of image b
 __global__ __launch_bounds__(256) void squeeze_partial_kernel(const float *x, int64_t ldx, int C, int HW, int S,
                                                               float *partial) {
     __shared__ f32x4 red[256];
@@ -79,7 +149,7 @@ __global__ __launch_bounds__(256) void squeeze_partial_kernel(const float *x, in
     const float *xb = x + (int64_t)b * HW * ldx;
     for (int qb = 0; qb < Q; qb += 256) {               // channel-quad groups of 256 when Q > 256
         const int nq = min(Q - qb, 256);
-        const int ph_n = nq < 256 ? 256 / nq : 1;
+        const int ph_n = 256 / nq;
         const int q = threadIdx.x % nq, ph = threadIdx.x / nq;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (ph < ph_n)
@@ -97,44 +167,86 @@ __global__ __launch_bounds__(256) void squeeze_partial_kernel(const float *x, in
 #pragma unroll
                 for (int j = 0; j < 4; ++j) tot[j] += o[j];
             }
-            *reinterpret_cast<f32x4 *>(partial + ((int64_t)b * S + s) * C + (qb + threadIdx.x) * 4) = tot;
+            *reinterpret_cast<f32x4 *>(partial + ((int64_t)b * (S + 1) + s) * C + (qb + threadIdx.x) * 4) = tot;
         }
         __syncthreads();
     }
 }
 
-// stage 2: one workgroup per image
-__global__ __launch_bounds__(256) void se_gate_kernel(const float *partial, int S, int C, int HW, const float *w1,
-                                                      const float *b1, int Cse, const float *w2, const float *b2,
+// stage 2a: mean[b][c] = sum_s partial[b][s][c] / HW, written into slice S of the partial buffer.
+// workgroup (64-channel group, b): 64 lanes over channels x 4 phases over slices, fixed reduction order.
+__global__ __launch_bounds__(256) void se_mean_kernel(float *partial, int S, int C, int HW) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const float *pb = partial + (int64_t)b * (S + 1) * C;
+    float a0 = 0.f, a1 = 0.f;
+    if (c < C) {
+        int k = ph;
+        for (; k + 4 < S; k += 8) {
+            a0 += pb[(int64_t)k * C + c];
+            a1 += pb[(int64_t)(k + 4) * C + c];
+        }
+        if (k < S) a0 += pb[(int64_t)k * C + c];
+    }
+    red[ph][lane] = a0 + a1;
+    __syncthreads();
+    if (ph == 0 && c < C)
+        partial[((int64_t)b * (S + 1) + S) * C + c] = (((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane]) *
+                                                      (1.0f / (float)HW);
+}
+
+// stage 2b: workgroup (64-channel group, b) recomputes the hidden layer of image b (cheap, L2-resident weights)
+// and emits its 64 gate channels with the expand dot product split over 4 k-phases; w2t is the expand weight
+// transposed to [Cse][C] so lanes read it coalesced.  Loops are unrolled so several loads are in flight.
+__global__ __launch_bounds__(256) void se_gate_kernel(const float *partial, int S, int C, const float *w1,
+                                                      const float *b1, int Cse, const float *w2t, const float *b2,
                                                       float *gate) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ float red[4][64];
     float *mean = sm;                 // [C]
     float *hid = sm + C;              // [Cse]
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const float inv = 1.0f / (float)HW;
-    for (int c = tid; c < C; c += 256) {
-        float s = 0.f;
-        for (int k = 0; k < S; ++k) s += partial[((int64_t)b * S + k) * C + c];
-        mean[c] = s * inv;
-    }
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const float *mb = partial + ((int64_t)b * (S + 1) + S) * C;
+    for (int c = tid; c < C; c += 256) mean[c] = mb[c];
     __syncthreads();
     const int wave = tid >> 6, lane = tid & 63;
     for (int o = wave; o < Cse; o += 4) {             // reduce conv: wave per output channel
-        float s = 0.f;
-        for (int c = lane; c < C; c += 64) s = fmaf(w1[(int64_t)o * C + c], mean[c], s);
+        const float *wr = w1 + (int64_t)o * C;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int c = lane;
+        for (; c + 192 < C; c += 256) {
+            a0 = fmaf(wr[c], mean[c], a0);
+            a1 = fmaf(wr[c + 64], mean[c + 64], a1);
+            a2 = fmaf(wr[c + 128], mean[c + 128], a2);
+            a3 = fmaf(wr[c + 192], mean[c + 192], a3);
+        }
+        for (; c < C; c += 64) a0 = fmaf(wr[c], mean[c], a0);
+        float acc = (a0 + a1) + (a2 + a3);
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
         if (lane == 0) {
-            s += b1[o];
-            hid[o] = s * mydet_sigmoid(s);
+            acc += b1[o];
+            hid[o] = acc * mydet_sigmoid(acc);
         }
     }
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {              // expand conv + sigmoid
-        float s = 0.f;
-        for (int k = 0; k < Cse; ++k) s = fmaf(w2[(int64_t)c * Cse + k], hid[k], s);
-        gate[(int64_t)b * C + c] = mydet_sigmoid(s + b2[c]);
+    const int c = blockIdx.x * 64 + lane;             // expand conv + sigmoid: 64 channels x 4 k-phases
+    float acc = 0.f;
+    if (c < C) {
+        float e0 = 0.f, e1 = 0.f;
+        int k = wave;
+        for (; k + 4 < Cse; k += 8) {
+            e0 = fmaf(w2t[(int64_t)k * C + c], hid[k], e0);
+            e1 = fmaf(w2t[(int64_t)(k + 4) * C + c], hid[k + 4], e1);
+        }
+        if (k < Cse) e0 = fmaf(w2t[(int64_t)k * C + c], hid[k], e0);
+        acc = e0 + e1;
     }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && c < C)
+        gate[(int64_t)b * C + c] = mydet_sigmoid((((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane]) + b2[c]);
 }
 
 // ----------------------------------------------------------------------------------------------- max pool
@@ -247,36 +359,59 @@ inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
 
-extern "C" int mydet_dwconv_f32(const float *x, int64_t ldx, const float *w, const float *scale, const float *shift,
-                                float *y, int64_t ldy, int B, int H, int W, int C, int K, int stride, int pad_t,
-                                int pad_l, int Ho, int Wo, int act, void *stream) {
-    if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || stride <= 0) return MYDET_E_BADARG;
-    if ((C & 3) || (ldx & 3) || (ldy & 3) || ldx < C || ldy < C || !al16(x) || !al16(w) || !al16(y)) return MYDET_E_BADARG;
-    if ((scale == nullptr) != (shift == nullptr) || (scale && (!al16(scale) || !al16(shift)))) return MYDET_E_BADARG;
-    if (K != 3 && K != 5) return MYDET_E_UNSUPP;
-    DwArgs p;
-    p.x = x; p.w = w; p.scale = scale; p.shift = shift; p.y = y; p.ldx = ldx; p.ldy = ldy;
-    p.C = C; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l; p.act = act;
-    p.total = (int64_t)B * Ho * Wo * (C >> 2);
-    if (K == 3) hipLaunchKernelGGL(dwconv_kernel<3>, dim3(grid_for(p.total)), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(dwconv_kernel<5>, dim3(grid_for(p.total)), dim3(256), 0, (hipStream_t)stream, p);
+template <int K, int ST>
+int launch_dw(const DwArgs &p0, int B, hipStream_t stream) {
+    DwArgs p = p0;
+    const bool strip4 = (p.Wo % 4) == 0;
+    const int TW = strip4 ? 4 : 1;
+    if (p.partial) {
+        const dim3 grid(p.S, B);
+        if (strip4) hipLaunchKernelGGL((dwconv_sum_kernel<K, ST, 4>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((dwconv_sum_kernel<K, ST, 1>), grid, dim3(256), 0, stream, p);
+    } else {
+        p.total = (int64_t)B * p.Ho * (p.Wo / TW) * (p.C >> 2);
+        if (strip4) hipLaunchKernelGGL((dwconv_kernel<K, ST, 4>), dim3(grid_for(p.total)), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((dwconv_kernel<K, ST, 1>), dim3(grid_for(p.total)), dim3(256), 0, stream, p);
+    }
     return mydet_launch_status();
 }
 
-extern "C" int mydet_se_gate_f32(const float *x, int64_t ldx, int B, int H, int W, int C, const float *w1,
-                                 const float *b1, int Cse, const float *w2, const float *b2, float *gate,
-                                 float *scratch, int S, void *stream) {
-    if (!x || !w1 || !b1 || !w2 || !b2 || !gate || !scratch || B <= 0 || H <= 0 || W <= 0 || C <= 0 || Cse <= 0)
+extern "C" int mydet_dwconv_f32(const float *x, int64_t ldx, const float *w, const float *scale, const float *shift,
+                                float *y, int64_t ldy, int B, int H, int W, int C, int K, int stride, int pad_t,
+                                int pad_l, int Ho, int Wo, int act, float *se_partial, int S, void *stream) {
+    if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0) return MYDET_E_BADARG;
+    if ((C & 3) || (ldx & 3) || (ldy & 3) || ldx < C || ldy < C || !al16(x) || !al16(w) || !al16(y)) return MYDET_E_BADARG;
+    if ((scale == nullptr) != (shift == nullptr) || (scale && (!al16(scale) || !al16(shift)))) return MYDET_E_BADARG;
+    if (se_partial && (S <= 0 || S > 4096 || B > 65535 || !al16(se_partial))) return MYDET_E_BADARG;
+    if ((K != 3 && K != 5) || (stride != 1 && stride != 2)) return MYDET_E_UNSUPP;
+    DwArgs p;
+    p.x = x; p.w = w; p.scale = scale; p.shift = shift; p.y = y; p.partial = se_partial; p.ldx = ldx; p.ldy = ldy;
+    p.C = C; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.pad_t = pad_t; p.pad_l = pad_l; p.act = act; p.S = S; p.total = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (K == 3) return stride == 1 ? launch_dw<3, 1>(p, B, st) : launch_dw<3, 2>(p, B, st);
+    return stride == 1 ? launch_dw<5, 1>(p, B, st) : launch_dw<5, 2>(p, B, st);
+}
+
+extern "C" int mydet_channel_sums_f32(const float *x, int64_t ldx, int B, int H, int W, int C, float *partial, int S,
+                                      void *stream) {
+    if (!x || !partial || B <= 0 || H <= 0 || W <= 0 || C <= 0 || S <= 0 || S > 4096 || B > 65535) return MYDET_E_BADARG;
+    if ((C & 3) || (ldx & 3) || ldx < C || !al16(x) || !al16(partial)) return MYDET_E_BADARG;
+    hipLaunchKernelGGL(squeeze_partial_kernel, dim3(S, B), dim3(256), 0, (hipStream_t)stream, x, ldx, C, H * W, S,
+                       partial);
+    return mydet_launch_status();
+}
+
+extern "C" int mydet_se_gate_f32(float *partial, int S, int B, int HW, int C, const float *w1, const float *b1,
+                                 int Cse, const float *w2t, const float *b2, float *gate, void *stream) {
+    if (!partial || !w1 || !b1 || !w2t || !b2 || !gate || B <= 0 || B > 65535 || HW <= 0 || C <= 0 || Cse <= 0 || S <= 0)
         return MYDET_E_BADARG;
-    if ((C & 3) || (ldx & 3) || ldx < C || !al16(x) || !al16(scratch) || S <= 0 || S > 4096) return MYDET_E_BADARG;
     const size_t lds = (size_t)(C + Cse) * sizeof(float);
     if (lds > 64 * 1024) return MYDET_E_UNSUPP;
-    hipLaunchKernelGGL(squeeze_partial_kernel, dim3(S, B), dim3(256), 0, (hipStream_t)stream, x, ldx, C, H * W, S,
-                       scratch);
-    int rc = mydet_launch_status();
+    hipLaunchKernelGGL(se_mean_kernel, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, partial, S, C, HW);
+    const int rc = mydet_launch_status();
     if (rc) return rc;
-    hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, scratch, S, C, H * W, w1, b1, Cse,
-                       w2, b2, gate);
+    hipLaunchKernelGGL(se_gate_kernel, dim3((C + 63) / 64, B), dim3(256), lds, (hipStream_t)stream, partial, S, C, w1,
+                       b1, Cse, w2t, b2, gate);
     return mydet_launch_status();
 }
 

@@ -144,37 +144,57 @@ def conv2d_stem(x, w_ohwi, scale, shift, stride, pad, act):
     return out
 
 
-def dwconv(x, w_kkc, scale, shift, k, stride, pad, act):
-    """Depthwise k x k conv, y = act(conv*scale + shift); w_kkc [k,k,C]; pad=(top,left,bottom,right)."""
+def se_slices(n_pixels):
+    """Number of pixel slices the SE average is split over (deterministic two-stage sum)."""
+    return max(1, min(128, n_pixels // 16))
+
+
+def dwconv(x, w_kkc, scale, shift, k, stride, pad, act, squeeze=False):
+    """Depthwise k x k conv, y = act(conv*scale + shift); w_kkc [k,k,C]; pad=(top,left,bottom,right).
+    squeeze=True also returns the per-slice channel sums [B,S,C] of y (input of `se_gate`)."""
     require_gpu(x, 'dwconv')
     x, ldx = to_nhwc(x)
     B, C, H, W = x.shape
     Ho = conv_out_size(H, k, stride, pad[0], pad[2])
     Wo = conv_out_size(W, k, stride, pad[1], pad[3])
     out, ldy = empty_nhwc(B, C, Ho, Wo, x.device)
+    partial, S = None, 0
+    if squeeze:
+        S = se_slices(Ho * Wo)
+        partial = torch.empty((B, S + 1, C), dtype=torch.float32, device=x.device)    # slice S: scratch for the mean
     t0 = TIMER.start() if TIMER else None
     code = _lib.lib().mydet_dwconv_f32(_ptr(x), ldx, _ptr(w_kkc), _ptr(scale), _ptr(shift), _ptr(out), ldy, B, H, W, C,
-                                       k, stride, pad[0], pad[1], Ho, Wo, act, _stream())
+                                       k, stride, pad[0], pad[1], Ho, Wo, act, _ptr(partial), S, _stream())
     if t0:
-        TIMER.stop('dwconv', t0, 4.0 * B * C * (H * W + Ho * Wo))
+        TIMER.stop(f'dwconv {C} k{k}s{stride} {H}x{W}' if TIMER_DETAIL else 'dwconv', t0, 4.0 * B * C * (H * W + Ho * Wo))
     _lib.check(code, 'mydet_dwconv_f32')
-    return out
+    return (out, partial) if squeeze else out
 
 
-def se_gate(x, w1, b1, w2, b2):
-    """Squeeze-excite gate [B,C] of x [B,C,H,W]: sigmoid(W2 . swish(W1 . mean_hw(x) + b1) + b2)."""
-    require_gpu(x, 'se_gate')
+def channel_sums(x):
+    """Per-slice channel sums [B,S,C] of x [B,C,H,W] (standalone squeeze)."""
+    require_gpu(x, 'channel_sums')
     x, ldx = to_nhwc(x)
     B, C, H, W = x.shape
+    S = se_slices(H * W)
+    partial = torch.empty((B, S + 1, C), dtype=torch.float32, device=x.device)
+    code = _lib.lib().mydet_channel_sums_f32(_ptr(x), ldx, B, H, W, C, _ptr(partial), S, _stream())
+    _lib.check(code, 'mydet_channel_sums_f32')
+    return partial
+
+
+def se_gate(partial, n_pixels, w1, b1, w2t, b2):
+    """gate [B,C] = sigmoid(W2 . swish(W1 . mean + b1) + b2) from per-slice sums [B,S+1,C]; w2t = W2 transposed [Cse,C]."""
+    require_gpu(partial, 'se_gate')
+    B, S, C = partial.shape
+    S -= 1
     Cse = w1.shape[0]
-    S = max(1, min(256, (H * W) // 256))
-    gate = torch.empty((B, C), dtype=torch.float32, device=x.device)
-    scratch = torch.empty((B, S, C), dtype=torch.float32, device=x.device)
+    gate = torch.empty((B, C), dtype=torch.float32, device=partial.device)
     t0 = TIMER.start() if TIMER else None
-    code = _lib.lib().mydet_se_gate_f32(_ptr(x), ldx, B, H, W, C, _ptr(w1), _ptr(b1), Cse, _ptr(w2), _ptr(b2),
-                                        _ptr(gate), _ptr(scratch), S, _stream())
+    code = _lib.lib().mydet_se_gate_f32(_ptr(partial), S, B, n_pixels, C, _ptr(w1), _ptr(b1), Cse, _ptr(w2t), _ptr(b2),
+                                        _ptr(gate), _stream())
     if t0:
-        TIMER.stop('se_gate', t0, 4.0 * B * C * H * W)
+        TIMER.stop('se_gate', t0, 4.0 * B * S * C)
     _lib.check(code, 'mydet_se_gate_f32')
     return gate
 

@@ -257,6 +257,11 @@ def test_dwconv(dev, k, s, pad, C, H, W, act):
                    scale.to(dev) if bn else None, shift.to(dev) if bn else None, k, s, pad, act)
     assert y.shape == ref.shape
     assert (y.cpu().double() - ref).abs().max() < 2e-5
+    # squeeze-fused form: same y bit for bit, plus per-slice channel sums
+    y2, partial = ops.dwconv(x.to(dev), w.permute(2, 3, 0, 1).reshape(k, k, C).contiguous().to(dev),
+                             scale.to(dev) if bn else None, shift.to(dev) if bn else None, k, s, pad, act, squeeze=True)
+    assert torch.equal(y2.contiguous(), y.contiguous())
+    np.testing.assert_allclose(partial[:, :-1].sum(dim=1).cpu().double().numpy(), ref.sum(dim=(2, 3)).numpy(), rtol=1e-5, atol=1e-4)
 
 
 def test_se_gate_and_gated_conv(dev):
@@ -271,7 +276,7 @@ def test_se_gate_and_gated_conv(dev):
         h = h * torch.sigmoid(h)
         gate_ref = torch.sigmoid(h @ w2.double().t() + b2.double())
         xd = x.to(dev).contiguous(memory_format=torch.channels_last)
-        gate = ops.se_gate(xd, w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev))
+        gate = ops.se_gate(ops.channel_sums(xd), H * W, w1.to(dev), b1.to(dev), w2.t().contiguous().to(dev), b2.to(dev))
         assert (gate.cpu().double() - gate_ref).abs().max() < 1e-5
         # project conv with the gate applied while staging A, + residual when shapes allow
         wp = torch.randn(Cout, C, 1, 1, generator=g) / C ** 0.5
