@@ -137,7 +137,7 @@ int mydet_upsample_concat_f32(const float *a, int64_t lda, int Ha, int Wa, int C
  *       its objectness/centerness logit (YOLO, FCOS) at a*cls_astride + conf_c0.
  *       (YOLO head: box == cls, astride 5+C, box_c0 0, conf_c0 4, cls_c0 5.)
  * anchors_wh: HOST pointer (the one exception to "device pointers only") to A pairs (w,h)
- *       in pixels; the <= 16 pairs travel as kernel arguments so the launch stays
+ *       in pixels (A <= 16); the pairs travel as kernel arguments so the launch stays
  *       graph-capturable (YOLO, RETINA; ignored for FCOS, where A == 1).
  * Candidate order inside a level is (a, y, x), x fastest.  N = candidates per image.
  * Outputs: bbox [B,N,4] f32, class_idx [B,N] i64, score [B,N] f32.

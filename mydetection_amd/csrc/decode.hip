@@ -1,22 +1,27 @@
 // Box decode of one pyramid level: raw head logits -> (cxcywh box, class index, score).
 //
-// HBM-bound (reads every head logit once: 8.57 MB/image for YOLOv3-80 @640^2, writes
-// 28 B per candidate).  A wave owns one pixel at a time: its logits (all anchors) are
-// pulled with 16-byte lane loads into a wave-private LDS strip, then for each anchor
-// the 64 lanes take the class logits (<= 2 per lane for 80 classes), apply the
-// logistic, and a 6-step butterfly picks max / first-argmax exactly as torch.max does
-// on the sigmoid values; lane a then finishes anchor a's box arithmetic (all anchors of the
-// pixel in one pass) in the reference's operation order (compiled with -ffp-contract=off so no product is fused into a sum).
+// HBM-bound: every head logit is read once (8.57 MB/image for YOLOv3-80 @640^2) and 28 B are written per
+// candidate.  A workgroup stages a tile of PIX consecutive pixels (all anchors, all channels) from HBM into LDS
+// with coalesced 16-byte loads -- the pixel-major head rows are contiguous in memory -- into rows padded to an
+// odd number of floats, so that in the compute phase, where a THREAD owns one candidate (pixel, anchor) and walks
+// its 80 class logits, the 64 lanes of a wave (64 different pixels, same channel) hit 64 different banks.
+// The class max / first argmax is a sequential strict-greater scan, i.e. torch.max's order: on the logits while
+// the float32 logistic keeps them apart, on the sigmoid values themselves once the max logit is >= 5 (near
+// saturation distinct logits collapse onto one float32 sigmoid and the reference's "first index among equal
+// sigmoids" is decided by those collisions).  Box arithmetic follows the reference's operation order; the file is
+// built with -ffp-contract=off so no product is fused into a sum.  Outputs of a wave are 64 consecutive
+// candidates: coalesced 16-byte box stores.
 //
 //   YOLO   models/detlayers/yolov3.py:41-69    cx=(s(tx)+x)*stride, w=exp(tw)*aw, score=s(conf)*max s(cls)
 //   RETINA models/detlayers/retinanet.py:63-82 cx=acx+tx*aw, w=exp(tw)*aw, clamp [1,max(H,W)], score=max s(cls)
 //   FCOS   models/detlayers/fcos2.py:222-251   ltrb=exp(t)*stride, clamp to image, score=sqrt(s(conf)*max s(cls))
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
 
 constexpr int MAX_A = 16;
-constexpr int WAVES = 4;
 
 struct DecodeArgs {
     int mode;
@@ -26,6 +31,7 @@ struct DecodeArgs {
     int A, C, H, W, img_h, img_w;
     int box_span, cls_span;      // floats of a pixel actually needed (multiple of 4)
     int same;                    // box and cls are the same tensor
+    int PIX, row;                // pixels per tile, LDS row length (odd)
     float stride;
     float aw[MAX_A], ah[MAX_A];
     float *bbox;
@@ -34,60 +40,63 @@ struct DecodeArgs {
     int64_t N, n_off, npix;
 };
 
-__global__ __launch_bounds__(64 * WAVES) void decode_kernel(const DecodeArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ float s_aw[MAX_A], s_ah[MAX_A];          // anchors, indexed per lane below
+__device__ __forceinline__ void stage_rows(float *sm, int row, int col0, const float *src, int64_t ld, int span,
+                                           int npx) {
+    const int q = span >> 2;
+    for (int i = threadIdx.x; i < npx * q; i += 256) {
+        const int r = i / q, c4 = i - r * q;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + (int64_t)r * ld + c4 * 4);
+        float *d = sm + r * row + col0 + c4 * 4;
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+}
+
+__global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ float s_aw[MAX_A], s_ah[MAX_A];
 #pragma unroll
     for (int a = 0; a < MAX_A; ++a)
         if (threadIdx.x == a) { s_aw[a] = p.aw[a]; s_ah[a] = p.ah[a]; }
-    __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int strip = p.cls_span + (p.same ? 0 : p.box_span);
-    float *lc = smem + wave * strip;
-    float *lb = p.same ? lc : lc + p.cls_span;
-    const int64_t nwaves = (int64_t)gridDim.x * WAVES;
     const int hw = p.H * p.W;
     const float fmaxhw = (float)(p.img_h > p.img_w ? p.img_h : p.img_w);
-
-    for (int64_t pix = (int64_t)blockIdx.x * WAVES + wave; pix < p.npix; pix += nwaves) {
-        const float *gc = p.cls + pix * p.ldcls;
-        for (int i = lane * 4; i < p.cls_span; i += 256)
-            *reinterpret_cast<f32x4 *>(lc + i) = *reinterpret_cast<const f32x4 *>(gc + i);
-        if (!p.same) {
-            const float *gb = p.box + pix * p.ldbox;
-            for (int i = lane * 4; i < p.box_span; i += 256)
-                *reinterpret_cast<f32x4 *>(lb + i) = *reinterpret_cast<const f32x4 *>(gb + i);
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int b = (int)(pix / hw);
-        const int rem = (int)(pix - (int64_t)b * hw);
-        const int gy = rem / p.W, gx = rem - gy * p.W;
-
-        // class max / first-argmax per anchor; lane a keeps anchor a's result
-        float mybest = 0.0f;
-        int mybi = 0;
-        for (int a = 0; a < p.A; ++a) {
-            const float *cl = lc + a * p.cls_astride + p.cls_c0;
-            float best = -1.0f;
-            int bi = 0x7fffffff;
-            if (lane < p.C) { best = mydet_sigmoid(cl[lane]); bi = lane; }
-            if (lane + 64 < p.C) {
-                const float s1 = mydet_sigmoid(cl[lane + 64]);
-                if (s1 > best) { best = s1; bi = lane + 64; }
+    const int box_col = p.same ? 0 : p.cls_span;
+    const int64_t ntiles = (p.npix + p.PIX - 1) / p.PIX;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t pix0 = tile * p.PIX;
+        const int npx = (int)(p.npix - pix0 < p.PIX ? p.npix - pix0 : p.PIX);
+        stage_rows(sm, p.row, 0, p.cls + pix0 * p.ldcls, p.ldcls, p.cls_span, npx);
+        if (!p.same) stage_rows(sm, p.row, box_col, p.box + pix0 * p.ldbox, p.ldbox, p.box_span, npx);
+        __syncthreads();
+        for (int c = threadIdx.x; c < p.PIX * p.A; c += 256) {
+            const int a = c / p.PIX, px = c - a * p.PIX;
+            if (px >= npx) continue;
+            const float *rowp = sm + px * p.row;
+            const float *cl = rowp + a * p.cls_astride + p.cls_c0;
+            // class max / first argmax (strict >: the first maximum wins, as torch.max)
+            float best = cl[0];
+            int bi = 0;
+#pragma unroll 8
+            for (int k = 1; k < p.C; ++k) {
+                const float v = cl[k];
+                if (v > best) { best = v; bi = k; }
             }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const float ob = __shfl_xor(best, off);
-                const int oi = __shfl_xor(bi, off);
-                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            float cmax;
+            if (best < 5.0f && best > -80.0f) {
+                cmax = mydet_sigmoid(best);
+            } else {                                   // near saturation: compare the sigmoid values themselves
+                cmax = mydet_sigmoid(cl[0]);
+                bi = 0;
+                for (int k = 1; k < p.C; ++k) {
+                    const float sv = mydet_sigmoid(cl[k]);
+                    if (sv > cmax) { cmax = sv; bi = k; }
+                }
             }
-            if (lane == a) { mybest = best; mybi = bi; }
-        }
-        // box arithmetic: lane a finishes anchor a (all anchors of the pixel in one pass)
-        if (lane < p.A) {
-            const int a = lane;
-            const float *t = lb + a * p.box_astride + p.box_c0;
+            const float *t = rowp + box_col + a * p.box_astride + p.box_c0;
             const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
+            const int64_t pix = pix0 + px;
+            const int b = (int)(pix / hw);
+            const int rem = (int)(pix - (int64_t)b * hw);
+            const int gy = rem / p.W, gx = rem - gy * p.W;
             const float aw = s_aw[a], ah = s_ah[a];
             f32x4 o;
             float sc;
@@ -96,7 +105,7 @@ __global__ __launch_bounds__(64 * WAVES) void decode_kernel(const DecodeArgs p) 
                 o[1] = (mydet_sigmoid(t1) + (float)gy) * p.stride;
                 o[2] = expf(t2) * aw;
                 o[3] = expf(t3) * ah;
-                sc = mydet_sigmoid(lc[a * p.cls_astride + p.conf_c0]) * mybest;
+                sc = mydet_sigmoid(rowp[a * p.cls_astride + p.conf_c0]) * cmax;
             } else if (p.mode == MYDET_DECODE_RETINA) {
                 const float acx = p.stride * 0.5f + (float)gx * p.stride;
                 const float acy = p.stride * 0.5f + (float)gy * p.stride;
@@ -106,7 +115,7 @@ __global__ __launch_bounds__(64 * WAVES) void decode_kernel(const DecodeArgs p) 
                 o[3] = expf(t3) * ah;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = fminf(fmaxf(o[j], 1.0f), fmaxhw);
-                sc = mybest;
+                sc = cmax;
             } else {
                 const float cx = (float)gx * p.stride + p.stride * 0.5f;
                 const float cy = (float)gy * p.stride + p.stride * 0.5f;
@@ -119,14 +128,14 @@ __global__ __launch_bounds__(64 * WAVES) void decode_kernel(const DecodeArgs p) 
                 o[1] = (y1 + y2) / 2.0f;
                 o[2] = x2 - x1;
                 o[3] = y2 - y1;
-                sc = sqrtf(mydet_sigmoid(lc[a * p.cls_astride + p.conf_c0]) * mybest);
+                sc = sqrtf(mydet_sigmoid(rowp[a * p.cls_astride + p.conf_c0]) * cmax);
             }
             const int64_t n = (int64_t)b * p.N + p.n_off + ((int64_t)a * p.H + gy) * p.W + gx;
             *reinterpret_cast<f32x4 *>(p.bbox + n * 4) = o;
-            p.cidx[n] = (int64_t)mybi;
+            p.cidx[n] = (int64_t)bi;
             p.score[n] = sc;
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
     }
 }
 
@@ -164,10 +173,20 @@ extern "C" int mydet_decode_f32(int mode, const float *box, int64_t ldbox, int b
     p.cls_span = (cls_need + 3) & ~3;
     p.box_span = (box_need + 3) & ~3;
     if (p.cls_span > ldcls || p.box_span > ldbox) return MYDET_E_BADARG;
-    const size_t lds = (size_t)WAVES * (p.cls_span + (p.same ? 0 : p.box_span)) * sizeof(float);
-    if (lds > 64 * 1024) return MYDET_E_UNSUPP;
-    int64_t blocks = (p.npix + WAVES - 1) / WAVES;
+    p.row = (p.cls_span + (p.same ? 0 : p.box_span)) | 1;               // odd row length: conflict-free column walks
+    p.PIX = 32;                                                        // 32-pixel tiles: 33 KB (YOLO), 4 workgroups per CU overlap load and compute
+    if (const char *e = getenv("MYDET_DECODE_PIX")) p.PIX = atoi(e);      // tuning knob
+    while (p.PIX > 4 && (size_t)p.PIX * p.row * sizeof(float) > 80 * 1024) p.PIX >>= 1;
+    const size_t lds = (size_t)p.PIX * p.row * sizeof(float);
+    if (lds > 80 * 1024) return MYDET_E_UNSUPP;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  80 * 1024);
+        attr_set = true;
+    }
+    int64_t blocks = (p.npix + p.PIX - 1) / p.PIX;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)blocks), dim3(64 * WAVES), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
     return mydet_launch_status();
 }

@@ -178,7 +178,7 @@ def test_effdet_family_vs_oracle_640(effdet):
     """640x640 (benchmark resolution), batch 2.  These nets are ~110 layers deep with |logit| up to ~90 on the
     synthetic weights, so float32 round-off alone moves a few scores by > 1e-4: the float32 CPU oracle (= the
     reference's arithmetic) itself sits that far from an exact (float64) evaluation.  The gate is therefore:
-    the HIP path must be as close to the float64 oracle as the float32 CPU path is (x1.5 slack), and within
+    the HIP path must be as close to the float64 oracle as the float32 CPU path is (rms within 1.5x, max within 3x), and within
     1e-4 of the float32 oracle on all but a handful of elements."""
     from mydetection_amd import synth
     from oracle import efficientdet as oe
@@ -194,8 +194,12 @@ def test_effdet_family_vs_oracle_640(effdet):
     sc, bb = sc.cpu().double(), bb.cpu().double()
     err_gpu_s, err_cpu_s = (sc - os64).abs().max().item(), (os_.double() - os64).abs().max().item()
     err_gpu_b, err_cpu_b = (bb - ob64).abs().max().item(), (ob.double() - ob64).abs().max().item()
-    assert err_gpu_s <= max(ATOL, 1.5 * err_cpu_s), (err_gpu_s, err_cpu_s)
-    assert err_gpu_b <= max(2e-3, 1.5 * err_cpu_b), (err_gpu_b, err_cpu_b)
+    # max errors are extreme-value statistics of round-off noise: 3x slack on the max, 1.5x on the rms
+    assert err_gpu_s <= max(ATOL, 3.0 * err_cpu_s), (err_gpu_s, err_cpu_s)
+    assert err_gpu_b <= max(2e-3, 3.0 * err_cpu_b), (err_gpu_b, err_cpu_b)
+    rms = lambda t: t.pow(2).mean().sqrt().item()                # noqa: E731
+    assert rms(sc - os64) <= 1.5 * rms(os_.double() - os64) + 1e-7
+    assert rms(bb - ob64) <= 1.5 * rms(ob.double() - ob64) + 1e-6
     bad = ((sc - os_.double()).abs() > ATOL + RTOL * os_.double().abs()).sum().item()
     assert bad <= 8, f'{bad} scores differ from the float32 oracle by more than 1e-4'
     assert (ci.cpu() != oc).sum().item() <= bb.shape[1] // 2000 + 2
