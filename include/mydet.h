@@ -56,6 +56,9 @@ int mydet_abi_version(void);
  *   (1x1 stride-1 convs without activation only): the squeeze-excite scale
  *   `torch.sigmoid(x_squeezed) * x` feeding `_project_conv`, external/efficientnet/model.py:83-85,
  *   without a pass over the expanded tensor.
+ * workspace: NULL, or scratch (16-byte aligned) for the split-K tail: when the grid is a few full rounds of the
+ *   chip plus a small remainder, the remainder tiles are cut along K, partial tiles go here and a fixup launch
+ *   sums them in a fixed order (deterministic); 64 MiB covers every layer of the three models.
  * Also covers: MBConv expand/project convs (external/efficientnet/model.py:75,85), BiFPN
  * input projections (models/fpns.py:446-448), SeparableConv2d.pointwise (models/modules.py:20),
  * C6/C7 convs (models/backbones.py:183-200), dense cls_last conv (models/rpns.py:155-158).
@@ -63,6 +66,7 @@ int mydet_abi_version(void);
 int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *w,
                            const float *scale, const float *shift,
                            const float *residual, int64_t ldr, const float *a_gate,
+                           void *workspace, int64_t workspace_bytes,
                            float *y, int64_t ldy,
                            int B, int H, int W, int Cin, int Cout,
                            int KH, int KW, int stride, int pad_t, int pad_l,

@@ -14,7 +14,8 @@ c_int, c_i64, c_f32, c_f64, c_ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float
 # name -> argtypes, exactly the prototypes of include/mydet.h
 SIGNATURES = {
     'mydet_abi_version': [],
-    'mydet_conv2d_igemm_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64] + [c_int] * 13 + [c_ptr],
+    'mydet_conv2d_igemm_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_i64]
+    + [c_int] * 13 + [c_ptr],
     'mydet_dwconv_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64] + [c_int] * 11 + [c_ptr, c_int, c_ptr],
     'mydet_channel_sums_f32': [c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr, c_int, c_ptr],
     'mydet_se_gate_f32': [c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr],

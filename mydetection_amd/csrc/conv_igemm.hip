@@ -37,6 +37,9 @@ struct ConvArgs {
     int64_t ldx, ldr, ldy;
     int B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, act;
     int M, K, ntiles, nblk;
+    int tile0, splits;        // split-K tail: first logical tile of this launch, K slices per tile (1 = whole K)
+    float *ws;                // split-K partial accumulators
+    size_t ws_bytes;
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -100,7 +103,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs &p, f32x16 (&acc)[TM][TN
     }
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool CIN32, int ACT, bool RES, bool GATE>
+template <int BM, int BN, int WM, int WN, int BK, bool CIN32, int ACT, bool RES, bool GATE, bool SPLIT = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs p) {
     constexpr int NT = WM * WN * 64;                // threads: one wave per (wm, wn)
     constexpr int LDS_LD = BK + 4;                 // padded LDS row (floats)
@@ -114,7 +117,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     float *Bs = smem + 2 * BM * LDS_LD;             // [2][BN][LDS_LD]
 
     const int tid = threadIdx.x;
-    const int lid = mydet_xcd_remap(blockIdx.x, p.nblk);
+    // SPLIT: block = (tail tile, K slice); otherwise one block per tile, XCD-grouped
+    const int lid = SPLIT ? p.tile0 + (int)blockIdx.x / p.splits : mydet_xcd_remap(blockIdx.x, p.nblk);
     const int m0 = (lid / p.ntiles) * BM;
     const int n0 = (lid % p.ntiles) * BN;
 
@@ -158,8 +162,21 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     }
 
     f32x4 areg[AI], breg[BI];
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk_all = (p.K + BK - 1) / BK;
+    int kt0 = 0, nk = nk_all;                        // this block's slab range [kt0, nk)
+    if (SPLIT) {
+        const int sp = (int)blockIdx.x % p.splits;
+        kt0 = (int)((int64_t)nk_all * sp / p.splits);
+        nk = (int)((int64_t)nk_all * (sp + 1) / p.splits);
+    }
     int tap = 0, c0 = 0, tapoff = 0;                 // CIN32 path: uniform tap / channel base / byte offset
+    if (SPLIT && CIN32) {
+        const int k0 = kt0 * BK;
+        tap = k0 / p.Cin;
+        c0 = k0 - tap * p.Cin;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        tapoff = (int)(((int64_t)kh * p.W + kw) * p.ldx) * 4;
+    }
 
     auto load_slab = [&](int kt) {
         if (CIN32) {
@@ -220,11 +237,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     const int a_off = (wm * TM * 32 + fr) * LDS_LD + fh * 4;
     const int b_off = (wn * TN * 32 + fr) * LDS_LD + fh * 4;
 
-    load_slab(0);
+    load_slab(kt0);
     store_slab(0);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int buf = (kt - kt0) & 1;
         // Unconditional prefetch: past the last slab the taps are masked off (A) and the
         // weight rows run into the next row or the range check (B) -- harmless, never consumed.
         load_slab(kt + 1);
@@ -249,6 +266,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
         __syncthreads();
     }
 
+    if (SPLIT) {     // raw partial tile, [vec4][thread] so lanes store contiguously; summed by conv_fixup_kernel
+        constexpr int NV4 = TM * TN * 4;
+        f32x4 *dst = reinterpret_cast<f32x4 *>(p.ws) + (int64_t)blockIdx.x * NV4 * NT + tid;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    dst[((i * TN + j) * 4 + v) * NT] =
+                        f32x4{acc[i][j][4 * v], acc[i][j][4 * v + 1], acc[i][j][4 * v + 2], acc[i][j][4 * v + 3]};
+        return;
+    }
     const int m_base = m0 + wm * TM * 32, n_base = n0 + wn * TN * 32;
     if ((m0 + BM <= p.M) && (n0 + BN <= p.Cout))
         epilogue<ACT, RES, true, TM, TN>(p, acc, m_base, n_base, fr, fh);
@@ -256,9 +286,43 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
         epilogue<ACT, RES, false, TM, TN>(p, acc, m_base, n_base, fr, fh);
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool CIN32, int ACT, bool RES, bool GATE = false>
+// Split-K tail: sums the K-slice partials of one tile in slice order and applies the fused epilogue.
+template <int BM, int BN, int WM, int WN, int ACT, bool RES>
+__global__ __launch_bounds__(WM * WN * 64) void conv_fixup_kernel(const ConvArgs p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int NV4 = TM * TN * 4;
+    const int tid = threadIdx.x;
+    const int lid = p.tile0 + (int)blockIdx.x;
+    const int m0 = (lid / p.ntiles) * BM, n0 = (lid % p.ntiles) * BN;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 31, fh = lane >> 5;
+    f32x16 acc[TM][TN];
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(p.ws) + (int64_t)blockIdx.x * p.splits * NV4 * NT + tid;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                f32x4 t = src[((i * TN + j) * 4 + v) * NT];
+                for (int sp = 1; sp < p.splits; ++sp) {
+                    const f32x4 o = src[((int64_t)sp * NV4 + (i * TN + j) * 4 + v) * NT];
+                    t[0] += o[0]; t[1] += o[1]; t[2] += o[2]; t[3] += o[3];
+                }
+                acc[i][j][4 * v] = t[0]; acc[i][j][4 * v + 1] = t[1]; acc[i][j][4 * v + 2] = t[2]; acc[i][j][4 * v + 3] = t[3];
+            }
+    const int m_base = m0 + wm * TM * 32, n_base = n0 + wn * TN * 32;
+    if ((m0 + BM <= p.M) && (n0 + BN <= p.Cout))
+        epilogue<ACT, RES, true, TM, TN>(p, acc, m_base, n_base, fr, fh);
+    else
+        epilogue<ACT, RES, false, TM, TN>(p, acc, m_base, n_base, fr, fh);
+}
+
+template <int BM, int BN, int WM, int WN, int BK, bool CIN32, int ACT, bool RES, bool GATE = false, bool SPLIT = false>
 int launch_inst(const ConvArgs &a, size_t lds, hipStream_t stream) {
-    auto kern = &conv_igemm_kernel<BM, BN, WM, WN, BK, CIN32, ACT, RES, GATE>;
+    auto kern = &conv_igemm_kernel<BM, BN, WM, WN, BK, CIN32, ACT, RES, GATE, SPLIT>;
     static bool attr_set = false;                  // > 64 KiB of dynamic LDS needs the opt-in once
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -288,26 +352,71 @@ int launch_act(const ConvArgs &a, size_t lds, hipStream_t stream) {
     }
 }
 
+template <int BM, int BN, int WM, int WN, int ACT, bool RES>
+int launch_fixup(const ConvArgs &a, int ntail, hipStream_t stream) {
+    hipLaunchKernelGGL((conv_fixup_kernel<BM, BN, WM, WN, ACT, RES>), dim3(ntail), dim3(WM * WN * 64), 0, stream, a);
+    return mydet_launch_status();
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_fixup_act(const ConvArgs &a, int ntail, hipStream_t stream) {
+    const bool res = a.res != nullptr;
+    switch (a.act) {
+        case MYDET_ACT_LEAKY:
+            return res ? launch_fixup<BM, BN, WM, WN, MYDET_ACT_LEAKY, true>(a, ntail, stream)
+                       : launch_fixup<BM, BN, WM, WN, MYDET_ACT_LEAKY, false>(a, ntail, stream);
+        case MYDET_ACT_SWISH:
+            return res ? launch_fixup<BM, BN, WM, WN, MYDET_ACT_SWISH, true>(a, ntail, stream)
+                       : launch_fixup<BM, BN, WM, WN, MYDET_ACT_SWISH, false>(a, ntail, stream);
+        default:
+            return res ? launch_fixup<BM, BN, WM, WN, MYDET_ACT_NONE, true>(a, ntail, stream)
+                       : launch_fixup<BM, BN, WM, WN, MYDET_ACT_NONE, false>(a, ntail, stream);
+    }
+}
+
+// `slots` = workgroups of this configuration the chip holds at once (256 CUs x workgroups per CU).  Workgroups
+// are equal-sized, so a grid of R full rounds plus a small remainder pays a whole extra round for the
+// remainder.  When that happens (and the caller gave workspace) the remainder tiles are instead cut along K into
+// `splits` slices that together fill the chip once, their partial tiles go to the workspace, and a small fixup
+// launch sums them in slice order and applies the epilogue: deterministic, no atomics.
 template <int BM, int BN, int WM, int WN, int BK>
-int launch(const ConvArgs &a0, hipStream_t stream) {
+int launch(const ConvArgs &a0, int slots, hipStream_t stream) {
     ConvArgs a = a0;
     const int mtiles = (a.M + BM - 1) / BM;
     a.ntiles = (a.Cout + BN - 1) / BN;
-    a.nblk = mtiles * a.ntiles;
+    const int total = mtiles * a.ntiles;
     const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
-    if ((a.Cin % BK) == 0) return launch_act<BM, BN, WM, WN, BK, true>(a, lds, stream);
-    return launch_act<BM, BN, WM, WN, BK, false>(a, lds, stream);
+    const bool cin = (a.Cin % BK) == 0;
+    const int nk = (a.K + BK - 1) / BK;
+    const int rounds = total / slots, rem = total % slots;
+    int splits = rem > 0 ? slots / rem : 0;
+    if (splits > 16) splits = 16;
+    if (splits > nk / 4) splits = nk / 4;
+    const size_t need = (size_t)rem * (splits > 0 ? splits : 0) * BM * BN * sizeof(float);
+    // only long-K layers: on short ones the two extra launches cost more than the spared round
+    const bool split = !a.gate && nk >= 32 && rounds >= 2 && rem > 0 && rem * 2 <= slots && splits >= 2 && a0.ws &&
+                       need <= a0.ws_bytes;
+    a.tile0 = 0; a.splits = 1;
+    a.nblk = split ? total - rem : total;
+    int rc = cin ? launch_act<BM, BN, WM, WN, BK, true>(a, lds, stream) : launch_act<BM, BN, WM, WN, BK, false>(a, lds, stream);
+    if (rc || !split) return rc;
+    a.tile0 = total - rem; a.splits = splits; a.nblk = rem * splits;
+    if (cin) rc = launch_inst<BM, BN, WM, WN, BK, true, MYDET_ACT_NONE, false, false, true>(a, lds, stream);
+    else rc = launch_inst<BM, BN, WM, WN, BK, false, MYDET_ACT_NONE, false, false, true>(a, lds, stream);
+    if (rc) return rc;
+    return launch_fixup_act<BM, BN, WM, WN>(a, rem, stream);
 }
 
 // Tile configurations (id -> BM x BN, wave grid, BK).  MYDET_CONV_CFG=<id> forces one (tuning only).
 int launch_cfg(int id, const ConvArgs &a, hipStream_t s) {
     switch (id) {
-        case 0: return launch<128, 128, 2, 2, 32>(a, s);
-        case 1: return launch<128, 64, 2, 2, 32>(a, s);
-        case 2: return launch<128, 32, 4, 1, 32>(a, s);
-        case 3: return launch<64, 64, 2, 2, 32>(a, s);
-        case 6: return launch<128, 64, 2, 2, 16>(a, s);
-        case 8: return launch<128, 128, 2, 4, 32>(a, s);     // 8 waves, wave tile 64x32
+        // last argument: resident workgroups = 256 CUs x (LDS / register limited workgroups per CU)
+        case 0: return launch<128, 128, 2, 2, 32>(a, 512, s);
+        case 1: return launch<128, 64, 2, 2, 32>(a, 512, s);
+        case 2: return launch<128, 32, 4, 1, 32>(a, 768, s);
+        case 3: return launch<64, 64, 2, 2, 32>(a, 1024, s);
+        case 6: return launch<128, 64, 2, 2, 16>(a, 1280, s);
+        case 8: return launch<128, 128, 2, 4, 32>(a, 512, s);     // 8 waves, wave tile 64x32
         default: return MYDET_E_BADARG;
     }
 }
@@ -325,7 +434,7 @@ int forced_cfg() {
 
 extern "C" int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *w, const float *scale,
                                       const float *shift, const float *residual, int64_t ldr, const float *a_gate,
-                                      float *y,
+                                      void *workspace, int64_t workspace_bytes, float *y,
                                       int64_t ldy, int B, int H, int W, int Cin, int Cout, int KH, int KW,
                                       int stride, int pad_t, int pad_l, int Ho, int Wo, int act, void *stream) {
     if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 ||
@@ -351,6 +460,9 @@ extern "C" int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride;
     a.pad_t = pad_t; a.pad_l = pad_l; a.Ho = Ho; a.Wo = Wo; a.act = act;
     a.M = (int)M64; a.K = KH * KW * Cin; a.ntiles = 0; a.nblk = 0;
+    a.tile0 = 0; a.splits = 1;
+    a.ws = ((uintptr_t)workspace & 15) ? nullptr : (float *)workspace;
+    a.ws_bytes = workspace_bytes > 0 ? (size_t)workspace_bytes : 0;
     hipStream_t s = (hipStream_t)stream;
     if (forced_cfg() >= 0) return launch_cfg(forced_cfg(), a, s);
     // Tile choice, from the per-shape sweep in profiles/ (tools/sweep_conv_cfg.sh):

@@ -91,6 +91,18 @@ def empty_nhwc(B, C, H, W, device, ld=None):
     return buf.permute(0, 3, 1, 2)[:, :C], ld
 
 
+_WORKSPACE = {}
+WORKSPACE_BYTES = 64 << 20
+
+
+def conv_workspace(device):
+    """Per-device scratch for the split-K tail of conv2d (stream-ordered reuse; one stream per process)."""
+    key = (device.type, device.index)
+    if key not in _WORKSPACE:
+        _WORKSPACE[key] = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
+    return _WORKSPACE[key]
+
+
 def conv_out_size(n, k, stride, pad_lo, pad_hi):
     return (n + pad_lo + pad_hi - k) // stride + 1
 
@@ -113,9 +125,11 @@ def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None
     if residual is not None:
         residual, ldr = to_nhwc(residual)
         assert residual.shape == out.shape
+    ws = conv_workspace(x.device)
     t0 = TIMER.start() if TIMER else None
     code = _lib.lib().mydet_conv2d_igemm_f32(
-        _ptr(x), ldx, _ptr(w_ohwi), _ptr(scale), _ptr(shift), _ptr(residual), ldr, _ptr(gate), _ptr(out), ldy,
+        _ptr(x), ldx, _ptr(w_ohwi), _ptr(scale), _ptr(shift), _ptr(residual), ldr, _ptr(gate),
+        _ptr(ws), ws.numel() * 4 if ws is not None else 0, _ptr(out), ldy,
         B, H, W, Cin, Cout, k, k, stride, pad[0], pad[1], Ho, Wo, act, _stream())
     if t0:
         name = f'conv_igemm {Cin}->{Cout} k{k}s{stride} {H}x{W}' if TIMER_DETAIL else 'conv_igemm'

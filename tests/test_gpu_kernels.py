@@ -312,3 +312,24 @@ def test_maxpool_and_bifpn_fuse(dev):
     ref = swish(sum([wi * f for wi, f in zip(w, [a, a2, F.max_pool2d(c_dbl, 3, 2, 1)])]))
     out = ops.bifpn_fuse([a.to(dev), a2.to(dev), c_dbl.to(dev)], [ops.FUSE_SAME, ops.FUSE_SAME, ops.FUSE_POOL], wts.to(dev))
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize('B,Cin,Cout,k,HW', [(11, 1024, 128, 1, 80),     # 64x64 tiles: 2200 = 2 rounds of 1024 + 152
+                                              (69, 128, 256, 3, 32)])     # 128x128 tiles: 1104 = 2 rounds of 512 + 80
+def test_conv_igemm_split_k_tail(dev, B, Cin, Cout, k, HW):
+    """Grids of R full rounds + a small remainder run the remainder tiles split along K (partials in the
+    workspace, summed in fixed order by the fixup launch); result must match a float32 CPU conv."""
+    from mydetection_amd import ops
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B, Cin, HW, HW, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    res = torch.randn(B, Cout, HW, HW, generator=g)
+    p = (k - 1) // 2
+    ref = F.leaky_relu(F.conv2d(x, w, None, 1, p) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), 0.1) + res
+    args = (x.to(dev).contiguous(memory_format=torch.channels_last), w.permute(0, 2, 3, 1).contiguous().to(dev),
+            scale.to(dev), shift.to(dev), k, 1, (p, p, p, p), 1)
+    y = ops.conv2d(*args, residual=res.to(dev).contiguous(memory_format=torch.channels_last))
+    assert (y.cpu() - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+    y2 = ops.conv2d(*args, residual=res.to(dev).contiguous(memory_format=torch.channels_last))
+    assert torch.equal(y, y2)                                  # deterministic

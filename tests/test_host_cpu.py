@@ -25,8 +25,8 @@ def test_argument_errors_are_reported_before_launch():
     from mydetection_amd import _lib
     lib = _lib.lib()
     null = ctypes.c_void_p(0)
-    assert lib.mydet_conv2d_igemm_f32(null, 0, null, null, null, null, 0, null, null, 0, 1, 1, 1, 4, 4, 1, 1, 1, 0, 0, 1, 1,
-                                      0, null) == -1
+    assert lib.mydet_conv2d_igemm_f32(null, 0, null, null, null, null, 0, null, null, 0, null, 0, 1, 1, 1, 4, 4, 1, 1, 1, 0, 0,
+                                      1, 1, 0, null) == -1
     assert lib.mydet_postprocess_f32(null, null, null, 1, 1 << 17, 0.5, 0.5, 512, null, null, null, null, null, null,
                                      null) == -2
     with pytest.raises(_lib.MydetError):
