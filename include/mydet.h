@@ -150,6 +150,19 @@ int mydet_upsample_concat_f32(const float *a, int64_t lda, int Ha, int Wa, int C
 #define MYDET_DECODE_YOLO   0
 #define MYDET_DECODE_RETINA 1
 #define MYDET_DECODE_FCOS   2
+typedef struct mydet_decode_level {
+    const float *box; int64_t ldbox;     /* device */
+    const float *cls; int64_t ldcls;     /* device */
+    const float *anchors_wh;             /* HOST, A pairs, or NULL (FCOS) */
+    int H, W;
+    float stride;
+    int64_t n_off;                       /* first candidate of this level inside [0, N) */
+} mydet_decode_level;
+/* All pyramid levels in one launch (the per-level loop of models/general.py:69-72 + the torch.cat of :74-76);
+ * `levels` is a HOST array of nlevels (<= 5) descriptors; the other arguments as for mydet_decode_f32. */
+int mydet_decode_levels_f32(int mode, int nlevels, const mydet_decode_level *levels, int box_astride, int box_c0,
+                            int cls_astride, int cls_c0, int conf_c0, int A, int C, int B, int img_h, int img_w,
+                            float *bbox, int64_t *class_idx, float *score, int64_t N, void *stream);
 int mydet_decode_f32(int mode,
                      const float *box, int64_t ldbox, int box_astride, int box_c0,
                      const float *cls, int64_t ldcls, int cls_astride, int cls_c0, int conf_c0,

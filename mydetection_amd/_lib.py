@@ -25,6 +25,8 @@ SIGNATURES = {
     'mydet_conv2d_stem_f32': [c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64] + [c_int] * 10 + [c_ptr],
     'mydet_upsample_concat_f32': [c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_int,
                                   c_int, c_ptr],
+    'mydet_decode_levels_f32': [c_int, c_int, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                c_ptr, c_ptr, c_ptr, c_i64, c_ptr],
     'mydet_decode_f32': [c_int, c_ptr, c_i64, c_int, c_int, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_int, c_int,
                          c_int, c_int, c_int, c_f32, c_int, c_int, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr],
     'mydet_postprocess_f32': [c_ptr, c_ptr, c_ptr, c_int, c_i64, c_f32, c_f64, c_int, c_ptr, c_ptr, c_ptr, c_ptr,
@@ -32,6 +34,14 @@ SIGNATURES = {
     'mydet_bboxes_iou_f32': [c_ptr, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr],
     'mydet_bboxes_to_original_f32': [c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_ptr],
 }
+
+
+
+class DecodeLevel(ctypes.Structure):
+    """mydet_decode_level (include/mydet.h)."""
+    _fields_ = [('box', c_ptr), ('ldbox', c_i64), ('cls', c_ptr), ('ldcls', c_i64), ('anchors_wh', c_ptr),
+                ('H', c_int), ('W', c_int), ('stride', c_f32), ('n_off', c_i64)]
+
 
 _lib = None
 

@@ -10,7 +10,8 @@
 // saturation distinct logits collapse onto one float32 sigmoid and the reference's "first index among equal
 // sigmoids" is decided by those collisions).  Box arithmetic follows the reference's operation order; the file is
 // built with -ffp-contract=off so no product is fused into a sum.  Outputs of a wave are 64 consecutive
-// candidates: coalesced 16-byte box stores.
+// candidates: coalesced 16-byte box stores.  All pyramid levels are decoded by ONE launch (a tile belongs to a
+// level), and a workgroup prefetches its next tile into registers while it computes the current one.
 //
 //   YOLO   models/detlayers/yolov3.py:41-69    cx=(s(tx)+x)*stride, w=exp(tw)*aw, score=s(conf)*max s(cls)
 //   RETINA models/detlayers/retinanet.py:63-82 cx=acx+tx*aw, w=exp(tw)*aw, clamp [1,max(H,W)], score=max s(cls)
@@ -22,51 +23,117 @@
 namespace {
 
 constexpr int MAX_A = 16;
+constexpr int MAX_LEVELS = 5;
+constexpr int MAXV = 12;          // float4 staging registers per thread (one tile = at most MAXV * 256 float4)
 
-struct DecodeArgs {
-    int mode;
+struct Level {
     const float *box, *cls;
-    int64_t ldbox, ldcls;
-    int box_astride, box_c0, cls_astride, cls_c0, conf_c0;
-    int A, C, H, W, img_h, img_w;
-    int box_span, cls_span;      // floats of a pixel actually needed (multiple of 4)
-    int same;                    // box and cls are the same tensor
-    int PIX, row;                // pixels per tile, LDS row length (odd)
+    int64_t ldbox, ldcls, n_off, npix;
+    int H, W, tile0, ntiles;
     float stride;
     float aw[MAX_A], ah[MAX_A];
+};
+
+struct DecodeArgs {
+    int mode, nlevels, total_tiles;
+    int box_astride, box_c0, cls_astride, cls_c0, conf_c0;
+    int A, C, img_h, img_w;
+    int box_span, cls_span;      // floats of a pixel actually needed (multiples of 4)
+    int same;                    // box and cls are the same tensor
+    int PIX, row;                // pixels per tile, LDS row length (odd)
+    unsigned qc, qb, mc, mb;     // float4 per row (cls, box) and their magic reciprocals: i / q == (i * m) >> 20
     float *bbox;
     int64_t *cidx;
     float *score;
-    int64_t N, n_off, npix;
+    int64_t N;
+    Level lv[MAX_LEVELS];
 };
 
-__device__ __forceinline__ void stage_rows(float *sm, int row, int col0, const float *src, int64_t ld, int span,
-                                           int npx) {
-    const int q = span >> 2;
-    for (int i = threadIdx.x; i < npx * q; i += 256) {
-        const int r = i / q, c4 = i - r * q;
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + (int64_t)r * ld + c4 * 4);
-        float *d = sm + r * row + col0 + c4 * 4;
-        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+// Staging is branch-free so the loads of a tile are all in flight together: indices past the tile are clamped
+// (they re-load the last element) and their LDS stores are diverted to a dump slot behind the tile.
+constexpr int MAXV_B = 2;         // float4 per thread for the box rows when they live in a separate tensor
+
+__device__ __forceinline__ void tile_load(const DecodeArgs &p, const Level &L, int tile, f32x4 (&v)[MAXV],
+                                          f32x4 (&vb)[MAXV_B]) {
+    const int64_t pix0 = (int64_t)tile * p.PIX;
+    const int npx = (int)(L.npix - pix0 < p.PIX ? L.npix - pix0 : p.PIX);
+    const unsigned ncls4 = npx * p.qc, nbox4 = npx * p.qb;
+    const float *cls = L.cls + pix0 * L.ldcls, *box = L.box + pix0 * L.ldbox;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        if (256u * j < ncls4) {                                            // uniform
+            unsigned i = threadIdx.x + 256u * j;
+            i = i < ncls4 ? i : ncls4 - 1;
+            const unsigned r = (i * p.mc) >> 20, c4 = i - r * p.qc;
+            v[j] = *reinterpret_cast<const f32x4 *>(cls + (int64_t)r * L.ldcls + c4 * 4);
+        }
+    }
+    if (!p.same) {
+#pragma unroll
+        for (int j = 0; j < MAXV_B; ++j) {
+            if (256u * j < nbox4) {
+                unsigned i = threadIdx.x + 256u * j;
+                i = i < nbox4 ? i : nbox4 - 1;
+                const unsigned r = (i * p.mb) >> 20, c4 = i - r * p.qb;
+                vb[j] = *reinterpret_cast<const f32x4 *>(box + (int64_t)r * L.ldbox + c4 * 4);
+            }
+        }
     }
 }
 
+// Registers -> LDS rows of odd length (4 dword writes per float4: the rows are not 16-byte aligned).
+__device__ __forceinline__ void tile_store(const DecodeArgs &p, int npx, const f32x4 (&v)[MAXV],
+                                           const f32x4 (&vb)[MAXV_B], float *sm) {
+    const unsigned ncls4 = npx * p.qc, nbox4 = npx * p.qb;
+    float *dump = sm + p.PIX * p.row;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        if (256u * j < ncls4) {
+            const unsigned i = threadIdx.x + 256u * j;
+            const unsigned r = (i * p.mc) >> 20, c4 = i - r * p.qc;
+            float *d = i < ncls4 ? sm + r * p.row + c4 * 4 : dump;
+            d[0] = v[j][0]; d[1] = v[j][1]; d[2] = v[j][2]; d[3] = v[j][3];
+        }
+    }
+    if (!p.same) {
+#pragma unroll
+        for (int j = 0; j < MAXV_B; ++j) {
+            if (256u * j < nbox4) {
+                const unsigned i = threadIdx.x + 256u * j;
+                const unsigned r = (i * p.mb) >> 20, c4 = i - r * p.qb;
+                float *d = i < nbox4 ? sm + r * p.row + p.cls_span + c4 * 4 : dump;
+                d[0] = vb[j][0]; d[1] = vb[j][1]; d[2] = vb[j][2]; d[3] = vb[j][3];
+            }
+        }
+    }
+}
+
+// grid = (tile slots, levels): blockIdx.y picks the level ONCE (static-index select chain, no dynamic indexing of
+// the kernel arguments), blockIdx.x strides over that level's tiles; surplus workgroups of small levels exit.
 __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float s_aw[MAX_A], s_ah[MAX_A];
+    const int l = blockIdx.y;
+    Level L = p.lv[0];
+#pragma unroll
+    for (int k = 1; k < MAX_LEVELS; ++k)
+        if (l == k) L = p.lv[k];
+    if ((int)blockIdx.x >= L.ntiles) return;
 #pragma unroll
     for (int a = 0; a < MAX_A; ++a)
-        if (threadIdx.x == a) { s_aw[a] = p.aw[a]; s_ah[a] = p.ah[a]; }
-    const int hw = p.H * p.W;
+        if (threadIdx.x == a) { s_aw[a] = L.aw[a]; s_ah[a] = L.ah[a]; }
     const float fmaxhw = (float)(p.img_h > p.img_w ? p.img_h : p.img_w);
     const int box_col = p.same ? 0 : p.cls_span;
-    const int64_t ntiles = (p.npix + p.PIX - 1) / p.PIX;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t pix0 = tile * p.PIX;
-        const int npx = (int)(p.npix - pix0 < p.PIX ? p.npix - pix0 : p.PIX);
-        stage_rows(sm, p.row, 0, p.cls + pix0 * p.ldcls, p.ldcls, p.cls_span, npx);
-        if (!p.same) stage_rows(sm, p.row, box_col, p.box + pix0 * p.ldbox, p.ldbox, p.box_span, npx);
+    const int hw = L.H * L.W;
+    const float st = L.stride;
+    f32x4 v[MAXV], vb[MAXV_B];
+    tile_load(p, L, blockIdx.x, v, vb);
+    for (int tile = blockIdx.x; tile < L.ntiles; tile += gridDim.x) {
+        const int64_t pix0 = (int64_t)tile * p.PIX;
+        const int npx = (int)(L.npix - pix0 < p.PIX ? L.npix - pix0 : p.PIX);
+        tile_store(p, npx, v, vb, sm);
         __syncthreads();
+        if (tile + (int)gridDim.x < L.ntiles) tile_load(p, L, tile + gridDim.x, v, vb);  // flies under the compute phase
         for (int c = threadIdx.x; c < p.PIX * p.A; c += 256) {
             const int a = c / p.PIX, px = c - a * p.PIX;
             if (px >= npx) continue;
@@ -75,10 +142,13 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs p) {
             // class max / first argmax (strict >: the first maximum wins, as torch.max)
             float best = cl[0];
             int bi = 0;
-#pragma unroll 8
-            for (int k = 1; k < p.C; ++k) {
-                const float v = cl[k];
-                if (v > best) { best = v; bi = k; }
+            for (int k0 = 1; k0 < p.C; k0 += 8) {      // 8 LDS reads in flight, then the ordered compare chain
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = cl[k0 + j < p.C ? k0 + j : p.C - 1];   // clamped repeats never win
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (x[j] > best) { best = x[j]; bi = k0 + j; }
             }
             float cmax;
             if (best < 5.0f && best > -80.0f) {
@@ -96,19 +166,19 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs p) {
             const int64_t pix = pix0 + px;
             const int b = (int)(pix / hw);
             const int rem = (int)(pix - (int64_t)b * hw);
-            const int gy = rem / p.W, gx = rem - gy * p.W;
+            const int gy = rem / L.W, gx = rem - gy * L.W;
             const float aw = s_aw[a], ah = s_ah[a];
             f32x4 o;
             float sc;
             if (p.mode == MYDET_DECODE_YOLO) {
-                o[0] = (mydet_sigmoid(t0) + (float)gx) * p.stride;
-                o[1] = (mydet_sigmoid(t1) + (float)gy) * p.stride;
+                o[0] = (mydet_sigmoid(t0) + (float)gx) * st;
+                o[1] = (mydet_sigmoid(t1) + (float)gy) * st;
                 o[2] = expf(t2) * aw;
                 o[3] = expf(t3) * ah;
                 sc = mydet_sigmoid(rowp[a * p.cls_astride + p.conf_c0]) * cmax;
             } else if (p.mode == MYDET_DECODE_RETINA) {
-                const float acx = p.stride * 0.5f + (float)gx * p.stride;
-                const float acy = p.stride * 0.5f + (float)gy * p.stride;
+                const float acx = st * 0.5f + (float)gx * st;
+                const float acy = st * 0.5f + (float)gy * st;
                 o[0] = acx + t0 * aw;
                 o[1] = acy + t1 * ah;
                 o[2] = expf(t2) * aw;
@@ -117,20 +187,20 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs p) {
                 for (int j = 0; j < 4; ++j) o[j] = fminf(fmaxf(o[j], 1.0f), fmaxhw);
                 sc = cmax;
             } else {
-                const float cx = (float)gx * p.stride + p.stride * 0.5f;
-                const float cy = (float)gy * p.stride + p.stride * 0.5f;
+                const float cx = (float)gx * st + st * 0.5f;
+                const float cy = (float)gy * st + st * 0.5f;
                 const float fw = (float)p.img_w, fh = (float)p.img_h;
-                const float x1 = fminf(fmaxf(cx - expf(t0) * p.stride, 0.0f), fw);
-                const float y1 = fminf(fmaxf(cy - expf(t1) * p.stride, 0.0f), fh);
-                const float x2 = fminf(fmaxf(cx + expf(t2) * p.stride, 0.0f), fw);
-                const float y2 = fminf(fmaxf(cy + expf(t3) * p.stride, 0.0f), fh);
+                const float x1 = fminf(fmaxf(cx - expf(t0) * st, 0.0f), fw);
+                const float y1 = fminf(fmaxf(cy - expf(t1) * st, 0.0f), fh);
+                const float x2 = fminf(fmaxf(cx + expf(t2) * st, 0.0f), fw);
+                const float y2 = fminf(fmaxf(cy + expf(t3) * st, 0.0f), fh);
                 o[0] = (x1 + x2) / 2.0f;
                 o[1] = (y1 + y2) / 2.0f;
                 o[2] = x2 - x1;
                 o[3] = y2 - y1;
                 sc = sqrtf(mydet_sigmoid(rowp[a * p.cls_astride + p.conf_c0]) * cmax);
             }
-            const int64_t n = (int64_t)b * p.N + p.n_off + ((int64_t)a * p.H + gy) * p.W + gx;
+            const int64_t n = (int64_t)b * p.N + L.n_off + ((int64_t)a * L.H + gy) * L.W + gx;
             *reinterpret_cast<f32x4 *>(p.bbox + n * 4) = o;
             p.cidx[n] = (int64_t)bi;
             p.score[n] = sc;
@@ -139,54 +209,87 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs p) {
     }
 }
 
+unsigned magic20(unsigned q, unsigned max_i) {       // m with (i * m) >> 20 == i / q for all i <= max_i (checked)
+    const unsigned m = (1u << 20) / q + 1;
+    for (unsigned i = 0; i <= max_i; ++i)
+        if (((uint64_t)i * m) >> 20 != i / q || (uint64_t)i * m > 0xFFFFFFFFull) return 0;
+    return m;
+}
+
 }  // namespace
+
+extern "C" int mydet_decode_levels_f32(int mode, int nlevels, const mydet_decode_level *levels, int box_astride,
+                                       int box_c0, int cls_astride, int cls_c0, int conf_c0, int A, int C, int B,
+                                       int img_h, int img_w, float *bbox, int64_t *class_idx, float *score, int64_t N,
+                                       void *stream) {
+    if (mode < 0 || mode > 2 || !levels || nlevels <= 0 || nlevels > MAX_LEVELS || !bbox || !class_idx || !score)
+        return MYDET_E_BADARG;
+    if (A <= 0 || A > MAX_A || C <= 0 || C > 128 || B <= 0 || ((uintptr_t)bbox & 15)) return MYDET_E_BADARG;
+    DecodeArgs p;
+    p.mode = mode; p.nlevels = nlevels;
+    p.box_astride = box_astride; p.box_c0 = box_c0; p.cls_astride = cls_astride; p.cls_c0 = cls_c0;
+    p.conf_c0 = conf_c0; p.A = A; p.C = C; p.img_h = img_h; p.img_w = img_w;
+    p.bbox = bbox; p.cidx = class_idx; p.score = score; p.N = N;
+    int cls_need = (A - 1) * cls_astride + cls_c0 + C;
+    if (mode != MYDET_DECODE_RETINA) {
+        const int cneed = (A - 1) * cls_astride + conf_c0 + 1;
+        cls_need = cls_need > cneed ? cls_need : cneed;
+    }
+    const int box_need = (A - 1) * box_astride + box_c0 + 4;
+    p.same = 1;
+    for (int l = 0; l < nlevels; ++l)
+        if (levels[l].box != levels[l].cls || levels[l].ldbox != levels[l].ldcls) p.same = 0;
+    if (p.same) cls_need = cls_need > box_need ? cls_need : box_need;
+    p.cls_span = (cls_need + 3) & ~3;
+    p.box_span = (box_need + 3) & ~3;
+    p.row = (p.cls_span + (p.same ? 0 : p.box_span)) | 1;               // odd row length: conflict-free column walks
+    p.qc = p.cls_span >> 2; p.qb = p.box_span >> 2;
+    p.PIX = 32;                                                        // 33 KB tiles for YOLO: 4 workgroups per CU
+    while (p.PIX > 1 && ((size_t)p.PIX * p.row * sizeof(float) > 60 * 1024 || (size_t)p.PIX * p.qc > MAXV * 256 ||
+                         (!p.same && (size_t)p.PIX * p.qb > MAXV_B * 256)))
+        p.PIX >>= 1;
+    if ((size_t)p.PIX * p.qc > MAXV * 256 || (!p.same && (size_t)p.PIX * p.qb > MAXV_B * 256)) return MYDET_E_UNSUPP;
+    p.mc = magic20(p.qc, p.PIX * p.qc);
+    p.mb = magic20(p.qb, p.PIX * p.qb);
+    if (!p.mc || !p.mb) return MYDET_E_UNSUPP;
+    int tile0 = 0;
+    for (int l = 0; l < MAX_LEVELS; ++l) {
+        Level &L = p.lv[l];
+        for (int a = 0; a < MAX_A; ++a) { L.aw[a] = 0.f; L.ah[a] = 0.f; }
+        if (l >= nlevels) { L = p.lv[0]; L.ntiles = 0; L.tile0 = tile0; continue; }
+        const mydet_decode_level &in = levels[l];
+        if (!in.box || !in.cls || in.H <= 0 || in.W <= 0 || (in.ldbox & 3) || (in.ldcls & 3) ||
+            ((uintptr_t)in.box & 15) || ((uintptr_t)in.cls & 15))
+            return MYDET_E_BADARG;
+        if (p.cls_span > in.ldcls || p.box_span > in.ldbox) return MYDET_E_BADARG;
+        if (mode != MYDET_DECODE_FCOS && !in.anchors_wh) return MYDET_E_BADARG;
+        if (in.n_off < 0 || in.n_off + (int64_t)A * in.H * in.W > N) return MYDET_E_BADARG;
+        L.box = in.box; L.cls = in.cls; L.ldbox = in.ldbox; L.ldcls = in.ldcls; L.n_off = in.n_off;
+        L.H = in.H; L.W = in.W; L.stride = in.stride; L.npix = (int64_t)B * in.H * in.W;
+        if (in.anchors_wh)      // HOST pointer: the pairs travel as kernel arguments
+            for (int a = 0; a < A; ++a) { L.aw[a] = in.anchors_wh[2 * a]; L.ah[a] = in.anchors_wh[2 * a + 1]; }
+        const int64_t nt = (L.npix + p.PIX - 1) / p.PIX;
+        if (nt + tile0 > 0x7fffffff) return MYDET_E_BADARG;
+        L.tile0 = tile0; L.ntiles = (int)nt;
+        tile0 += (int)nt;
+    }
+    p.total_tiles = tile0;
+    const size_t lds = ((size_t)p.PIX * p.row + 4) * sizeof(float);     // + dump slot for clamped staging lanes
+    int max_tiles = 0;
+    for (int l = 0; l < nlevels; ++l) max_tiles = p.lv[l].ntiles > max_tiles ? p.lv[l].ntiles : max_tiles;
+    const int gx = max_tiles < 256 * 6 ? max_tiles : 256 * 6;
+    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)gx, (unsigned)nlevels), dim3(256), lds, (hipStream_t)stream, p);
+    return mydet_launch_status();
+}
 
 extern "C" int mydet_decode_f32(int mode, const float *box, int64_t ldbox, int box_astride, int box_c0,
                                 const float *cls, int64_t ldcls, int cls_astride, int cls_c0, int conf_c0,
                                 const float *anchors_wh, int A, int C, int B, int H, int W, float stride,
                                 int img_h, int img_w, float *bbox, int64_t *class_idx, float *score, int64_t N,
                                 int64_t n_off, void *stream) {
-    if (mode < 0 || mode > 2 || !box || !cls || !bbox || !class_idx || !score) return MYDET_E_BADARG;
-    if (A <= 0 || A > MAX_A || C <= 0 || C > 128 || B <= 0 || H <= 0 || W <= 0) return MYDET_E_BADARG;
-    if ((ldbox & 3) || (ldcls & 3) || ((uintptr_t)box & 15) || ((uintptr_t)cls & 15) || ((uintptr_t)bbox & 15))
-        return MYDET_E_BADARG;
-    if (mode != MYDET_DECODE_FCOS && !anchors_wh) return MYDET_E_BADARG;
-    if (n_off < 0 || n_off + (int64_t)A * H * W > N) return MYDET_E_BADARG;
-    DecodeArgs p;
-    p.mode = mode; p.box = box; p.cls = cls; p.ldbox = ldbox; p.ldcls = ldcls;
-    p.box_astride = box_astride; p.box_c0 = box_c0; p.cls_astride = cls_astride; p.cls_c0 = cls_c0;
-    p.conf_c0 = conf_c0; p.A = A; p.C = C; p.H = H; p.W = W; p.img_h = img_h; p.img_w = img_w;
-    p.stride = stride; p.bbox = bbox; p.cidx = class_idx; p.score = score; p.N = N; p.n_off = n_off;
-    p.npix = (int64_t)B * H * W;
-    for (int a = 0; a < MAX_A; ++a) { p.aw[a] = 0.f; p.ah[a] = 0.f; }
-    // anchors_wh is a HOST pointer (mydet.h): the pairs travel as kernel arguments.
-    if (anchors_wh)
-        for (int a = 0; a < A; ++a) { p.aw[a] = anchors_wh[2 * a]; p.ah[a] = anchors_wh[2 * a + 1]; }
-    int cls_need = (A - 1) * cls_astride + cls_c0 + C;
-    if (mode != MYDET_DECODE_RETINA) {
-        const int cneed = (A - 1) * cls_astride + conf_c0 + 1;
-        cls_need = cls_need > cneed ? cls_need : cneed;
-    }
-    int box_need = (A - 1) * box_astride + box_c0 + 4;
-    p.same = (box == cls && ldbox == ldcls) ? 1 : 0;
-    if (p.same) cls_need = cls_need > box_need ? cls_need : box_need;
-    p.cls_span = (cls_need + 3) & ~3;
-    p.box_span = (box_need + 3) & ~3;
-    if (p.cls_span > ldcls || p.box_span > ldbox) return MYDET_E_BADARG;
-    p.row = (p.cls_span + (p.same ? 0 : p.box_span)) | 1;               // odd row length: conflict-free column walks
-    p.PIX = 32;                                                        // 32-pixel tiles: 33 KB (YOLO), 4 workgroups per CU overlap load and compute
-    if (const char *e = getenv("MYDET_DECODE_PIX")) p.PIX = atoi(e);      // tuning knob
-    while (p.PIX > 4 && (size_t)p.PIX * p.row * sizeof(float) > 80 * 1024) p.PIX >>= 1;
-    const size_t lds = (size_t)p.PIX * p.row * sizeof(float);
-    if (lds > 80 * 1024) return MYDET_E_UNSUPP;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  80 * 1024);
-        attr_set = true;
-    }
-    int64_t blocks = (p.npix + p.PIX - 1) / p.PIX;
-    if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
-    return mydet_launch_status();
+    mydet_decode_level lv;
+    lv.box = box; lv.ldbox = ldbox; lv.cls = cls; lv.ldcls = ldcls; lv.anchors_wh = anchors_wh;
+    lv.H = H; lv.W = W; lv.stride = stride; lv.n_off = n_off;
+    return mydet_decode_levels_f32(mode, 1, &lv, box_astride, box_c0, cls_astride, cls_c0, conf_c0, A, C, B, img_h,
+                                   img_w, bbox, class_idx, score, N, stream);
 }

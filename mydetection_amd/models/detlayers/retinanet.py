@@ -65,3 +65,15 @@ class RetinaLayer(nn.Module):
         preds = {'bbox': bbox[:, n_off:n_off + n], 'class_idx': cls_idx[:, n_off:n_off + n],
                  'score': score[:, n_off:n_off + n]}
         return preds, None
+
+    def _describe(self, raw, img_size):
+        """Level descriptor for the single-launch decode (ops.decode_levels), or None."""
+        packed = getattr(raw, 'packed', None)
+        if packed is None:
+            return None
+        box, ldb, bas, bc0 = packed['box']
+        cls, ldc, cas, cc0, _ = packed['cls']
+        nH, nW = raw['bbox'].shape[2:4]
+        return {'mode': ops.DECODE_RETINA, 'layout': (bas, bc0, cas, cc0, 0), 'A': self.num_anchors, 'C': self.n_cls,
+                'level': {'box': box, 'ldbox': ldb, 'cls': cls, 'ldcls': ldc, 'anchors_wh': self.anchor_wh.numpy(),
+                          'H': nH, 'W': nW, 'stride': self.stride}}

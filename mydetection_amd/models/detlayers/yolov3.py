@@ -55,3 +55,14 @@ class YOLOLayer(nn.Module):
             'score': score[:, n_off:n_off + n],
         }
         return preds, None
+
+    def _describe(self, raw, img_size):
+        """Level descriptor for the single-launch decode (ops.decode_levels), or None."""
+        packed = getattr(raw, 'packed', None)
+        if packed is None:
+            return None
+        head, ld, per, _ = packed['box']
+        nH, nW = raw['bbox'].shape[2:4]
+        return {'mode': ops.DECODE_YOLO, 'layout': (per, 0, per, 5, 4), 'A': self.num_anchors, 'C': self.n_cls,
+                'level': {'box': head, 'ldbox': ld, 'cls': head, 'ldcls': ld, 'anchors_wh': self.anchors.numpy(),
+                          'H': nH, 'W': nW, 'stride': self.stride}}

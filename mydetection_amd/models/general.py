@@ -4,6 +4,7 @@ import json
 
 import torch
 
+from .. import ops
 from .registry import get_backbone, get_fpn, get_rpn, get_det_layer
 from ..utils.structures import ImageObjects
 
@@ -70,6 +71,17 @@ class OneStageBBox(torch.nn.Module):
         bbs = torch.empty((nB, n_total, 4), dtype=torch.float32, device=x.device)
         cls_idx = torch.empty((nB, n_total), dtype=torch.int64, device=x.device)
         scores = torch.empty((nB, n_total), dtype=torch.float32, device=x.device)
+        descs = [getattr(layer, '_describe', lambda *_: None)(raw, self.img_size)
+                 for layer, raw in zip(self.det_layers, all_branch_preds)]
+        if all(d is not None for d in descs) and len({(d['mode'], d['layout'], d['A'], d['C']) for d in descs}) == 1:
+            # every level in ONE launch, written at its offset of the level-concatenated arrays
+            levels, n_off = [], 0
+            for d, n in zip(descs, counts):
+                levels.append(dict(d['level'], n_off=n_off))
+                n_off += n
+            d = descs[0]
+            ops.decode_levels(d['mode'], levels, *d['layout'], d['A'], d['C'], nB, self.img_size, bbs, cls_idx, scores)
+            return bbs, cls_idx, scores
         n_off = 0
         for i, raw_preds in enumerate(all_branch_preds):
             self.det_layers[i](raw_preds, self.img_size, None, _out=(bbs, cls_idx, scores, n_off))

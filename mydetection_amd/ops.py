@@ -300,6 +300,35 @@ def decode(mode, box, ldbox, box_astride, box_c0, cls, ldcls, cls_astride, cls_c
     _lib.check(code, 'mydet_decode_f32')
 
 
+def decode_levels(mode, levels, box_astride, box_c0, cls_astride, cls_c0, conf_c0, A, C, B, img_hw, bbox, class_idx,
+                  score):
+    """Decode every pyramid level with one launch.  levels: list of dicts with keys box, ldbox, cls, ldcls,
+    anchors_wh (array-like [A,2] or None), H, W, stride, n_off."""
+    require_gpu(bbox, 'decode_levels')
+    n = len(levels)
+    arr = (_lib.DecodeLevel * n)()
+    keep = []                                         # host anchor arrays must outlive the call
+    work = 0.0
+    for i, lv in enumerate(levels):
+        anch = None
+        if lv['anchors_wh'] is not None:
+            anch = np.ascontiguousarray(np.asarray(lv['anchors_wh'], dtype=np.float32).reshape(-1))
+            assert anch.size == 2 * A
+            keep.append(anch)
+        arr[i] = _lib.DecodeLevel(lv['box'].data_ptr(), lv['ldbox'], lv['cls'].data_ptr(), lv['ldcls'],
+                                  anch.ctypes.data if anch is not None else None, lv['H'], lv['W'], float(lv['stride']),
+                                  lv['n_off'])
+        per_pix = A * (C + 4 + (0 if mode == DECODE_RETINA else 1))
+        work += 4.0 * B * lv['H'] * lv['W'] * per_pix + 28.0 * B * A * lv['H'] * lv['W']
+    t0 = TIMER.start() if TIMER else None
+    code = _lib.lib().mydet_decode_levels_f32(mode, n, ctypes.cast(arr, ctypes.c_void_p), box_astride, box_c0,
+                                              cls_astride, cls_c0, conf_c0, A, C, B, int(img_hw[0]), int(img_hw[1]),
+                                              _ptr(bbox), _ptr(class_idx), _ptr(score), bbox.shape[1], _stream())
+    if t0:
+        TIMER.stop('decode', t0, work)
+    _lib.check(code, 'mydet_decode_levels_f32')
+
+
 def postprocess(bbox, class_idx, score, conf_thres, nms_thres, topk=TOPK):
     """Batched filter/top-k/class-aware NMS.  bbox [B,N,4], class_idx [B,N] i64, score [B,N].
 
