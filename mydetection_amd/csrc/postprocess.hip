@@ -6,8 +6,8 @@
 // design goal is few dependent steps:
 //   1. filter: one coalesced sweep of score[N]; passing candidates become unique 64-bit
 //      keys (sortable score bits << 32 | ~index) compacted into an HBM scratch strip.
-//   2. top-k (only if more than k pass): 8-pass byte-wise radix SELECT of the k-th
-//      largest key -- no sort of the N candidates.  Key order = score desc, index asc,
+//   2. top-k (only if more than k pass): the k-th largest key is found bit by bit (ballot/popcount
+//      counting, stops as soon as a threshold cuts off exactly k keys) -- no sort of the N candidates.  Key order = score desc, index asc,
 //      which fixes the tie order torch.topk leaves unspecified.
 //   3. bitonic sort of the <= 512 selected in LDS by (class asc, score desc, index asc):
 //      this is the reference's output order (per-class loop over sorted unique labels,
@@ -16,8 +16,9 @@
 //   4. suppression matrix: bit j of row i set iff j > i, same class, (double)IoU > thr --
 //      IoU in the exact float32 operation order of torchvision's CPU nms kernel (this file
 //      is built with -ffp-contract=off).
-//   5. greedy pass by one wave over the 512-bit rows (next rows prefetched off the
-//      dependent chain), then rank-by-popcount compaction of survivors.
+//   5. greedy pass by one wave, 64 boxes at a time: inside a chunk the dependent chain stays on the scalar
+//      unit (bit test, v_readlane of the diagonal word, scalar OR); survivors of the chunk then OR their rows
+//      into the later words by wave reduction.  Rank-by-popcount compaction of survivors follows.
 // Replaces ImageObjects.post_process / non_max_suppression (utils/structures.py:92-173).
 #include "common.h"
 
@@ -52,11 +53,10 @@ __global__ __launch_bounds__(NT) void postprocess_kernel(const PPArgs p) {
     __shared__ unsigned long long s_key[KMAX];
     __shared__ unsigned long long s_mask[KMAX * 8];
     __shared__ float s_x1[KMAX], s_y1[KMAX], s_x2[KMAX], s_y2[KMAX], s_area[KMAX];
-    __shared__ int s_cls[KMAX];
-    __shared__ unsigned s_hist[256];
+    __shared__ int s_cls[KMAX], s_segend[KMAX];
+    __shared__ int s_cnt[3];
     __shared__ unsigned long long s_removed[8];
-    __shared__ unsigned long long s_prefix;
-    __shared__ int s_n, s_nsel, s_need;
+    __shared__ int s_n, s_nsel;
 
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
@@ -81,35 +81,35 @@ __global__ __launch_bounds__(NT) void postprocess_kernel(const PPArgs p) {
     // scratch written above is re-read by other threads of this workgroup only
     __threadfence_block();
 
-    // 2. k-th largest key by radix select
+    // 2. k-th largest key, built bit by bit from the top: with candidate = prefix | bit, count(key >= candidate)
+    //    says whether the k-th largest has that bit.  Counting is a ballot + popcount per wave and ONE LDS add per
+    //    wave (no histogram: scores share their exponent bytes, a byte histogram would serialise on a few bins).
+    //    Stops as soon as a candidate cuts off exactly k keys.  The first 16 keys of a thread stay in registers.
     unsigned long long kth = 0;
     if (n > p.topk) {
-        if (tid == 0) { s_prefix = 0; s_need = p.topk; }
-        for (int pass = 0; pass < 8; ++pass) {
-            const int shift = 56 - 8 * pass;
-            if (tid < 256) s_hist[tid] = 0;
+        constexpr int RK = 16;
+        unsigned long long rk[RK];
+#pragma unroll
+        for (int j = 0; j < RK; ++j) rk[j] = tid + j * NT < n ? keys[tid + j * NT] : 0ull;
+        if (tid < 3) s_cnt[tid] = 0;
+        __syncthreads();
+        unsigned long long prefix = 0;
+        for (int bit = 63, it = 0; bit >= 0; --bit, ++it) {
+            const unsigned long long cand = prefix | (1ull << bit);
+            int c = 0;
+#pragma unroll
+            for (int j = 0; j < RK; ++j) c += rk[j] >= cand ? 1 : 0;
+            for (int i = tid + RK * NT; i < n; i += NT) c += keys[i] >= cand ? 1 : 0;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
+            if ((tid & 63) == 0) atomicAdd(&s_cnt[it % 3], c);
+            if (tid == 0) s_cnt[(it + 1) % 3] = 0;
             __syncthreads();
-            const unsigned long long prefix = s_prefix;
-            const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
-            for (int i = tid; i < n; i += NT) {
-                const unsigned long long k = keys[i];
-                if ((k & himask) == prefix) atomicAdd(&s_hist[(unsigned)(k >> shift) & 255u], 1u);
-            }
-            __syncthreads();
-            if (tid == 0) {
-                int need = s_need;
-                int bin = 255;
-                for (; bin > 0; --bin) {
-                    const int h = (int)s_hist[bin];
-                    if (h >= need) break;
-                    need -= h;
-                }
-                s_need = need;
-                s_prefix = prefix | ((unsigned long long)bin << shift);
-            }
-            __syncthreads();
+            const int cnt = s_cnt[it % 3];
+            if (cnt >= p.topk) prefix = cand;
+            if (cnt == p.topk) break;
         }
-        kth = s_prefix;
+        kth = prefix;
     }
 
     // 3. gather the selected, build (class, ~score, index) keys, sort
@@ -153,41 +153,85 @@ __global__ __launch_bounds__(NT) void postprocess_kernel(const PPArgs p) {
         s_cls[tid] = (int)(k >> 49);
     }
     __syncthreads();
-    const int nwords = (nsel + 63) >> 6;
-    for (int item = tid; item < nsel * 8; item += NT) {
-        const int i = item >> 3, w = item & 7;
-        unsigned long long bits = 0;
-        if (w < nwords && w * 64 + 63 > i) {
+    // rows are zero except inside the row's own class segment (classes are contiguous after the sort).  
+    for (int w = tid; w < nsel * 8; w += NT) s_mask[w] = 0ull;
+    if (tid < nsel) {                                   // end of my class segment: upper bound of my class
+        const int ic = s_cls[tid];
+        int lo = tid + 1, hi = nsel;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_cls[mid] == ic) lo = mid + 1; else hi = mid;
+        }
+        s_segend[tid] = lo;
+    }
+    __syncthreads();
+    // a wave owns rows i = wave, wave+16, ...; for each it walks only the 64-box words that overlap
+    // [i+1, end of i's class segment): lane = one j, the word is the wave's ballot (no atomics, conflict-free LDS)
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int i = wave; i < nsel; i += NT / 64) {
+            const int e = s_segend[i];
             const float ix1 = s_x1[i], iy1 = s_y1[i], ix2 = s_x2[i], iy2 = s_y2[i], ia = s_area[i];
-            const int ic = s_cls[i];
-            for (int jj = 0; jj < 64; ++jj) {
-                const int j = w * 64 + jj;
-                if (j > i && j < nsel && s_cls[j] == ic) {
+            for (int w = (i + 1) >> 6; w * 64 < e; ++w) {
+                const int j = w * 64 + lane;
+                bool sup = false;
+                if (j > i && j < e) {
                     const float xx1 = fmaxf(ix1, s_x1[j]), yy1 = fmaxf(iy1, s_y1[j]);
                     const float xx2 = fminf(ix2, s_x2[j]), yy2 = fminf(iy2, s_y2[j]);
                     const float ww = fmaxf(0.0f, xx2 - xx1), hh = fmaxf(0.0f, yy2 - yy1);
                     const float inter = ww * hh;
                     const float ovr = inter / (ia + s_area[j] - inter);
-                    if ((double)ovr > p.nms) bits |= 1ull << jj;
+                    sup = (double)ovr > p.nms;
                 }
+                const unsigned long long bits = __ballot(sup);
+                if (lane == 0) s_mask[i * 8 + w] = bits;
             }
         }
-        s_mask[item] = bits;
     }
     __syncthreads();
 
     // 5. greedy scan (wave 0; lane w < 8 owns word w of the removed set)
+    // One wave, 64 boxes at a time.  Lane l holds row 64c+l.  Inside a chunk the dependent chain runs on the
+    // scalar unit only (bit test on a 64-bit scalar, v_readlane of the diagonal word, scalar OR); the chunk's
+    // survivors then OR their rows into the later words with one wave reduction per word.
     if (tid < 64) {
-        unsigned long long removed = 0;
-        const int lw = tid & 7;
-        unsigned long long row = nsel > 0 ? s_mask[lw] : 0ull;
-        for (int i = 0; i < nsel; ++i) {
-            const unsigned long long nxt = (i + 1 < nsel) ? s_mask[(i + 1) * 8 + lw] : 0ull;   // off the chain
-            const unsigned long long rw = __shfl(removed, i >> 6);
-            if (!((rw >> (i & 63)) & 1ull)) removed |= row;
-            row = nxt;
+        const int lane = tid;
+        unsigned long long removed[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) removed[w] = 0ull;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (c * 64 < nsel) {                                   // uniform
+                const int r = c * 64 + lane;
+                const bool valid = r < nsel;
+                unsigned long long mw[8];
+#pragma unroll
+                for (int w = c; w < 8; ++w) mw[w] = valid ? s_mask[r * 8 + w] : 0ull;
+                const unsigned dlo = (unsigned)mw[c], dhi = (unsigned)(mw[c] >> 32);
+                unsigned long long rc = removed[c];
+                const int nb = nsel - c * 64 < 64 ? nsel - c * 64 : 64;
+                for (int bq = 0; bq < nb; ++bq) {
+                    const unsigned long long d = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, bq) << 32) |
+                                                 (unsigned long long)(unsigned)__builtin_amdgcn_readlane(dlo, bq);
+                    if (!((rc >> bq) & 1ull)) rc |= d;
+                }
+                removed[c] = rc;
+                const bool kept = valid && !((rc >> lane) & 1ull);
+#pragma unroll
+                for (int w = c + 1; w < 8; ++w) {
+                    unsigned lo = kept ? (unsigned)mw[w] : 0u, hi = kept ? (unsigned)(mw[w] >> 32) : 0u;
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) {
+                        lo |= __shfl_xor(lo, off);
+                        hi |= __shfl_xor(hi, off);
+                    }
+                    removed[w] |= ((unsigned long long)hi << 32) | lo;
+                }
+            }
         }
-        if (tid < 8) s_removed[tid] = removed;
+#pragma unroll
+        for (int w = 0; w < 8; ++w)
+            if (lane == w) s_removed[w] = removed[w];
     }
     __syncthreads();
 
