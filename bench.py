@@ -178,10 +178,19 @@ def main():
     stages['decode']['achieved_GBs'] = round(dec_bytes / (dec_ms * 1e-3) / 1e9, 1)
     stages['decode']['frac_hbm_peak'] = round(dec_bytes / (dec_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+    # HBM/fabric bytes per conv launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same
+    # command, corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE x2 for 16-byte-per-lane loads, WRITE_SIZE
+    # exact); measured offline because counters need the profiler, committed under profiles/
+    traffic = None
+    pmc_path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_b32_640.json')
+    if args.batch == 32 and args.size == 640 and os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path)).get('conv_igemm')
+        if pmc:
+            traffic = round(pmc['hbm_read_bytes_per_launch_x2corr'] + pmc['hbm_write_bytes_per_launch'])
 
     total_images = world * args.batch * args.steps
     out = {
-        'metric': 'images/sec at batch 32, 640x640, YOLOv3-80 (backbone -> FPN -> head -> decode -> NMS)',
+        'metric': f'images/sec at batch {args.batch}, {args.size}x{args.size}, YOLOv3-80 (backbone -> FPN -> head -> decode -> NMS)',
         'value': round(total_images / elapsed, 2),
         'unit': 'images/sec',
         'n_gpus': world,
@@ -199,7 +208,9 @@ def main():
                    'exchange': 'all-gather of 14 340 B detection records' if world > 1 else 'none'},
         'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel (v_mfma_f32_32x32x2_f32)',
                      'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                     'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
+                     'traffic_unit': 'bytes per launch (PMC, profiles/r01_pmc_traffic_b32_640.json)',
+                     'algorithmic_bytes_per_launch': 364300000,
                      'launches_per_step': n_conv / args.steps,
                      'avg_launch_ms': round(conv_ms / n_conv, 4),
                      'algorithmic_gflop_per_launch': round(conv_flops / n_conv / 1e9, 3)},
