@@ -88,7 +88,8 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    rehearse = world == 1 and 'RANK' in os.environ and os.environ.get('MYDET_REHEARSE_RCCL') == '1'
+    if world > 1 or rehearse:      # (rehearse: one-rank RCCL group, exercises the collective path on a 1-GPU box)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=dev)          # nccl == RCCL on ROCm
@@ -116,14 +117,14 @@ def main():
 
     def step():
         if graphed is not None:
-            return parallel.gather_detections(graphed())
+            return parallel.gather_detections(graphed(), always=rehearse)
         with torch.no_grad():
             bb, ci, sc = model.forward_candidates(x)
             rec = batched_post_process(bb, ci, sc, conf, nms)
-            return parallel.gather_detections(rec)
+            return parallel.gather_detections(rec, always=rehearse)
 
     def barrier():
-        if world > 1:
+        if world > 1 or rehearse:
             torch.distributed.barrier()
 
     for _ in range(args.warmup):
@@ -150,7 +151,7 @@ def main():
         torch.cuda.synchronize()
         timer, ops.TIMER = ops.TIMER, None
 
-    if world > 1:
+    if world > 1 or rehearse:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -222,7 +223,7 @@ def main():
         out['cpu_baseline']['gpu_over_cpu'] = round(out['value'] / out['cpu_baseline']['value'], 1)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or rehearse:
         torch.distributed.destroy_process_group()
 
 

@@ -54,6 +54,9 @@ def lib():
     """Load (once) and return the bound library; raise MissingHipLibrary if it was not built."""
     global _lib
     if _lib is None:
+        # PyTorch-ROCm ships its own libamdhip64; it must be in the process BEFORE this library is loaded so that
+        # both resolve to ONE HIP runtime (otherwise launches here hit a runtime with no device: hipError 100).
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise MissingHipLibrary(
                 f'{LIB_PATH} not found. mydetection_amd has no CPU/PyTorch fallback: build the gfx950 '

@@ -44,9 +44,12 @@ def unpack_records(buf):
     return {'count': buf[:, 0].contiguous(), 'bbox': bbox, 'class_idx': cls, 'score': score, 'index': index}
 
 
-def gather_detections(rec, group=None):
-    """All ranks end up with the records of the whole batch in rank order (equal shard sizes)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+def gather_detections(rec, group=None, always=False):
+    """All ranks end up with the records of the whole batch in rank order (equal shard sizes).
+    `always` runs the collective even for a one-rank group (used to rehearse the RCCL path on one GPU)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return rec
+    if dist.get_world_size(group) == 1 and not always:
         return rec
     buf = pack_records(rec)
     world = dist.get_world_size(group)
