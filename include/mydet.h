@@ -197,6 +197,13 @@ int mydet_bboxes_iou_f32(const float *a, int Na, const float *b, int Nb, int xyx
 int mydet_bboxes_to_original_f32(float *bbox, int64_t n, float ori_w, float ori_h,
                                  float tl_x, float tl_y, float imw, float imh, void *stream);
 
+/* Device-side image preparation (first stage before the path): uint8 [B,H,W,3] images ->
+ * float32 [B,3,Hp,Wp]: zero-pad right/bottom (utils/image_ops.py:38-52), /255 (tvf.to_tensor,
+ * api/detection.py:160), and, when norm != 0, (x - mean)/std per channel (utils/image_ops.py:177-180).
+ * mean3/std3 are HOST pointers to 3 floats. */
+int mydet_preprocess_u8_f32(const unsigned char *img, int B, int H, int W, float *out, int Hp, int Wp, int norm,
+                            const float *mean3, const float *std3, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

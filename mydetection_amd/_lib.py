@@ -32,6 +32,7 @@ SIGNATURES = {
     'mydet_postprocess_f32': [c_ptr, c_ptr, c_ptr, c_int, c_i64, c_f32, c_f64, c_int, c_ptr, c_ptr, c_ptr, c_ptr,
                               c_ptr, c_ptr, c_ptr],
     'mydet_bboxes_iou_f32': [c_ptr, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr],
+    'mydet_preprocess_u8_f32': [c_ptr, c_int, c_int, c_int, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr],
     'mydet_bboxes_to_original_f32': [c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_ptr],
 }
 

@@ -5,8 +5,11 @@ on the MI355X and only the surviving detections come back to the host.
 """
 import os
 
+import numpy as np
 import PIL.Image
 import torch
+
+from .. import ops
 
 from ..models.general import name_to_model
 from ..utils import image_ops as imgUtils
@@ -94,13 +97,11 @@ class Detector():
         conf_thres = kwargs.get('conf_thres', self.conf_thres)
         nms_thres = kwargs.get('nms_thres', self.nms_thres)
 
-        pil_img, pad_info = self._preprocess_pil(pil_img, pre_proc, input_size)
-        t_img = imgUtils.to_tensor(pil_img)
-        t_img = imgUtils.format_tensor_img(t_img, code=self.model.input_format)
-
-        input_ = t_img.unsqueeze(0)
+        # host: PIL resize only; pad + to_tensor + normalise run in one HIP kernel on the uint8 image
+        pil_img, pad_info, out_hw = self._preprocess_pil(pil_img, pre_proc, input_size, pad_on_device=True)
+        u8 = torch.from_numpy(np.array(pil_img.convert('RGB'), dtype=np.uint8)).cuda()
+        input_ = ops.preprocess_u8(u8, out_hw, self.model.input_format)
         assert input_.dim() == 4
-        input_ = input_.cuda()
         with torch.no_grad():
             dts = self.model(input_)
         assert isinstance(dts, list)
@@ -110,22 +111,62 @@ class Detector():
             dts.bboxes_to_original_(pad_info)
         return dts
 
-    def _preprocess_pil(self, pil_img, pre_proc_name, input_size=None):
+    def _preprocess_pil(self, pil_img, pre_proc_name, input_size=None, pad_on_device=False):
+        """reference: api/detection.py:177-205.  With pad_on_device the right/bottom zero padding of the
+        '*_divisible' modes is left to the device kernel and the padded (H, W) is returned as third value."""
         assert isinstance(pil_img, PIL.Image.Image), 'input must be a PIL.Image'
         assert isinstance(self.divisibe, int)
         ori_h, ori_w = pil_img.height, pil_img.width
+        div = self.divisibe
+
+        def padded(img):
+            return (int(np.ceil(img.height / div) * div), int(np.ceil(img.width / div) * div))
         if pre_proc_name == 'pad_divisible':
-            pil_img = imgUtils.pad_to_divisible(pil_img, self.divisibe)
+            out_hw = padded(pil_img)
+            if not pad_on_device:
+                pil_img = imgUtils.pad_to_divisible(pil_img, div)
             pad_info = None
         elif pre_proc_name == 'resize_pad_divisible':
             assert input_size is not None
             pil_img = imgUtils.resize_pil(pil_img, input_size, shorter=False)
             new_h, new_w = pil_img.height, pil_img.width
-            pil_img = imgUtils.pad_to_divisible(pil_img, self.divisibe)
+            out_hw = padded(pil_img)
+            if not pad_on_device:
+                pil_img = imgUtils.pad_to_divisible(pil_img, div)
             pad_info = (ori_w, ori_h, 0, 0, new_w, new_h)
         elif pre_proc_name == 'resize_pad_square':
             assert input_size is not None
             pil_img, _, pad_info = imgUtils.rect_to_square(pil_img, None, input_size, aug=False)
+            out_hw = (pil_img.height, pil_img.width)
         else:
             raise Exception('Unknown preprocessing name')
-        return pil_img, pad_info
+        return (pil_img, pad_info, out_hw) if pad_on_device else (pil_img, pad_info)
+
+    def predict_batch(self, pil_imgs, **kwargs):
+        """Batched form of detect_one for images that preprocess to the same size (e.g. 'resize_pad_square'):
+        one forward + one batched post-process for the whole list (the reference loops image by image,
+        api/detection.py:67-74).  Returns a list of ImageObjects in the original image coordinates."""
+        from ..parallel import records_to_objects
+        from ..utils.structures import batched_post_process
+        pre_proc = kwargs.get('preprocessing', self.preprocess)
+        input_size = kwargs.get('input_size', self.input_size)
+        conf_thres = kwargs.get('conf_thres', self.conf_thres)
+        nms_thres = kwargs.get('nms_thres', self.nms_thres)
+        u8s, pads, hw = [], [], None
+        for img in pil_imgs:
+            p_img, pad_info, out_hw = self._preprocess_pil(img, pre_proc, input_size, pad_on_device=True)
+            arr = np.array(p_img.convert('RGB'), dtype=np.uint8)
+            assert hw is None or (hw == out_hw and arr.shape == u8s[0].shape), 'images must preprocess to one size'
+            hw = out_hw
+            u8s.append(arr)
+            pads.append(pad_info)
+        u8 = torch.from_numpy(np.stack(u8s)).cuda()
+        x = ops.preprocess_u8(u8, hw, self.model.input_format)
+        with torch.no_grad():
+            bb, ci, sc = self.model.forward_candidates(x)
+            rec = batched_post_process(bb, ci, sc, conf_thres, nms_thres)
+        objs = records_to_objects(rec, img_hw=tuple(hw), bb_format=self.model.bb_format)
+        for o, pad_info in zip(objs, pads):
+            if pad_info is not None:
+                o.bboxes_to_original_(pad_info)
+        return objs

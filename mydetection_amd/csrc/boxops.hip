@@ -69,3 +69,45 @@ extern "C" int mydet_bboxes_to_original_f32(float *bbox, int64_t n, float ori_w,
                        n, ori_w, ori_h, tl_x, tl_y, imw, imh);
     return mydet_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Device-side image preparation: uint8 HWC image(s) -> float32 planar CHW,
+//   zero-pad right/bottom to (Hp, Wp) in the uint8 domain   utils/image_ops.py:38-52 (pad_to_divisible)
+//   x / 255                                                  tvf.to_tensor, api/detection.py:160
+//   (x - mean[c]) / std[c] when norm != 0                    utils/image_ops.py:177-180 ('RGB_1_norm')
+// in exactly that operation order.  One thread per output pixel, the three channels of a pixel together.
+namespace {
+__global__ __launch_bounds__(256) void preprocess_kernel(const unsigned char *img, int H, int W, float *out, int Hp,
+                                                         int Wp, int norm, float m0, float m1, float m2, float s0,
+                                                         float s1, float s2, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % Wp);
+    const int64_t t = i / Wp;
+    const int y = (int)(t % Hp);
+    const int64_t b = t / Hp;
+    float v[3] = {0.f, 0.f, 0.f};
+    if (y < H && x < W) {
+        const unsigned char *p = img + ((b * H + y) * W + x) * 3;
+        v[0] = (float)p[0] / 255.0f; v[1] = (float)p[1] / 255.0f; v[2] = (float)p[2] / 255.0f;
+    }
+    if (norm) {
+        v[0] = (v[0] - m0) / s0; v[1] = (v[1] - m1) / s1; v[2] = (v[2] - m2) / s2;
+    }
+    const int64_t plane = (int64_t)Hp * Wp;
+    float *o = out + b * 3 * plane + (int64_t)y * Wp + x;
+    o[0] = v[0]; o[plane] = v[1]; o[2 * plane] = v[2];
+}
+}  // namespace
+
+extern "C" int mydet_preprocess_u8_f32(const unsigned char *img, int B, int H, int W, float *out, int Hp, int Wp,
+                                       int norm, const float *mean3, const float *std3, void *stream) {
+    if (!img || !out || B <= 0 || H <= 0 || W <= 0 || Hp < H || Wp < W) return MYDET_E_BADARG;
+    if (norm && (!mean3 || !std3)) return MYDET_E_BADARG;
+    const int64_t total = (int64_t)B * Hp * Wp;
+    const float m0 = norm ? mean3[0] : 0.f, m1 = norm ? mean3[1] : 0.f, m2 = norm ? mean3[2] : 0.f;
+    const float s0 = norm ? std3[0] : 1.f, s1 = norm ? std3[1] : 1.f, s2 = norm ? std3[2] : 1.f;
+    hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, img, H,
+                       W, out, Hp, Wp, norm, m0, m1, m2, s0, s1, s2, total);
+    return mydet_launch_status();
+}

@@ -377,3 +377,30 @@ def bboxes_to_original_(bbox, pad_info):
                                                    _stream())
     _lib.check(code, 'mydet_bboxes_to_original_f32')
     return bbox
+
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def preprocess_u8(img_u8, out_hw, input_format):
+    """uint8 [B,H,W,3] (or [H,W,3]) device tensor -> float32 [B,3,Hp,Wp]: zero-pad right/bottom, /255, and for
+    'RGB_1_norm' the ImageNet normalisation -- the tensor the reference builds on the host with tvf.pad +
+    tvf.to_tensor + format_tensor_img (api/detection.py:158-163)."""
+    require_gpu(img_u8, 'preprocess_u8')
+    if img_u8.dim() == 3:
+        img_u8 = img_u8.unsqueeze(0)
+    assert img_u8.dtype == torch.uint8 and img_u8.shape[-1] == 3
+    img_u8 = img_u8.contiguous()
+    B, H, W, _ = img_u8.shape
+    Hp, Wp = out_hw
+    if input_format not in ('RGB_1', 'RGB_1_norm'):
+        raise NotImplementedError()
+    norm = 1 if input_format == 'RGB_1_norm' else 0
+    mean = np.asarray(IMAGENET_MEAN, dtype=np.float32)
+    std = np.asarray(IMAGENET_STD, dtype=np.float32)
+    out = torch.empty((B, 3, Hp, Wp), dtype=torch.float32, device=img_u8.device)
+    code = _lib.lib().mydet_preprocess_u8_f32(_ptr(img_u8), B, H, W, _ptr(out), Hp, Wp, norm,
+                                              ctypes.c_void_p(mean.ctypes.data), ctypes.c_void_p(std.ctypes.data), _stream())
+    _lib.check(code, 'mydet_preprocess_u8_f32')
+    return out

@@ -203,3 +203,31 @@ def test_effdet_family_vs_oracle_640(effdet):
     bad = ((sc - os_.double()).abs() > ATOL + RTOL * os_.double().abs()).sum().item()
     assert bad <= 8, f'{bad} scores differ from the float32 oracle by more than 1e-4'
     assert (ci.cpu() != oc).sum().item() <= bb.shape[1] // 2000 + 2
+
+
+def test_device_preprocess_and_batched_detector(model):
+    """Row 8f: pad + to_tensor + normalise on the device (bit-exact vs the reference's host arithmetic) and the
+    batched Detector.predict_batch == per-image detect_one."""
+    import PIL.Image
+    from mydetection_amd import ops, synth
+    from mydetection_amd.api import Detector
+    from mydetection_amd.utils import image_ops
+    m, cfg = model
+    rng = np.random.Generator(np.random.PCG64(21))
+    u8 = rng.integers(0, 256, size=(2, 37, 53, 3), dtype=np.uint8)
+    for fmt in ('RGB_1', 'RGB_1_norm'):
+        out = ops.preprocess_u8(torch.from_numpy(u8).cuda(), (64, 64), fmt).cpu()
+        for b in range(2):
+            pil = image_ops.pad_to_divisible(PIL.Image.fromarray(u8[b]), 64)          # zero pad (uint8), then
+            ref = image_ops.format_tensor_img(image_ops.to_tensor(pil), fmt)          # /255, normalise
+            assert torch.equal(out[b], ref), fmt
+    det = Detector(model_and_cfg=(m, cfg))
+    imgs = [PIL.Image.fromarray((synth.make_images(1, (240, 320), seed=30 + i)[0].permute(1, 2, 0).numpy() * 255).astype(np.uint8))
+            for i in range(3)]
+    kw = dict(preprocessing='resize_pad_square', input_size=320, conf_thres=0.005)
+    batch = det.predict_batch(imgs, **kw)
+    assert len(batch) == 3
+    for img, d in zip(imgs, batch):
+        one = det.detect_one(pil_img=img, **kw)
+        assert len(one) == len(d) > 0 and d.img_hw == (240, 320)
+        assert torch.equal(one.cats, d.cats) and torch.equal(one.scores, d.scores) and torch.equal(one.bboxes, d.bboxes)
