@@ -53,63 +53,56 @@ struct DecodeArgs {
 // (they re-load the last element) and their LDS stores are diverted to a dump slot behind the tile.
 constexpr int MAXV_B = 2;         // float4 per thread for the box rows when they live in a separate tensor
 
-__device__ __forceinline__ void tile_load(const DecodeArgs &p, const Level &L, int tile, f32x4 (&v)[MAXV],
-                                          f32x4 (&vb)[MAXV_B]) {
+template <int NV, int NVB>
+__device__ __forceinline__ void tile_load(const DecodeArgs &p, const Level &L, int tile, f32x4 (&v)[NV],
+                                          f32x4 (&vb)[NVB ? NVB : 1]) {
     const int64_t pix0 = (int64_t)tile * p.PIX;
     const int npx = (int)(L.npix - pix0 < p.PIX ? L.npix - pix0 : p.PIX);
     const unsigned ncls4 = npx * p.qc, nbox4 = npx * p.qb;
     const float *cls = L.cls + pix0 * L.ldcls, *box = L.box + pix0 * L.ldbox;
 #pragma unroll
-    for (int j = 0; j < MAXV; ++j) {
-        if (256u * j < ncls4) {                                            // uniform
-            unsigned i = threadIdx.x + 256u * j;
-            i = i < ncls4 ? i : ncls4 - 1;
-            const unsigned r = (i * p.mc) >> 20, c4 = i - r * p.qc;
-            v[j] = *reinterpret_cast<const f32x4 *>(cls + (int64_t)r * L.ldcls + c4 * 4);
-        }
+    for (int j = 0; j < NV; ++j) {
+        unsigned i = threadIdx.x + 256u * j;
+        i = i < ncls4 ? i : ncls4 - 1;
+        const unsigned r = (i * p.mc) >> 20, c4 = i - r * p.qc;
+        v[j] = *reinterpret_cast<const f32x4 *>(cls + (int64_t)r * L.ldcls + c4 * 4);
     }
-    if (!p.same) {
 #pragma unroll
-        for (int j = 0; j < MAXV_B; ++j) {
-            if (256u * j < nbox4) {
-                unsigned i = threadIdx.x + 256u * j;
-                i = i < nbox4 ? i : nbox4 - 1;
-                const unsigned r = (i * p.mb) >> 20, c4 = i - r * p.qb;
-                vb[j] = *reinterpret_cast<const f32x4 *>(box + (int64_t)r * L.ldbox + c4 * 4);
-            }
-        }
+    for (int j = 0; j < NVB; ++j) {
+        unsigned i = threadIdx.x + 256u * j;
+        i = i < nbox4 ? i : nbox4 - 1;
+        const unsigned r = (i * p.mb) >> 20, c4 = i - r * p.qb;
+        vb[j] = *reinterpret_cast<const f32x4 *>(box + (int64_t)r * L.ldbox + c4 * 4);
     }
 }
 
 // Registers -> LDS rows of odd length (4 dword writes per float4: the rows are not 16-byte aligned).
-__device__ __forceinline__ void tile_store(const DecodeArgs &p, int npx, const f32x4 (&v)[MAXV],
-                                           const f32x4 (&vb)[MAXV_B], float *sm) {
+template <int NV, int NVB>
+__device__ __forceinline__ void tile_store(const DecodeArgs &p, int npx, const f32x4 (&v)[NV],
+                                           const f32x4 (&vb)[NVB ? NVB : 1], float *sm) {
     const unsigned ncls4 = npx * p.qc, nbox4 = npx * p.qb;
     float *dump = sm + p.PIX * p.row;
 #pragma unroll
-    for (int j = 0; j < MAXV; ++j) {
-        if (256u * j < ncls4) {
-            const unsigned i = threadIdx.x + 256u * j;
-            const unsigned r = (i * p.mc) >> 20, c4 = i - r * p.qc;
-            float *d = i < ncls4 ? sm + r * p.row + c4 * 4 : dump;
-            d[0] = v[j][0]; d[1] = v[j][1]; d[2] = v[j][2]; d[3] = v[j][3];
-        }
+    for (int j = 0; j < NV; ++j) {
+        const unsigned i = threadIdx.x + 256u * j;
+        const unsigned r = (i * p.mc) >> 20, c4 = i - r * p.qc;
+        float *d = i < ncls4 ? sm + r * p.row + c4 * 4 : dump;
+        d[0] = v[j][0]; d[1] = v[j][1]; d[2] = v[j][2]; d[3] = v[j][3];
     }
-    if (!p.same) {
 #pragma unroll
-        for (int j = 0; j < MAXV_B; ++j) {
-            if (256u * j < nbox4) {
-                const unsigned i = threadIdx.x + 256u * j;
-                const unsigned r = (i * p.mb) >> 20, c4 = i - r * p.qb;
-                float *d = i < nbox4 ? sm + r * p.row + p.cls_span + c4 * 4 : dump;
-                d[0] = vb[j][0]; d[1] = vb[j][1]; d[2] = vb[j][2]; d[3] = vb[j][3];
-            }
-        }
+    for (int j = 0; j < NVB; ++j) {
+        const unsigned i = threadIdx.x + 256u * j;
+        const unsigned r = (i * p.mb) >> 20, c4 = i - r * p.qb;
+        float *d = i < nbox4 ? sm + r * p.row + p.cls_span + c4 * 4 : dump;
+        d[0] = vb[j][0]; d[1] = vb[j][1]; d[2] = vb[j][2]; d[3] = vb[j][3];
     }
 }
 
 // grid = (tile slots, levels): blockIdx.y picks the level ONCE (static-index select chain, no dynamic indexing of
 // the kernel arguments), blockIdx.x strides over that level's tiles; surplus workgroups of small levels exit.
+// NV / NVB: float4 staging registers per thread for the class rows / the separate box rows (0 when box == cls);
+// compile-time so the prefetch of a tile is one straight-line run of loads, all in flight together.
+template <int NV, int NVB>
 __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float s_aw[MAX_A], s_ah[MAX_A];
@@ -126,14 +119,15 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs p) {
     const int box_col = p.same ? 0 : p.cls_span;
     const int hw = L.H * L.W;
     const float st = L.stride;
-    f32x4 v[MAXV], vb[MAXV_B];
-    tile_load(p, L, blockIdx.x, v, vb);
+    f32x4 v[NV], vb[NVB ? NVB : 1];
+    tile_load<NV, NVB>(p, L, blockIdx.x, v, vb);
     for (int tile = blockIdx.x; tile < L.ntiles; tile += gridDim.x) {
         const int64_t pix0 = (int64_t)tile * p.PIX;
         const int npx = (int)(L.npix - pix0 < p.PIX ? L.npix - pix0 : p.PIX);
-        tile_store(p, npx, v, vb, sm);
+        tile_store<NV, NVB>(p, npx, v, vb, sm);
         __syncthreads();
-        if (tile + (int)gridDim.x < L.ntiles) tile_load(p, L, tile + gridDim.x, v, vb);  // flies under the compute phase
+        if (tile + (int)gridDim.x < L.ntiles)                  // flies under the compute phase
+            tile_load<NV, NVB>(p, L, tile + gridDim.x, v, vb);
         for (int c = threadIdx.x; c < p.PIX * p.A; c += 256) {
             const int a = c / p.PIX, px = c - a * p.PIX;
             if (px >= npx) continue;
@@ -209,6 +203,13 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs p) {
     }
 }
 
+template <int NV>
+void launch_nvb(int needb, dim3 grid, size_t lds, void *stream, const DecodeArgs &p) {
+    if (needb == 0) hipLaunchKernelGGL((decode_kernel<NV, 0>), grid, dim3(256), lds, (hipStream_t)stream, p);
+    else if (needb == 1) hipLaunchKernelGGL((decode_kernel<NV, 1>), grid, dim3(256), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((decode_kernel<NV, 2>), grid, dim3(256), lds, (hipStream_t)stream, p);
+}
+
 unsigned magic20(unsigned q, unsigned max_i) {       // m with (i * m) >> 20 == i / q for all i <= max_i (checked)
     const unsigned m = (1u << 20) / q + 1;
     for (unsigned i = 0; i <= max_i; ++i)
@@ -244,11 +245,16 @@ extern "C" int mydet_decode_levels_f32(int mode, int nlevels, const mydet_decode
     p.box_span = (box_need + 3) & ~3;
     p.row = (p.cls_span + (p.same ? 0 : p.box_span)) | 1;               // odd row length: conflict-free column walks
     p.qc = p.cls_span >> 2; p.qb = p.box_span >> 2;
-    p.PIX = 32;                                                        // 33 KB tiles for YOLO: 4 workgroups per CU
-    while (p.PIX > 1 && ((size_t)p.PIX * p.row * sizeof(float) > 60 * 1024 || (size_t)p.PIX * p.qc > MAXV * 256 ||
-                         (!p.same && (size_t)p.PIX * p.qb > MAXV_B * 256)))
-        p.PIX >>= 1;
-    if ((size_t)p.PIX * p.qc > MAXV * 256 || (!p.same && (size_t)p.PIX * p.qb > MAXV_B * 256)) return MYDET_E_UNSUPP;
+    // 32-pixel tiles (33 KB for YOLO: 4 workgroups per CU), grown while a tile holds fewer candidates than the
+    // workgroup has threads (single-anchor heads) and still fits the LDS / staging-register budget
+    auto fits = [&](int pix) {
+        return (size_t)pix * p.row * sizeof(float) <= 60 * 1024 && (size_t)pix * p.qc <= MAXV * 256 &&
+               (p.same || (size_t)pix * p.qb <= MAXV_B * 256);
+    };
+    p.PIX = 32;
+    while (p.PIX > 1 && !fits(p.PIX)) p.PIX >>= 1;
+    if (!fits(p.PIX)) return MYDET_E_UNSUPP;
+    while (p.PIX * A < 256 && fits(p.PIX * 2)) p.PIX <<= 1;
     p.mc = magic20(p.qc, p.PIX * p.qc);
     p.mb = magic20(p.qb, p.PIX * p.qb);
     if (!p.mc || !p.mb) return MYDET_E_UNSUPP;
@@ -277,8 +283,24 @@ extern "C" int mydet_decode_levels_f32(int mode, int nlevels, const mydet_decode
     const size_t lds = ((size_t)p.PIX * p.row + 4) * sizeof(float);     // + dump slot for clamped staging lanes
     int max_tiles = 0;
     for (int l = 0; l < nlevels; ++l) max_tiles = p.lv[l].ntiles > max_tiles ? p.lv[l].ntiles : max_tiles;
-    const int gx = max_tiles < 256 * 6 ? max_tiles : 256 * 6;
-    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)gx, (unsigned)nlevels), dim3(256), lds, (hipStream_t)stream, p);
+    // one resident round of workgroups per level (256 CUs x workgroups per CU by LDS / 4 waves per SIMD): the
+    // big level's workgroups then all run concurrently and loop over equal shares of its tiles
+    int per_cu = (int)((160 * 1024) / (lds + 512));
+    per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
+    if (const char *e = getenv("MYDET_DECODE_GX")) per_cu = atoi(e);      // tuning knob
+    const int resident = 256 * per_cu;
+    const int gx = max_tiles < resident ? max_tiles : resident;
+    const int need = (int)(((size_t)p.PIX * p.qc + 255) / 256);
+    const int needb = p.same ? 0 : (int)(((size_t)p.PIX * p.qb + 255) / 256);
+    const dim3 grid((unsigned)gx, (unsigned)nlevels);
+    if (need <= 1) launch_nvb<1>(needb, grid, lds, stream, p);
+    else if (need <= 2) launch_nvb<2>(needb, grid, lds, stream, p);
+    else if (need <= 3) launch_nvb<3>(needb, grid, lds, stream, p);
+    else if (need <= 4) launch_nvb<4>(needb, grid, lds, stream, p);
+    else if (need <= 6) launch_nvb<6>(needb, grid, lds, stream, p);
+    else if (need <= 8) launch_nvb<8>(needb, grid, lds, stream, p);
+    else if (need <= 10) launch_nvb<10>(needb, grid, lds, stream, p);
+    else launch_nvb<12>(needb, grid, lds, stream, p);
     return mydet_launch_status();
 }
 
