@@ -72,6 +72,23 @@ int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *w,
                            int KH, int KW, int stride, int pad_t, int pad_l,
                            int Ho, int Wo, int act, void *stream);
 
+/* The same fused conv + epilogue for KH = KW = 3, stride 1, pad 1 (Ho = H, Wo = W) by Winograd F(2x2,3x3):
+ * 16 transform-domain GEMMs on FP32 MFMA with the input/output transforms fused into staging and epilogue
+ * (2.25x fewer multiplies; float32 throughout, only the association order of the sums differs from the direct
+ * form).  Call sites replaced: the 3x3 ConvBnLeaky of Darknet53 / DarkBlock / YOLOBranch
+ * (models/modules.py:69-73,94-95; models/backbones.py:14-41; models/fpns.py:38-47) and the dense 3x3 convs of
+ * models/backbones.py:183-200, models/rpns.py:155-158.
+ * u: weights in the transform domain, produced once per layer by mydet_wino_weights_f32 from the OHWI weight
+ *    (mydet_wino_weights_floats(Cout, Cin) floats; 0 if the shape is unsupported).
+ * Needs Cin % 8 == 0, Cout % 4 == 0, ldy % 4 == 0 (ldr % 4 == 0), 16-byte aligned pointers; otherwise
+ * MYDET_E_UNSUPP and the caller uses mydet_conv2d_igemm_f32.
+ */
+int64_t mydet_wino_weights_floats(int Cout, int Cin);
+int mydet_wino_weights_f32(const float *w_ohwi, int Cout, int Cin, float *u, void *stream);
+int mydet_conv2d_wino_f32(const float *x, int64_t ldx, const float *u, const float *scale, const float *shift,
+                          const float *residual, int64_t ldr, float *y, int64_t ldy, int B, int H, int W, int Cin,
+                          int Cout, int act, void *stream);
+
 /* First-layer convolution (Cin == 3, 3x3) reading the image with arbitrary strides
  * (NCHW as handed over by api/detection.py:160-166, or channels-last) and writing NHWC.
  * Replaces netlist[0] of Darknet53 (models/backbones.py:14) and the EfficientNet stem.

@@ -16,6 +16,9 @@ SIGNATURES = {
     'mydet_abi_version': [],
     'mydet_conv2d_igemm_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_i64]
     + [c_int] * 13 + [c_ptr],
+    'mydet_wino_weights_floats': [c_int, c_int],
+    'mydet_wino_weights_f32': [c_ptr, c_int, c_int, c_ptr, c_ptr],
+    'mydet_conv2d_wino_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64] + [c_int] * 6 + [c_ptr],
     'mydet_dwconv_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64] + [c_int] * 11 + [c_ptr, c_int, c_ptr],
     'mydet_channel_sums_f32': [c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr, c_int, c_ptr],
     'mydet_se_gate_f32': [c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
@@ -36,6 +39,9 @@ SIGNATURES = {
     'mydet_bboxes_to_original_f32': [c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_ptr],
 }
 
+
+
+RETURNS_I64 = {'mydet_wino_weights_floats'}
 
 
 class DecodeLevel(ctypes.Structure):
@@ -67,7 +73,7 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(handle, name)          # AttributeError here = ABI mismatch, also loud
             fn.argtypes = argtypes
-            fn.restype = c_int
+            fn.restype = c_i64 if name in RETURNS_I64 else c_int
         if handle.mydet_abi_version() != 1:
             raise MissingHipLibrary('libmydet_hip.so ABI version mismatch; rebuild it')
         _lib = handle

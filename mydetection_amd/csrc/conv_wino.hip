@@ -1,0 +1,306 @@
+// 3x3 stride-1 pad-1 convolution by Winograd F(2x2,3x3) on the gfx950 FP32 matrix cores, fully fused:
+// input transform while staging, 16 transform-domain GEMMs on v_mfma_f32_32x32x2_f32, output transform +
+// BN/activation/residual in the epilogue.  2.25x fewer multiplies than the direct form and no transformed tensor
+// ever touches HBM: x is read once per output-channel block, y written once.
+//
+//   tile  = 2x2 output pixels (4x4 input patch d, origin (2ty-1, 2tx-1), zero outside the image)
+//   V     = Bt d B          (adds only; per tile, per input channel)        Bt = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+//   U     = G g Gt          (once per weight, mydet_wino_weights_f32)        G  = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+//   M_p   = sum_c U_p[n][c] * V_p[c][tile]      for the 16 positions p = 4i+j -- the MFMA part
+//   Y     = At M A          (per tile, per output channel)                  At = [1 1 1 0; 0 1 -1 -1]
+//   y     = act(Y*scale[n] + shift[n]) + residual
+//
+// A 256-thread workgroup owns 32 tiles x 64 output channels; each of its 4 waves 16 channels x 32 tiles for ALL 16
+// positions as 16x16 v_mfma_f32_16x16x4_f32 blocks (16 positions x 2 tile blocks x 4 = 128 accumulator registers),
+// so two workgroups share a CU and one's staging / epilogue hides under the other's MFMAs.  K = Cin is walked 8
+// channels at a time through one 48 KB LDS slab laid out in MFMA-fragment order: [position pair][k quarter][row]
+// float4 = {pos 2p, 2p+1 at k; pos 2p, 2p+1 at k+1}, so one ds_read_b128 feeds two positions, every fragment read
+// is a linear run of 16-byte lanes (no padding, no conflicts) and so is every staging write.
+// Every thread stages one channel of one tile's patch (16 dword buffer loads, transform in registers, 8 LDS
+// stores) and 8 float4 of weights (straight through): the next slab's loads are issued before the 64 MFMAs of
+// the current one and land in LDS between two barriers.  Out-of-image patch pixels use voffset 0xFFFFFFFF
+// (hardware range check returns 0); the K advance rides in the scalar offset.
+// Output channels are MFMA rows, so a lane ends up with 4 consecutive channels of a pixel: 16-byte stores.
+//
+// Replaces the same ATen chain as conv_igemm.hip for the 3x3 layers of ConvBnLeaky / DarkBlock
+// (models/modules.py:69-73,94-95) and the dense 3x3 convs of models/backbones.py:183-200, models/rpns.py:155-158.
+// float32 throughout; versus the direct form only the association order of the sums differs.
+#include "common.h"
+
+namespace {
+
+constexpr unsigned OOB = 0xFFFFFFFFu;
+constexpr int TILES = 32, CH = 64;                     // workgroup tile: 2x2-output tiles x output channels
+constexpr int U_BYTES = 8 * 4 * CH * 16;              // one 8-channel slab of U (32 KB) ...
+constexpr int V_KS = TILES * 16 + 128;                 // V: bytes between k quarters (+128: spreads the staging stores
+constexpr int V_PS = 4 * V_KS;                         //    of a wave over the banks), between position pairs
+constexpr int V_BYTES = 8 * V_PS;                      // ... and of V (20 KB)
+constexpr int LDS_BYTES = U_BYTES + V_BYTES;
+
+struct WinoArgs {
+    const float *x, *u, *scale, *shift, *res;
+    float *y;
+    int64_t ldx, ldr, ldy;
+    int B, H, W, Cin, Cout, CoutP;
+    int TH, TW, MT, ntn, nblk;
+};
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *base, int64_t bytes) {
+    const uint64_t a = (uint64_t)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const int64_t capped = bytes > 0x7FFFFFF0ll ? 0x7FFFFFF0ll : bytes;
+    const int n = __builtin_amdgcn_readfirstlane((int)capped);
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, n, 0x00020000);
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int ACT, bool RES>
+__global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lid = mydet_xcd_remap(blockIdx.x, p.nblk);
+    const int m0 = (lid / p.ntn) * TILES, n0 = (lid % p.ntn) * CH;
+    const int tpi = p.TH * p.TW;                       // tiles per image
+    const int b0 = m0 / tpi;
+
+    // ---- staging: every thread brings one channel of one tile's patch (16 dwords) and 8 float4 of weights
+    const int64_t img = (int64_t)p.H * p.W * p.ldx;
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x + b0 * img, (p.B - b0) * img * 4);
+    const __amdgpu_buffer_rsrc_t ur = make_rsrc(p.u, (int64_t)p.Cin * 16 * p.CoutP * 4);
+    // a wave covers 8 tiles x the 8 channels of the slab: one 32-byte run per patch pixel and load instruction
+    const int slot = wave * 8 + (lane >> 3), kc = lane & 7;
+    unsigned off[16];
+    {
+        const int mt = m0 + slot;
+        const int mm = mt < p.MT ? mt : p.MT - 1;
+        const int b = mm / tpi, r = mm - b * tpi, ty = r / p.TW, tx = r - ty * p.TW;
+        const int iy0 = 2 * ty - 1, ix0 = 2 * tx - 1;
+        const int base = (int)(((((int64_t)(b - b0) * p.H + iy0) * p.W + ix0) * p.ldx + kc) * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = mt < p.MT && (unsigned)(iy0 + i) < (unsigned)p.H && (unsigned)(ix0 + j) < (unsigned)p.W;
+                off[i * 4 + j] = ok ? (unsigned)(base + (int)(((int64_t)i * p.W + j) * p.ldx * 4)) : OOB;
+            }
+    }
+    // V slab element (pair, quarter = kc/2, tile): this thread owns components {2s, 2s+1}, s = kc & 1
+    const unsigned wr_v = U_BYTES + (unsigned)((kc >> 1) * V_KS + slot * 16 + (kc & 1) * 8);
+    // U slab float4 q*256 + tid (q = position pair): global and LDS order coincide
+    const unsigned uoff = (unsigned)(((tid >> 6) * p.CoutP + n0 + (tid & 63)) * 16);
+    const unsigned ustep = __builtin_amdgcn_readfirstlane(64u * (unsigned)p.CoutP);   // bytes between position pairs
+    const unsigned wr_u = (unsigned)tid * 16u;
+
+    // ---- compute role: wave w owns channels 16w..16w+15 and all 32 tiles (two 16x16 blocks)
+    const int fr = lane & 15, fq = lane >> 4;
+    const unsigned rd_u = (unsigned)(fq * CH + wave * 16 + fr) * 16u;        // + position pair * 4*CH*16
+    const unsigned rd_v = U_BYTES + (unsigned)(fq * V_KS + fr * 16);         // + pair * V_PS, + 256 for block 1
+
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) acc[q][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float gv[16];
+    f32x4 gu[8];
+    auto load_slab = [&](int kt) {
+        const unsigned sv = (unsigned)kt * 32u, su = (unsigned)kt * ustep * 8u;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            gv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off[q], sv, 0));
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            gu[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, uoff, su + q * ustep, 0));
+    };
+    auto store_slab = [&]() {
+        float t[16];                                   // V = Bt d B (rows, then columns) of this thread's channel
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[j] = gv[j] - gv[8 + j]; t[4 + j] = gv[4 + j] + gv[8 + j];
+            t[8 + j] = gv[8 + j] - gv[4 + j]; t[12 + j] = gv[4 + j] - gv[12 + j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float t0 = t[4 * i], t1 = t[4 * i + 1], t2 = t[4 * i + 2], t3 = t[4 * i + 3];
+            *reinterpret_cast<f32x2 *>(smem + wr_v + (2 * i) * V_PS) = f32x2{t0 - t2, t1 + t2};
+            *reinterpret_cast<f32x2 *>(smem + wr_v + (2 * i + 1) * V_PS) = f32x2{t2 - t1, t1 - t3};
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) *reinterpret_cast<f32x4 *>(smem + wr_u + q * 4096) = gu[q];
+    };
+
+    const int nk = p.Cin >> 3;
+    load_slab(0);
+    store_slab();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        load_slab(kt + 1 < nk ? kt + 1 : kt);          // past the end: re-load the last slab, never consumed
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) {
+            const f32x4 ua = *reinterpret_cast<const f32x4 *>(smem + rd_u + pp * (4 * CH * 16));
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(smem + rd_v + pp * V_PS);
+            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(smem + rd_v + pp * V_PS + 256);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    acc[2 * pp + e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[2 * s + e], v0[2 * s + e], acc[2 * pp + e][0], 0, 0, 0);
+                    acc[2 * pp + e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[2 * s + e], v1[2 * s + e], acc[2 * pp + e][1], 0, 0, 0);
+                }
+        }
+        __syncthreads();                               // every wave is done with the slab
+        if (kt + 1 < nk) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(gv[q]));  // pins the transform below the MFMAs
+            store_slab();
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane = tile fr (+16 for block 1), its 4 accumulator components = channels n0+16w+4fq+(0..3)
+    const int n = n0 + wave * 16 + fq * 4;
+    const bool nok = n < p.Cout;                       // Cout % 4 == 0: the four channels stand or fall together
+    const int nc = nok ? n : 0;
+    const f32x4 scl = p.scale ? *reinterpret_cast<const f32x4 *>(p.scale + nc) : f32x4{1.f, 1.f, 1.f, 1.f};
+    const f32x4 sft = p.shift ? *reinterpret_cast<const f32x4 *>(p.shift + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t oimg = (int64_t)p.H * p.W;
+    const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y + b0 * oimg * p.ldy, (p.B - b0) * oimg * p.ldy * 4);
+    const __amdgpu_buffer_rsrc_t rr =
+        make_rsrc(RES ? p.res + b0 * oimg * p.ldr : p.y, (p.B - b0) * oimg * (RES ? p.ldr : p.ldy) * 4);
+    unsigned yo[2][4];                                 // byte offsets of the 2 x 4 output pixels (OOB when masked)
+    f32x4 rv[2][4];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const int mt = m0 + blk * 16 + fr;
+        const bool tok = mt < p.MT && nok;
+        const int mm = mt < p.MT ? mt : p.MT - 1;
+        const int b = mm / tpi, r = mm - b * tpi, ty = r / p.TW, tx = r - ty * p.TW;
+        const int oy = 2 * ty, ox = 2 * tx;
+        const int64_t pix = ((int64_t)(b - b0) * p.H + oy) * p.W + ox;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int a = o >> 1, c = o & 1;
+            const bool ok = tok && oy + a < p.H && ox + c < p.W;
+            const int64_t px = pix + (int64_t)a * p.W + c;
+            yo[blk][o] = ok ? (unsigned)((px * p.ldy + n) * 4) : OOB;
+            if (RES)                                   // all residual loads in flight before the first store
+                rv[blk][o] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                           rr, ok ? (unsigned)((px * p.ldr + n) * 4) : OOB, 0, 0));
+        }
+    }
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        f32x4 s0[4], s1[4];                            // At M: rows (m0+m1+m2), (m1-m2-m3) per column j
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s0[j] = acc[j][blk] + acc[4 + j][blk] + acc[8 + j][blk];
+            s1[j] = acc[4 + j][blk] - acc[8 + j][blk] - acc[12 + j][blk];
+        }
+        f32x4 out[4];
+        out[0] = s0[0] + s0[1] + s0[2];
+        out[1] = s0[1] - s0[2] - s0[3];
+        out[2] = s1[0] + s1[1] + s1[2];
+        out[3] = s1[1] - s1[2] - s1[3];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            f32x4 v = out[o] * scl + sft;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (ACT == MYDET_ACT_LEAKY) v[e] = v[e] > 0.0f ? v[e] : v[e] * 0.1f;
+                if (ACT == MYDET_ACT_SWISH) v[e] = v[e] * mydet_sigmoid(v[e]);
+            }
+            if (RES) v += rv[blk][o];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, yo[blk][o], 0, 0);
+        }
+    }
+}
+
+// U = G g Gt in float64, rounded once; layout [Cin/8][8 position pairs][4 k quarters][CoutP][4] with the float4 =
+// {pos 2p, 2p+1 at k; pos 2p, 2p+1 at k+1}, k = 2*quarter (CoutP = Cout rounded up to 64, zero rows): exactly the LDS slab,
+// so a workgroup's share of a slab is 32 contiguous runs of 64 float4.
+__global__ void wino_weights_kernel(const float *w, int Cout, int Cin, int CoutP, float *u) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)CoutP * Cin) return;
+    const int n = (int)(i / Cin), c = (int)(i - (int64_t)n * Cin);
+    double g[3][3], t[4][3];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) g[a][b] = n < Cout ? (double)w[(((int64_t)n * 3 + a) * 3 + b) * Cin + c] : 0.0;
+    for (int b = 0; b < 3; ++b) {
+        t[0][b] = g[0][b];
+        t[1][b] = 0.5 * (g[0][b] + g[1][b] + g[2][b]);
+        t[2][b] = 0.5 * (g[0][b] - g[1][b] + g[2][b]);
+        t[3][b] = g[2][b];
+    }
+    const int kc = c >> 3, kq = (c >> 1) & 3, ks = c & 1;
+    for (int a = 0; a < 4; ++a) {
+        const double r[4] = {t[a][0], 0.5 * (t[a][0] + t[a][1] + t[a][2]), 0.5 * (t[a][0] - t[a][1] + t[a][2]), t[a][2]};
+        for (int b = 0; b < 4; ++b) {
+            const int q = a * 4 + b;
+            u[((((int64_t)kc * 8 + (q >> 1)) * 4 + kq) * CoutP + n) * 4 + ks * 2 + (q & 1)] = (float)r[b];
+        }
+    }
+}
+
+template <int ACT, bool RES>
+int launch_inst(const WinoArgs &a, hipStream_t stream) {
+    auto kern = &conv_wino_kernel<ACT, RES>;
+    hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(256), LDS_BYTES, stream, a);
+    return mydet_launch_status();
+}
+
+}  // namespace
+
+extern "C" int64_t mydet_wino_weights_floats(int Cout, int Cin) {
+    if (Cout <= 0 || Cin <= 0 || (Cin & 7)) return 0;
+    return (int64_t)16 * Cin * ((Cout + 63) / 64 * 64);
+}
+
+extern "C" int mydet_wino_weights_f32(const float *w, int Cout, int Cin, float *u, void *stream) {
+    if (!w || !u || Cout <= 0 || Cin <= 0) return MYDET_E_BADARG;
+    if (Cin & 7) return MYDET_E_UNSUPP;
+    const int CoutP = (Cout + 63) / 64 * 64;
+    const int64_t n = (int64_t)CoutP * Cin;
+    hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       Cout, Cin, CoutP, u);
+    return mydet_launch_status();
+}
+
+extern "C" int mydet_conv2d_wino_f32(const float *x, int64_t ldx, const float *u, const float *scale,
+                                     const float *shift, const float *residual, int64_t ldr, float *y, int64_t ldy,
+                                     int B, int H, int W, int Cin, int Cout, int act, void *stream) {
+    if (!x || !u || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || act < 0 || act > 2)
+        return MYDET_E_BADARG;
+    if ((ldx & 3) || ldx < Cin || ldy < Cout || (residual && ldr < Cout)) return MYDET_E_BADARG;
+    if (((uintptr_t)x & 15) || ((uintptr_t)u & 15) || ((uintptr_t)y & 15) || (residual && ((uintptr_t)residual & 15)) ||
+        (scale && ((uintptr_t)scale & 15)) || (shift && ((uintptr_t)shift & 15)))
+        return MYDET_E_BADARG;
+    if ((Cin & 7) || (Cout & 3) || (ldy & 3) || (residual && (ldr & 3))) return MYDET_E_UNSUPP;
+    WinoArgs a;
+    a.x = x; a.u = u; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+    a.ldx = ldx; a.ldr = residual ? ldr : ldy; a.ldy = ldy;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.CoutP = (Cout + 63) / 64 * 64;
+    a.TH = (H + 1) / 2; a.TW = (W + 1) / 2;
+    const int64_t MT = (int64_t)B * a.TH * a.TW;
+    if (MT > (int64_t)1 << 30) return MYDET_E_UNSUPP;
+    // 32-bit byte offsets inside a workgroup's window: the images its 32 tiles touch
+    const int64_t span = TILES / ((int64_t)a.TH * a.TW) + 2;
+    const int64_t ldmax = ldx > ldy ? (ldx > a.ldr ? ldx : a.ldr) : (ldy > a.ldr ? ldy : a.ldr);
+    if ((int64_t)H * W * ldmax * 4 * span >= 0x7FFFFFF0ll || (int64_t)16 * Cin * a.CoutP * 4 >= 0x7FFFFFF0ll)
+        return MYDET_E_UNSUPP;
+    a.MT = (int)MT;
+    a.ntn = a.CoutP / CH;
+    a.nblk = (int)((MT + TILES - 1) / TILES) * a.ntn;
+    hipStream_t s = (hipStream_t)stream;
+    const bool res = residual != nullptr;
+    switch (act) {
+        case MYDET_ACT_LEAKY: return res ? launch_inst<MYDET_ACT_LEAKY, true>(a, s) : launch_inst<MYDET_ACT_LEAKY, false>(a, s);
+        case MYDET_ACT_SWISH: return res ? launch_inst<MYDET_ACT_SWISH, true>(a, s) : launch_inst<MYDET_ACT_SWISH, false>(a, s);
+        default: return res ? launch_inst<MYDET_ACT_NONE, true>(a, s) : launch_inst<MYDET_ACT_NONE, false>(a, s);
+    }
+}

@@ -7,6 +7,7 @@ Every function launches hand-written HIP kernels; no arithmetic falls back to AT
 input in a foreign layout is re-laid out with one tensor copy before the launch).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -107,9 +108,30 @@ def conv_out_size(n, k, stride, pad_lo, pad_hi):
     return (n + pad_lo + pad_hi - k) // stride + 1
 
 
-def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None, out_ld=None, gate=None):
+# MYDET_CONV_WINO=0 keeps every 3x3 layer on the direct implicit-GEMM kernel (A/B measurements)
+WINOGRAD = os.environ.get('MYDET_CONV_WINO', '1') != '0'
+
+
+def wino_weights(w_ohwi):
+    """Transform-domain copy of a 3x3 OHWI weight for `conv2d(..., wino=)`, or None when the shape is not covered
+    (Cin % 8, Cout % 4) -- the layer then stays on the direct kernel."""
+    require_gpu(w_ohwi, 'wino_weights')
+    Cout, kh, kw, Cin = w_ohwi.shape
+    if kh != 3 or kw != 3 or Cout % 4:
+        return None
+    n = _lib.lib().mydet_wino_weights_floats(Cout, Cin)
+    if n <= 0:
+        return None
+    u = torch.empty(n, dtype=torch.float32, device=w_ohwi.device)
+    w = w_ohwi.contiguous()
+    _lib.check(_lib.lib().mydet_wino_weights_f32(_ptr(w), Cout, Cin, _ptr(u), _stream()), 'mydet_wino_weights_f32')
+    return u
+
+
+def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None, out_ld=None, gate=None, wino=None):
     """y = act(conv(x * gate)*scale + shift) + residual.  x logical [B,Cin,H,W]; pad=(top,left,bottom,right);
-    gate: optional [B,Cin] per-image channel multipliers (squeeze-excite), 1x1 convs only."""
+    gate: optional [B,Cin] per-image channel multipliers (squeeze-excite), 1x1 convs only;
+    wino: optional `wino_weights(w_ohwi)`: 3x3 stride-1 pad-1 layers then run the fused Winograd kernel."""
     require_gpu(x, 'conv2d')
     x, ldx = to_nhwc(x)
     B, Cin, H, W = x.shape
@@ -125,6 +147,16 @@ def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None
     if residual is not None:
         residual, ldr = to_nhwc(residual)
         assert residual.shape == out.shape
+    if (wino is not None and WINOGRAD and gate is None and k == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1)
+            and ldy % 4 == 0 and ldr % 4 == 0):
+        t0 = TIMER.start() if TIMER else None
+        code = _lib.lib().mydet_conv2d_wino_f32(_ptr(x), ldx, _ptr(wino), _ptr(scale), _ptr(shift), _ptr(residual), ldr,
+                                                _ptr(out), ldy, B, H, W, Cin, Cout, act, _stream())
+        if t0:      # priced with the direct form's flops: the algorithmic work of the layer
+            name = f'conv_wino {Cin}->{Cout} k3s1 {H}x{W}' if TIMER_DETAIL else 'conv_wino'
+            TIMER.stop(name, t0, 2.0 * B * Ho * Wo * Cout * 9 * Cin)
+        _lib.check(code, 'mydet_conv2d_wino_f32')
+        return out
     ws = conv_workspace(x.device)
     t0 = TIMER.start() if TIMER else None
     code = _lib.lib().mydet_conv2d_igemm_f32(

@@ -16,7 +16,7 @@ def dev():
     return torch.device('cuda:0')
 
 
-def _conv_case(dev, B, Cin, Cout, k, s, H, W, act, residual=False, bias_only=False, pad=None, seed=0):
+def _conv_case(dev, B, Cin, Cout, k, s, H, W, act, residual=False, bias_only=False, pad=None, seed=0, wino=False):
     from mydetection_amd import ops
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, Cin, H, W, generator=g)
@@ -35,9 +35,14 @@ def _conv_case(dev, B, Cin, Cout, k, s, H, W, act, residual=False, bias_only=Fal
     if residual:
         res = torch.randn(ref.shape, generator=g)
         ref = ref + res.double()
-    y = ops.conv2d(x.to(dev).contiguous(memory_format=torch.channels_last), w.permute(0, 2, 3, 1).contiguous().to(dev),
+    w_dev = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    u = None
+    if wino:
+        u = ops.wino_weights(w_dev)
+        assert u is not None and ops.WINOGRAD
+    y = ops.conv2d(x.to(dev).contiguous(memory_format=torch.channels_last), w_dev,
                    scale.to(dev) if scale is not None else None, shift.to(dev), k, s, pad, act,
-                   residual=res.to(dev).contiguous(memory_format=torch.channels_last) if residual else None)
+                   residual=res.to(dev).contiguous(memory_format=torch.channels_last) if residual else None, wino=u)
     assert tuple(y.shape) == tuple(ref.shape)
     err = (y.cpu().double() - ref).abs().max().item()
     tol = 2e-5 * max(1.0, ref.abs().max().item())
@@ -59,6 +64,28 @@ def _conv_case(dev, B, Cin, Cout, k, s, H, W, act, residual=False, bias_only=Fal
 ])
 def test_conv_igemm_vs_fp64(dev, case):
     _conv_case(dev, **case)
+
+
+@pytest.mark.parametrize('case', [
+    dict(B=1, Cin=32, Cout=64, H=16, W=16, act=1, residual=True),      # DarkBlock 3x3 + residual, one workgroup row
+    dict(B=2, Cin=128, Cout=256, H=20, W=20, act=1, residual=True),    # 4 channel blocks, tiles straddle images
+    dict(B=4, Cin=512, Cout=1024, H=10, W=10, act=1),                  # deep K: 64 slabs
+    dict(B=3, Cin=64, Cout=128, H=13, W=11, act=1),                    # odd H and W: half-empty edge tiles
+    dict(B=1, Cin=88, Cout=88, H=10, W=10, act=0, bias_only=True),     # Cout % 64 != 0 (zero-padded U rows)
+    dict(B=2, Cin=88, Cout=84, H=5, W=5, act=2),                       # ragged everything, swish
+    dict(B=32, Cin=64, Cout=128, H=40, W=40, act=1, residual=True),    # big grid (XCD remap path)
+])
+def test_conv_winograd_vs_fp64(dev, case):
+    """Fused Winograd F(2x2,3x3) kernel (3x3, stride 1, pad 1) against the same float64 reference and tolerance
+    as the direct implicit-GEMM kernel."""
+    _conv_case(dev, k=3, s=1, wino=True, **case)
+
+
+def test_conv_winograd_unsupported_shapes_stay_direct(dev):
+    from mydetection_amd import ops
+    assert ops.wino_weights(torch.zeros(64, 3, 3, 12, device=dev)) is None     # Cin % 8
+    assert ops.wino_weights(torch.zeros(255, 3, 3, 64, device=dev)) is None    # Cout % 4
+    assert ops.wino_weights(torch.zeros(64, 1, 1, 64, device=dev)) is None     # not 3x3
 
 
 def test_conv_igemm_output_slice_and_padded_ld(dev):
