@@ -49,6 +49,17 @@ def prepare_conv(owner, slot, conv, bn, depthwise=False):
     return hit[1]
 
 
+def prepare_wino(owner, slot, w_ohwi):
+    """Transform-domain copy of a prepared 3x3 OHWI weight (ops.wino_weights), or None when the fused Winograd
+    kernel does not cover the shape.  Cached on `owner` next to the weight it was made from."""
+    cache = owner.__dict__.setdefault('_prep_cache', {})
+    hit = cache.get(slot)
+    if hit is None or hit[0] is not w_ohwi:
+        hit = (w_ohwi, ops.wino_weights(w_ohwi) if ops.WINOGRAD else None)
+        cache[slot] = hit
+    return hit[1]
+
+
 class FusedConvMixin:
     """Caches kernel-ready parameters (OHWI weights, per-channel scale/shift)."""
 
@@ -76,7 +87,8 @@ class ConvBnLeaky(nn.Module, FusedConvMixin):
         p = (self.k - 1) // 2
         if w.shape[3] == 3 and self.k == 3 and w.shape[0] == 32 and residual is None:
             return ops.conv2d_stem(x, w, scale, shift, self.s, (p, p, p, p), ops.ACT_LEAKY)
-        return ops.conv2d(x, w, scale, shift, self.k, self.s, (p, p, p, p), ops.ACT_LEAKY, residual=residual)
+        u = prepare_wino(self, 'wino', w) if self.k == 3 and self.s == 1 else None
+        return ops.conv2d(x, w, scale, shift, self.k, self.s, (p, p, p, p), ops.ACT_LEAKY, residual=residual, wino=u)
 
 
 class DarkBlock(nn.Module):
