@@ -10,9 +10,10 @@ Workload = BASELINE.json configs[1] (yolov3_80, batch 32 per GPU, 640x640, synth
 Metric: images/sec over all GPUs (weak scaling: 32 images per GPU).
 
 The JSON line also carries
-  roofline     -- the dominant kernel (implicit-GEMM conv on FP32 MFMA): algorithmic FLOPs of its
-                  launches / their HIP-event durations measured inside the timed region, against
-                  the 157.3 TFLOP/s FP32 matrix peak (MI355X_MICROARCH.md)
+  roofline     -- the dominant kernel (the conv family with the most time per step: fused Winograd or
+                  implicit GEMM, both on FP32 MFMA): algorithmic FLOPs of its launches / their HIP-event
+                  durations measured inside the timed region, against the 157.3 TFLOP/s FP32 matrix
+                  peak (MI355X_MICROARCH.md); `mfma_frac` = multiplies actually issued / peak
   cpu_baseline -- the CPU oracle (port of the reference path) timed on this host's cores on a
                   bounded sample (rank 0, N=1 only)
   stages       -- per-kernel-family time per step, incl. the NMS launch (latency-bound; p50 reported)
@@ -170,7 +171,6 @@ def main():
         if world > 1:
             torch.distributed.destroy_process_group()
         return
-    n_conv, conv_ms, conv_flops = summ['conv_igemm']
     stages = {k: {'launches_per_step': v[0] / args.steps, 'ms_per_step': round(v[1] / args.steps, 4)} for k, v in summ.items()}
     pp_spans = [a.elapsed_time(b) for a, b, _ in timer.spans['postprocess']]
     stages['postprocess']['p50_ms'] = round(statistics.median(pp_spans), 4)
@@ -178,16 +178,28 @@ def main():
     dec_ms, dec_bytes = summ['decode'][1], summ['decode'][2]
     stages['decode']['achieved_GBs'] = round(dec_bytes / (dec_ms * 1e-3) / 1e9, 1)
     stages['decode']['frac_hbm_peak'] = round(dec_bytes / (dec_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+    # Dominant kernel = the conv family with the most time per step.  `achieved` prices its launches with the
+    # ALGORITHMIC flops of the layers (2*MACs of the direct form); the Winograd kernel issues 2.25x
+    # fewer multiplies than that, so its matrix-pipe occupancy is reported next to it as `mfma_frac`.
+    kernels = {'conv_igemm': ('conv_igemm_kernel (implicit GEMM, v_mfma_f32_32x32x2_f32)', 1.0),
+               'conv_wino': ('conv_wino_kernel (fused Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32)', 2.25)}
+    fams = {k: summ[k] for k in kernels if k in summ}
+    dom = max(fams, key=lambda k: fams[k][1])
+    n_conv, conv_ms, conv_flops = fams[dom]
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12
-    # HBM/fabric bytes per conv launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same
-    # command, corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE x2 for 16-byte-per-lane loads, WRITE_SIZE
-    # exact); measured offline because counters need the profiler, committed under profiles/
+    for k, (n_k, ms_k, fl_k) in fams.items():
+        stages[k]['algorithmic_TFLOPs'] = round(fl_k / (ms_k * 1e-3) / 1e12, 2)
+        stages[k]['mfma_frac'] = round(fl_k / kernels[k][1] / (ms_k * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
+    # HBM/fabric bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command,
+    # corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE x2 for 16-byte-per-lane loads, WRITE_SIZE exact);
+    # measured offline because counters need the profiler, committed under profiles/
     traffic = None
     pmc_path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_b32_640.json')
     if args.batch == 32 and args.size == 640 and os.path.exists(pmc_path):
-        pmc = json.load(open(pmc_path)).get('conv_igemm')
+        pmc = json.load(open(pmc_path)).get(dom)
         if pmc:
             traffic = round(pmc['hbm_read_bytes_per_launch_x2corr'] + pmc['hbm_write_bytes_per_launch'])
+    alg_bytes = round(timer.bytes.get(dom, 0.0) / n_conv) if n_conv else None
 
     total_images = world * args.batch * args.steps
     out = {
@@ -207,11 +219,15 @@ def main():
                                f'batch {args.batch}/GPU, {args.size}x{args.size}, random-init calibrated weights',
                    'global_batch': world * args.batch, 'image_size': args.size, 'parallelism': f'dp{world}',
                    'exchange': 'all-gather of 14 340 B detection records' if world > 1 else 'none'},
-        'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel (v_mfma_f32_32x32x2_f32)',
+        'roofline': {'bound': 'mfma', 'kernel': kernels[dom][0],
                      'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
+                     'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                     'mfma_frac': round(achieved / kernels[dom][1] / PEAK_FP32_MFMA_TFLOPS, 4),
+                     'note': 'achieved = algorithmic (direct-form) FLOPs / HIP-event time; mfma_frac = multiplies actually '
+                             'issued on the matrix pipe / peak (Winograd issues 1/2.25 of the algorithmic count)',
+                     'traffic': traffic,
                      'traffic_unit': 'bytes per launch (PMC, profiles/r01_pmc_traffic_b32_640.json)',
-                     'algorithmic_bytes_per_launch': 364300000,
+                     'algorithmic_bytes_per_launch': alg_bytes,
                      'launches_per_step': n_conv / args.steps,
                      'avg_launch_ms': round(conv_ms / n_conv, 4),
                      'algorithmic_gflop_per_launch': round(conv_flops / n_conv / 1e9, 3)},

@@ -10,32 +10,32 @@
 //   Y     = At M A          (per tile, per output channel)                  At = [1 1 1 0; 0 1 -1 -1]
 //   y     = act(Y*scale[n] + shift[n]) + residual
 //
-// A 256-thread workgroup owns 32 tiles x 64 output channels; each of its 4 waves 16 channels x 32 tiles for ALL 16
-// positions as 16x16 v_mfma_f32_16x16x4_f32 blocks (16 positions x 2 tile blocks x 4 = 128 accumulator registers),
-// so two workgroups share a CU and one's staging / epilogue hides under the other's MFMAs.  K = Cin is walked 8
-// channels at a time through one 48 KB LDS slab laid out in MFMA-fragment order: [position pair][k quarter][row]
-// float4 = {pos 2p, 2p+1 at k; pos 2p, 2p+1 at k+1}, so one ds_read_b128 feeds two positions, every fragment read
-// is a linear run of 16-byte lanes (no padding, no conflicts) and so is every staging write.
-// Every thread stages one channel of one tile's patch (16 dword buffer loads, transform in registers, 8 LDS
-// stores) and 8 float4 of weights (straight through): the next slab's loads are issued before the 64 MFMAs of
-// the current one and land in LDS between two barriers.  Out-of-image patch pixels use voffset 0xFFFFFFFF
-// (hardware range check returns 0); the K advance rides in the scalar offset.
-// Output channels are MFMA rows, so a lane ends up with 4 consecutive channels of a pixel: 16-byte stores.
+// A wave owns 16 output channels x 32 tiles for ALL 16 positions as 16x16 v_mfma_f32_16x16x4_f32 blocks
+// (16 positions x 2 tile blocks x 4 = 128 accumulator registers, two waves per SIMD); a workgroup of NW waves owns
+// 64 channels x 8*NW tiles (see the two shapes at the kernel).  K = Cin is walked 8 channels at a time through LDS
+// slabs laid out in MFMA-fragment order: [position pair][k quarter][row] float4 = {pos 2p, 2p+1 at k; pos 2p, 2p+1
+// at k+1}, so one ds_read_b128 feeds two positions; the tile column of V is XOR-swizzled with the k quarter so that
+// the fragment reads and the staging stores are both bank-conflict free without padding.
+// Every thread stages one channel of one tile's patch (16 dword buffer loads -- a wave covers 8 tiles x the 8
+// channels of the slab, one 32-byte run per pixel --, transform in registers, 8 LDS stores) and its share of the
+// weights (straight through, global and LDS order coincide): the next slab's loads are issued before the 64 MFMAs
+// of the current one.  Out-of-image patch pixels use voffset 0xFFFFFFFF (hardware range check returns 0); the K
+// advance rides in the scalar offset.  Fragment reads of position pair p+1 are issued under pair p's MFMAs.
+// Output channels are MFMA rows, so a lane ends up with 4 consecutive channels of a pixel: 16-byte stores, and the
+// residual loads of a lane are all in flight before its first store.
 //
 // Replaces the same ATen chain as conv_igemm.hip for the 3x3 layers of ConvBnLeaky / DarkBlock
 // (models/modules.py:69-73,94-95) and the dense 3x3 convs of models/backbones.py:183-200, models/rpns.py:155-158.
 // float32 throughout; versus the direct form only the association order of the sums differs.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
 
 constexpr unsigned OOB = 0xFFFFFFFFu;
-constexpr int TILES = 32, CH = 64;                     // workgroup tile: 2x2-output tiles x output channels
-constexpr int U_BYTES = 8 * 4 * CH * 16;              // one 8-channel slab of U (32 KB) ...
-constexpr int V_KS = TILES * 16 + 128;                 // V: bytes between k quarters (+128: spreads the staging stores
-constexpr int V_PS = 4 * V_KS;                         //    of a wave over the banks), between position pairs
-constexpr int V_BYTES = 8 * V_PS;                      // ... and of V (20 KB)
-constexpr int LDS_BYTES = U_BYTES + V_BYTES;
+constexpr int CH = 64;                                 // output channels per workgroup
+constexpr int U_BYTES = 8 * 4 * CH * 16;              // one 8-channel slab of U (32 KB)
 
 struct WinoArgs {
     const float *x, *u, *scale, *shift, *res;
@@ -58,8 +58,18 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *base, i
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int ACT, bool RES>
-__global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoArgs p) {
+// NW = 4: 32 tiles per workgroup, one LDS slab, two barriers per slab, two workgroups per CU -- short-K layers,
+//         where a workgroup's prologue and epilogue must hide under its neighbour's MFMAs.
+// NW = 8: 64 tiles per workgroup (waves 0-3 / 4-7 take 32 tiles each and share the weights), two LDS slabs, ONE
+//         barrier per slab: the next slab's transform and LDS stores are woven into the second half of the
+//         current slab's MFMAs, so in steady state the matrix pipe only idles across that barrier.
+template <int ACT, bool RES, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_wino_kernel(const WinoArgs p) {
+    constexpr int TILES = 8 * NW;                      // 2x2-output tiles per workgroup
+    constexpr int V_KS = TILES * 16, V_PS = 4 * V_KS;  // V: bytes between k quarters / position pairs
+    constexpr int SLAB = U_BYTES + 8 * V_PS;           // 48 KB (NW = 4) / 64 KB (NW = 8)
+    constexpr int NU = 2048 / (64 * NW);               // float4 of weights each thread stages per slab
+    constexpr bool DB = NW == 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lid = mydet_xcd_remap(blockIdx.x, p.nblk);
@@ -67,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoArgs p) {
     const int tpi = p.TH * p.TW;                       // tiles per image
     const int b0 = m0 / tpi;
 
-    // ---- staging: every thread brings one channel of one tile's patch (16 dwords) and 8 float4 of weights
+    // ---- staging: every thread brings one channel of one tile's patch (16 dwords) and NU float4 of weights
     const int64_t img = (int64_t)p.H * p.W * p.ldx;
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x + b0 * img, (p.B - b0) * img * 4);
     const __amdgpu_buffer_rsrc_t ur = make_rsrc(p.u, (int64_t)p.Cin * 16 * p.CoutP * 4);
@@ -88,17 +98,20 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoArgs p) {
                 off[i * 4 + j] = ok ? (unsigned)(base + (int)(((int64_t)i * p.W + j) * p.ldx * 4)) : OOB;
             }
     }
-    // V slab element (pair, quarter = kc/2, tile): this thread owns components {2s, 2s+1}, s = kc & 1
-    const unsigned wr_v = U_BYTES + (unsigned)((kc >> 1) * V_KS + slot * 16 + (kc & 1) * 8);
-    // U slab float4 q*256 + tid (q = position pair): global and LDS order coincide
+    // V slab element (pair, quarter kq = kc/2, tile): this thread owns components {2s, 2s+1}, s = kc & 1.  The tile
+    // column is XOR-swizzled with 2*kq: the ds_write_b64 lane groups (2 tiles x 8 channels) and the ds_read_b128
+    // lane groups (8 + 8 tiles of two adjacent quarters) then both touch every bank once.
+    const unsigned wr_v = U_BYTES + (unsigned)((kc >> 1) * V_KS + ((slot ^ (kc & 6)) * 16) + (kc & 1) * 8);
+    // U slab float4 q*64*NW + tid: global and LDS order coincide
     const unsigned uoff = (unsigned)(((tid >> 6) * p.CoutP + n0 + (tid & 63)) * 16);
-    const unsigned ustep = __builtin_amdgcn_readfirstlane(64u * (unsigned)p.CoutP);   // bytes between position pairs
+    const unsigned ustep = __builtin_amdgcn_readfirstlane(16u * NW * (unsigned)p.CoutP);   // bytes between q and q+1
     const unsigned wr_u = (unsigned)tid * 16u;
 
-    // ---- compute role: wave w owns channels 16w..16w+15 and all 32 tiles (two 16x16 blocks)
+    // ---- compute role: wave owns channels 16*wc.. and tiles 32*wt..32*wt+31 (two 16x16 blocks)
+    const int wc = wave & 3, wt = wave >> 2;
     const int fr = lane & 15, fq = lane >> 4;
-    const unsigned rd_u = (unsigned)(fq * CH + wave * 16 + fr) * 16u;        // + position pair * 4*CH*16
-    const unsigned rd_v = U_BYTES + (unsigned)(fq * V_KS + fr * 16);         // + pair * V_PS, + 256 for block 1
+    const unsigned rd_u = (unsigned)(fq * CH + wc * 16 + fr) * 16u;                  // + position pair * 4*CH*16
+    const unsigned rd_v = U_BYTES + (unsigned)(fq * V_KS + ((wt * 32 + fr) ^ (2 * fq)) * 16);   // + pair * V_PS, + 256: block 1
 
     f32x4 acc[16][2];
 #pragma unroll
@@ -107,17 +120,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoArgs p) {
         for (int e = 0; e < 2; ++e) acc[q][e] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     float gv[16];
-    f32x4 gu[8];
+    f32x4 gu[NU];
     auto load_slab = [&](int kt) {
-        const unsigned sv = (unsigned)kt * 32u, su = (unsigned)kt * ustep * 8u;
+        const unsigned sv = (unsigned)kt * 32u, su = (unsigned)kt * (512u * (unsigned)p.CoutP);
 #pragma unroll
         for (int q = 0; q < 16; ++q)
             gv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off[q], sv, 0));
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
+        for (int q = 0; q < NU; ++q)
             gu[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, uoff, su + q * ustep, 0));
     };
-    auto store_slab = [&]() {
+    auto store_slab = [&](char *slab) {
         float t[16];                                   // V = Bt d B (rows, then columns) of this thread's channel
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -127,44 +140,63 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float t0 = t[4 * i], t1 = t[4 * i + 1], t2 = t[4 * i + 2], t3 = t[4 * i + 3];
-            *reinterpret_cast<f32x2 *>(smem + wr_v + (2 * i) * V_PS) = f32x2{t0 - t2, t1 + t2};
-            *reinterpret_cast<f32x2 *>(smem + wr_v + (2 * i + 1) * V_PS) = f32x2{t2 - t1, t1 - t3};
+            *reinterpret_cast<f32x2 *>(slab + wr_v + (2 * i) * V_PS) = f32x2{t0 - t2, t1 + t2};
+            *reinterpret_cast<f32x2 *>(slab + wr_v + (2 * i + 1) * V_PS) = f32x2{t2 - t1, t1 - t3};
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) *reinterpret_cast<f32x4 *>(smem + wr_u + q * 4096) = gu[q];
+        for (int q = 0; q < NU; ++q) *reinterpret_cast<f32x4 *>(slab + wr_u + q * (1024 * NW)) = gu[q];
+    };
+    // MFMAs of position pairs [p0, p1) of one slab; the fragments of pair pp+1 are read under pair pp's MFMAs
+    f32x4 fu[2], fv[2][2];
+    auto read_frag = [&](const char *slab, int pp, int st) {
+        fu[st] = *reinterpret_cast<const f32x4 *>(slab + rd_u + pp * (4 * CH * 16));
+        fv[st][0] = *reinterpret_cast<const f32x4 *>(slab + rd_v + pp * V_PS);
+        fv[st][1] = *reinterpret_cast<const f32x4 *>(slab + rd_v + pp * V_PS + 256);
+    };
+    auto mma_pair = [&](int pp, int st) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+                    acc[2 * pp + e][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                        fu[st][2 * s + e], fv[st][blk][2 * s + e], acc[2 * pp + e][blk], 0, 0, 0);
     };
 
     const int nk = p.Cin >> 3;
     load_slab(0);
-    store_slab();
+    store_slab(smem);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
+        const char *cur = smem + (DB ? (kt & 1) * SLAB : 0);
         load_slab(kt + 1 < nk ? kt + 1 : kt);          // past the end: re-load the last slab, never consumed
         __builtin_amdgcn_sched_barrier(0);
+        read_frag(cur, 0, 0);
 #pragma unroll
         for (int pp = 0; pp < 8; ++pp) {
-            const f32x4 ua = *reinterpret_cast<const f32x4 *>(smem + rd_u + pp * (4 * CH * 16));
-            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(smem + rd_v + pp * V_PS);
-            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(smem + rd_v + pp * V_PS + 256);
+            if (pp + 1 < 8) read_frag(cur, pp + 1, (pp + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);         // keeps the reads above this pair's MFMAs
+            if (DB && pp == 4) {                       // the other slab was last read before the previous barrier
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    acc[2 * pp + e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[2 * s + e], v0[2 * s + e], acc[2 * pp + e][0], 0, 0, 0);
-                    acc[2 * pp + e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[2 * s + e], v1[2 * s + e], acc[2 * pp + e][1], 0, 0, 0);
-                }
+                for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(gv[q]));  // pins the transform to this point
+                store_slab(smem + ((kt + 1) & 1) * SLAB);
+            }
+            mma_pair(pp, pp & 1);
         }
         __syncthreads();                               // every wave is done with the slab
-        if (kt + 1 < nk) {
+        if (!DB) {
+            if (kt + 1 < nk) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(gv[q]));  // pins the transform below the MFMAs
-            store_slab();
+                for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(gv[q]));  // pins the transform below the MFMAs
+                store_slab(smem);
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 
-    // ---- epilogue: lane = tile fr (+16 for block 1), its 4 accumulator components = channels n0+16w+4fq+(0..3)
-    const int n = n0 + wave * 16 + fq * 4;
+    // ---- epilogue: lane = tile 32*wt + fr (+16 for block 1), its 4 accumulator components = channels n0+16wc+4fq+(0..3)
+    const int n = n0 + wc * 16 + fq * 4;
     const bool nok = n < p.Cout;                       // Cout % 4 == 0: the four channels stand or fall together
     const int nc = nok ? n : 0;
     const f32x4 scl = p.scale ? *reinterpret_cast<const f32x4 *>(p.scale + nc) : f32x4{1.f, 1.f, 1.f, 1.f};
@@ -177,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoArgs p) {
     f32x4 rv[2][4];
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
-        const int mt = m0 + blk * 16 + fr;
+        const int mt = m0 + wt * 32 + blk * 16 + fr;
         const bool tok = mt < p.MT && nok;
         const int mm = mt < p.MT ? mt : p.MT - 1;
         const int b = mm / tpi, r = mm - b * tpi, ty = r / p.TW, tx = r - ty * p.TW;
@@ -247,11 +279,34 @@ __global__ void wino_weights_kernel(const float *w, int Cout, int Cin, int CoutP
     }
 }
 
+template <int ACT, bool RES, int NW>
+int launch_nw(WinoArgs a, hipStream_t stream) {
+    constexpr int TILES = 8 * NW;
+    constexpr int LDS = (U_BYTES + 8 * 4 * TILES * 16) * (NW == 8 ? 2 : 1);
+    auto kern = &conv_wino_kernel<ACT, RES, NW>;
+    static bool attr_set = false;                  // > 64 KiB of dynamic LDS needs the opt-in once
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    a.nblk = (int)(((int64_t)a.MT + TILES - 1) / TILES) * a.ntn;
+    hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(64 * NW), LDS, stream, a);
+    return mydet_launch_status();
+}
+
+int forced_nw() {
+    static int v = -2;
+    if (v == -2) {
+        const char *e = getenv("MYDET_WINO_NW");     // tuning only: 4 or 8
+        v = e ? atoi(e) : -1;
+    }
+    return v;
+}
+
 template <int ACT, bool RES>
 int launch_inst(const WinoArgs &a, hipStream_t stream) {
-    auto kern = &conv_wino_kernel<ACT, RES>;
-    hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(256), LDS_BYTES, stream, a);
-    return mydet_launch_status();
+    const int nw = forced_nw() > 0 ? forced_nw() : (a.Cin >= 128 ? 8 : 4);
+    return nw == 8 ? launch_nw<ACT, RES, 8>(a, stream) : launch_nw<ACT, RES, 4>(a, stream);
 }
 
 }  // namespace
@@ -288,14 +343,13 @@ extern "C" int mydet_conv2d_wino_f32(const float *x, int64_t ldx, const float *u
     a.TH = (H + 1) / 2; a.TW = (W + 1) / 2;
     const int64_t MT = (int64_t)B * a.TH * a.TW;
     if (MT > (int64_t)1 << 30) return MYDET_E_UNSUPP;
-    // 32-bit byte offsets inside a workgroup's window: the images its 32 tiles touch
-    const int64_t span = TILES / ((int64_t)a.TH * a.TW) + 2;
+    // 32-bit byte offsets inside a workgroup's window: the images its (at most 64) tiles touch
+    const int64_t span = 64 / ((int64_t)a.TH * a.TW) + 2;
     const int64_t ldmax = ldx > ldy ? (ldx > a.ldr ? ldx : a.ldr) : (ldy > a.ldr ? ldy : a.ldr);
     if ((int64_t)H * W * ldmax * 4 * span >= 0x7FFFFFF0ll || (int64_t)16 * Cin * a.CoutP * 4 >= 0x7FFFFFF0ll)
         return MYDET_E_UNSUPP;
     a.MT = (int)MT;
     a.ntn = a.CoutP / CH;
-    a.nblk = (int)((MT + TILES - 1) / TILES) * a.ntn;
     hipStream_t s = (hipStream_t)stream;
     const bool res = residual != nullptr;
     switch (act) {

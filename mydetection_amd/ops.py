@@ -29,16 +29,18 @@ class KernelTimer:
 
     def __init__(self):
         self.spans = {}
+        self.bytes = {}                  # name -> algorithmic bytes (operands read once + result written once)
 
     def start(self):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()                      # torch's current stream == the stream handed to the C ABI
         return ev
 
-    def stop(self, name, start_ev, work=0.0):
+    def stop(self, name, start_ev, work=0.0, nbytes=0.0):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         self.spans.setdefault(name, []).append((start_ev, ev, work))
+        self.bytes[name] = self.bytes.get(name, 0.0) + nbytes
 
     def summary(self):
         """name -> (launches, total_ms, total_work); call after torch.cuda.synchronize()."""
@@ -154,7 +156,8 @@ def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None
                                                 _ptr(out), ldy, B, H, W, Cin, Cout, act, _stream())
         if t0:      # priced with the direct form's flops: the algorithmic work of the layer
             name = f'conv_wino {Cin}->{Cout} k3s1 {H}x{W}' if TIMER_DETAIL else 'conv_wino'
-            TIMER.stop(name, t0, 2.0 * B * Ho * Wo * Cout * 9 * Cin)
+            TIMER.stop(name, t0, 2.0 * B * Ho * Wo * Cout * 9 * Cin,
+                       4.0 * (B * H * W * Cin + B * Ho * Wo * Cout * (2 if residual is not None else 1) + 9 * Cin * Cout))
         _lib.check(code, 'mydet_conv2d_wino_f32')
         return out
     ws = conv_workspace(x.device)
@@ -165,7 +168,8 @@ def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None
         B, H, W, Cin, Cout, k, k, stride, pad[0], pad[1], Ho, Wo, act, _stream())
     if t0:
         name = f'conv_igemm {Cin}->{Cout} k{k}s{stride} {H}x{W}' if TIMER_DETAIL else 'conv_igemm'
-        TIMER.stop(name, t0, 2.0 * B * Ho * Wo * Cout * k * k * Cin)
+        TIMER.stop(name, t0, 2.0 * B * Ho * Wo * Cout * k * k * Cin,
+                   4.0 * (B * H * W * Cin + B * Ho * Wo * Cout * (2 if residual is not None else 1) + k * k * Cin * Cout))
     _lib.check(code, 'mydet_conv2d_igemm_f32')
     return out
 

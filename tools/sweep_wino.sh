@@ -1,7 +1,8 @@
 #!/bin/bash
-# Direct vs Winograd on the 3x3 stride-1 layers of YOLOv3-80 at batch 32, 640x640.
+# Direct vs Winograd (both workgroup shapes) on the 3x3 stride-1 layers of YOLOv3-80 at batch 32, 640x640.
 for cfg in "32 64 320" "64 128 160" "128 256 80" "256 512 40" "512 1024 20"; do
   set -- $cfg
-  python tools/bench_conv.py --cin $1 --cout $2 --hw $3 --res || exit 1
-  python tools/bench_conv.py --cin $1 --cout $2 --hw $3 --res --wino || exit 1
+  [ -n "$SKIP_DIRECT" ] || python tools/bench_conv.py --cin $1 --cout $2 --hw $3 --res || exit 1
+  MYDET_WINO_NW=4 python tools/bench_conv.py --cin $1 --cout $2 --hw $3 --res --wino || exit 1
+  MYDET_WINO_NW=8 python tools/bench_conv.py --cin $1 --cout $2 --hw $3 --res --wino || exit 1
 done
