@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     from mydetection_amd import _lib
     header = open(os.path.join(ROOT, 'include', 'mydet.h')).read()
-    declared = set(re.findall(r'\bint\s+(mydet_\w+)\s*\(', header))
+    declared = set(re.findall(r'\b(?:int|int64_t)\s+(mydet_\w+)\s*\(', header))
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     handle = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
@@ -29,6 +29,8 @@ def test_argument_errors_are_reported_before_launch():
                                       1, 1, 0, null) == -1
     assert lib.mydet_postprocess_f32(null, null, null, 1, 1 << 17, 0.5, 0.5, 512, null, null, null, null, null, null,
                                      null) == -2
+    assert lib.mydet_conv2d_wino_f32(null, 0, null, null, null, null, 0, null, 0, 1, 8, 8, 8, 8, 0, null) == -1
+    assert lib.mydet_wino_weights_floats(64, 12) == 0 and lib.mydet_wino_weights_floats(70, 16) == 16 * 16 * 128
     with pytest.raises(_lib.MydetError):
         _lib.check(-1, 'x')
 
