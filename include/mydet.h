@@ -80,14 +80,17 @@ int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *w,
  * models/backbones.py:183-200, models/rpns.py:155-158.
  * u: weights in the transform domain, produced once per layer by mydet_wino_weights_f32 from the OHWI weight
  *    (mydet_wino_weights_floats(Cout, Cin) floats; 0 if the shape is unsupported).
+ * workspace: NULL, or 16-byte aligned scratch (32 MiB suffices): grids of two or more resident rounds then run a
+ *    stream-K schedule -- one round of persistent workgroups with equal shares of the K iterations; items whose K
+ *    was cut leave partial outputs here and a fixup launch sums them in K order (deterministic).
  * Needs Cin % 8 == 0, Cout % 4 == 0, ldy % 4 == 0 (ldr % 4 == 0), 16-byte aligned pointers; otherwise
  * MYDET_E_UNSUPP and the caller uses mydet_conv2d_igemm_f32.
  */
 int64_t mydet_wino_weights_floats(int Cout, int Cin);
 int mydet_wino_weights_f32(const float *w_ohwi, int Cout, int Cin, float *u, void *stream);
 int mydet_conv2d_wino_f32(const float *x, int64_t ldx, const float *u, const float *scale, const float *shift,
-                          const float *residual, int64_t ldr, float *y, int64_t ldy, int B, int H, int W, int Cin,
-                          int Cout, int act, void *stream);
+                          const float *residual, int64_t ldr, void *workspace, int64_t workspace_bytes, float *y,
+                          int64_t ldy, int B, int H, int W, int Cin, int Cout, int act, void *stream);
 
 /* First-layer convolution (Cin == 3, 3x3) reading the image with arbitrary strides
  * (NCHW as handed over by api/detection.py:160-166, or channels-last) and writing NHWC.

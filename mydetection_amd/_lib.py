@@ -18,7 +18,8 @@ SIGNATURES = {
     + [c_int] * 13 + [c_ptr],
     'mydet_wino_weights_floats': [c_int, c_int],
     'mydet_wino_weights_f32': [c_ptr, c_int, c_int, c_ptr, c_ptr],
-    'mydet_conv2d_wino_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64] + [c_int] * 6 + [c_ptr],
+    'mydet_conv2d_wino_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64] + [c_int] * 6
+    + [c_ptr],
     'mydet_dwconv_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64] + [c_int] * 11 + [c_ptr, c_int, c_ptr],
     'mydet_channel_sums_f32': [c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr, c_int, c_ptr],
     'mydet_se_gate_f32': [c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr],

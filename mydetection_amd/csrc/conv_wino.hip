@@ -43,7 +43,16 @@ struct WinoArgs {
     int64_t ldx, ldr, ldy;
     int B, H, W, Cin, Cout, CoutP;
     int TH, TW, MT, ntn, nblk;
+    // stream-K schedule (SK kernels): `nwg` persistent workgroups split the items*nk slab iterations evenly; a piece
+    // that does not cover its item's whole K writes its output-domain partial sums to ws (slot 2w: piece that starts
+    // inside an item, 2w+1: piece that starts an item but does not finish it) for conv_wino_fixup_kernel
+    int nwg, nk;
+    float *ws;
+    size_t ws_bytes;
 };
+
+// first slab iteration of persistent workgroup w: floor(w * total / nwg)
+__device__ __forceinline__ int64_t sk_begin(int w, int64_t total, int nwg) { return (int64_t)w * total / nwg; }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -58,144 +67,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *base, i
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// NW = 4: 32 tiles per workgroup, one LDS slab, two barriers per slab, two workgroups per CU -- short-K layers,
-//         where a workgroup's prologue and epilogue must hide under its neighbour's MFMAs.
-// NW = 8: 64 tiles per workgroup (waves 0-3 / 4-7 take 32 tiles each and share the weights), two LDS slabs, ONE
-//         barrier per slab: the next slab's transform and LDS stores are woven into the second half of the
-//         current slab's MFMAs, so in steady state the matrix pipe only idles across that barrier.
-template <int ACT, bool RES, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_wino_kernel(const WinoArgs p) {
-    constexpr int TILES = 8 * NW;                      // 2x2-output tiles per workgroup
-    constexpr int V_KS = TILES * 16, V_PS = 4 * V_KS;  // V: bytes between k quarters / position pairs
-    constexpr int SLAB = U_BYTES + 8 * V_PS;           // 48 KB (NW = 4) / 64 KB (NW = 8)
-    constexpr int NU = 2048 / (64 * NW);               // float4 of weights each thread stages per slab
-    constexpr bool DB = NW == 8;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int lid = mydet_xcd_remap(blockIdx.x, p.nblk);
-    const int m0 = (lid / p.ntn) * TILES, n0 = (lid % p.ntn) * CH;
-    const int tpi = p.TH * p.TW;                       // tiles per image
-    const int b0 = m0 / tpi;
-
-    // ---- staging: every thread brings one channel of one tile's patch (16 dwords) and NU float4 of weights
-    const int64_t img = (int64_t)p.H * p.W * p.ldx;
-    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x + b0 * img, (p.B - b0) * img * 4);
-    const __amdgpu_buffer_rsrc_t ur = make_rsrc(p.u, (int64_t)p.Cin * 16 * p.CoutP * 4);
-    // a wave covers 8 tiles x the 8 channels of the slab: one 32-byte run per patch pixel and load instruction
-    const int slot = wave * 8 + (lane >> 3), kc = lane & 7;
-    unsigned off[16];
-    {
-        const int mt = m0 + slot;
-        const int mm = mt < p.MT ? mt : p.MT - 1;
-        const int b = mm / tpi, r = mm - b * tpi, ty = r / p.TW, tx = r - ty * p.TW;
-        const int iy0 = 2 * ty - 1, ix0 = 2 * tx - 1;
-        const int base = (int)(((((int64_t)(b - b0) * p.H + iy0) * p.W + ix0) * p.ldx + kc) * 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool ok = mt < p.MT && (unsigned)(iy0 + i) < (unsigned)p.H && (unsigned)(ix0 + j) < (unsigned)p.W;
-                off[i * 4 + j] = ok ? (unsigned)(base + (int)(((int64_t)i * p.W + j) * p.ldx * 4)) : OOB;
-            }
-    }
-    // V slab element (pair, quarter kq = kc/2, tile): this thread owns components {2s, 2s+1}, s = kc & 1.  The tile
-    // column is XOR-swizzled with 2*kq: the ds_write_b64 lane groups (2 tiles x 8 channels) and the ds_read_b128
-    // lane groups (8 + 8 tiles of two adjacent quarters) then both touch every bank once.
-    const unsigned wr_v = U_BYTES + (unsigned)((kc >> 1) * V_KS + ((slot ^ (kc & 6)) * 16) + (kc & 1) * 8);
-    // U slab float4 q*64*NW + tid: global and LDS order coincide
-    const unsigned uoff = (unsigned)(((tid >> 6) * p.CoutP + n0 + (tid & 63)) * 16);
-    const unsigned ustep = __builtin_amdgcn_readfirstlane(16u * NW * (unsigned)p.CoutP);   // bytes between q and q+1
-    const unsigned wr_u = (unsigned)tid * 16u;
-
-    // ---- compute role: wave owns channels 16*wc.. and tiles 32*wt..32*wt+31 (two 16x16 blocks)
-    const int wc = wave & 3, wt = wave >> 2;
-    const int fr = lane & 15, fq = lane >> 4;
-    const unsigned rd_u = (unsigned)(fq * CH + wc * 16 + fr) * 16u;                  // + position pair * 4*CH*16
-    const unsigned rd_v = U_BYTES + (unsigned)(fq * V_KS + ((wt * 32 + fr) ^ (2 * fq)) * 16);   // + pair * V_PS, + 256: block 1
-
-    f32x4 acc[16][2];
-#pragma unroll
-    for (int q = 0; q < 16; ++q)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) acc[q][e] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    float gv[16];
-    f32x4 gu[NU];
-    auto load_slab = [&](int kt) {
-        const unsigned sv = (unsigned)kt * 32u, su = (unsigned)kt * (512u * (unsigned)p.CoutP);
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-            gv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off[q], sv, 0));
-#pragma unroll
-        for (int q = 0; q < NU; ++q)
-            gu[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, uoff, su + q * ustep, 0));
-    };
-    auto store_slab = [&](char *slab) {
-        float t[16];                                   // V = Bt d B (rows, then columns) of this thread's channel
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            t[j] = gv[j] - gv[8 + j]; t[4 + j] = gv[4 + j] + gv[8 + j];
-            t[8 + j] = gv[8 + j] - gv[4 + j]; t[12 + j] = gv[4 + j] - gv[12 + j];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float t0 = t[4 * i], t1 = t[4 * i + 1], t2 = t[4 * i + 2], t3 = t[4 * i + 3];
-            *reinterpret_cast<f32x2 *>(slab + wr_v + (2 * i) * V_PS) = f32x2{t0 - t2, t1 + t2};
-            *reinterpret_cast<f32x2 *>(slab + wr_v + (2 * i + 1) * V_PS) = f32x2{t2 - t1, t1 - t3};
-        }
-#pragma unroll
-        for (int q = 0; q < NU; ++q) *reinterpret_cast<f32x4 *>(slab + wr_u + q * (1024 * NW)) = gu[q];
-    };
-    // MFMAs of position pairs [p0, p1) of one slab; the fragments of pair pp+1 are read under pair pp's MFMAs
-    f32x4 fu[2], fv[2][2];
-    auto read_frag = [&](const char *slab, int pp, int st) {
-        fu[st] = *reinterpret_cast<const f32x4 *>(slab + rd_u + pp * (4 * CH * 16));
-        fv[st][0] = *reinterpret_cast<const f32x4 *>(slab + rd_v + pp * V_PS);
-        fv[st][1] = *reinterpret_cast<const f32x4 *>(slab + rd_v + pp * V_PS + 256);
-    };
-    auto mma_pair = [&](int pp, int st) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-#pragma unroll
-                for (int blk = 0; blk < 2; ++blk)
-                    acc[2 * pp + e][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                        fu[st][2 * s + e], fv[st][blk][2 * s + e], acc[2 * pp + e][blk], 0, 0, 0);
-    };
-
-    const int nk = p.Cin >> 3;
-    load_slab(0);
-    store_slab(smem);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const char *cur = smem + (DB ? (kt & 1) * SLAB : 0);
-        load_slab(kt + 1 < nk ? kt + 1 : kt);          // past the end: re-load the last slab, never consumed
-        __builtin_amdgcn_sched_barrier(0);
-        read_frag(cur, 0, 0);
-#pragma unroll
-        for (int pp = 0; pp < 8; ++pp) {
-            if (pp + 1 < 8) read_frag(cur, pp + 1, (pp + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);         // keeps the reads above this pair's MFMAs
-            if (DB && pp == 4) {                       // the other slab was last read before the previous barrier
-#pragma unroll
-                for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(gv[q]));  // pins the transform to this point
-                store_slab(smem + ((kt + 1) & 1) * SLAB);
-            }
-            mma_pair(pp, pp & 1);
-        }
-        __syncthreads();                               // every wave is done with the slab
-        if (!DB) {
-            if (kt + 1 < nk) {
-#pragma unroll
-                for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(gv[q]));  // pins the transform below the MFMAs
-                store_slab(smem);
-            }
-            __syncthreads();
-        }
-    }
-
-    // ---- epilogue: lane = tile 32*wt + fr (+16 for block 1), its 4 accumulator components = channels n0+16wc+4fq+(0..3)
+// y = act(Y*scale + shift) + residual for one item: lane = tile m0 + 32*wt + 16*blk + fr, its four components =
+// channels n0 + 16*wc + 4*fq + (0..3); out[blk][2a+c] = output pixel (2ty+a, 2tx+c).  All residual loads of a
+// lane are in flight before its first store.
+template <int ACT, bool RES>
+__device__ __forceinline__ void wino_epilogue(const WinoArgs &p, const f32x4 (&out)[2][4], int m0, int n0, int b0,
+                                              int wc, int wt, int fr, int fq) {
+    const int tpi = p.TH * p.TW;
     const int n = n0 + wc * 16 + fq * 4;
     const bool nok = n < p.Cout;                       // Cout % 4 == 0: the four channels stand or fall together
     const int nc = nok ? n : 0;
@@ -221,27 +99,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_wino_kernel(con
             const bool ok = tok && oy + a < p.H && ox + c < p.W;
             const int64_t px = pix + (int64_t)a * p.W + c;
             yo[blk][o] = ok ? (unsigned)((px * p.ldy + n) * 4) : OOB;
-            if (RES)                                   // all residual loads in flight before the first store
+            if (RES)
                 rv[blk][o] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                                            rr, ok ? (unsigned)((px * p.ldr + n) * 4) : OOB, 0, 0));
         }
     }
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-        f32x4 s0[4], s1[4];                            // At M: rows (m0+m1+m2), (m1-m2-m3) per column j
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s0[j] = acc[j][blk] + acc[4 + j][blk] + acc[8 + j][blk];
-            s1[j] = acc[4 + j][blk] - acc[8 + j][blk] - acc[12 + j][blk];
-        }
-        f32x4 out[4];
-        out[0] = s0[0] + s0[1] + s0[2];
-        out[1] = s0[1] - s0[2] - s0[3];
-        out[2] = s1[0] + s1[1] + s1[2];
-        out[3] = s1[1] - s1[2] - s1[3];
+    for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-            f32x4 v = out[o] * scl + sft;
+            f32x4 v = out[blk][o] * scl + sft;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (ACT == MYDET_ACT_LEAKY) v[e] = v[e] > 0.0f ? v[e] : v[e] * 0.1f;
@@ -250,7 +117,226 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_wino_kernel(con
             if (RES) v += rv[blk][o];
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, yo[blk][o], 0, 0);
         }
+}
+
+// NW = 4: 32 tiles per workgroup, one LDS slab, two barriers per slab, two workgroups per CU -- short-K layers,
+//         where a workgroup's prologue and epilogue must hide under its neighbour's MFMAs.
+// NW = 8: 64 tiles per workgroup (waves 0-3 / 4-7 take 32 tiles each and share the weights), two LDS slabs, ONE
+//         barrier per slab: the next slab's transform and LDS stores are woven into the second half of the
+//         current slab's MFMAs, so in steady state the matrix pipe only idles across that barrier.
+//
+// SK = false: one workgroup per item (item = 8*NW tiles x 64 channels), all of K.
+// SK = true : stream-K.  The grid is one resident round of persistent workgroups; workgroup w owns the slab
+//         iterations [w*T/G, (w+1)*T/G) of the item-major, K-minor sequence, so every workgroup does the same
+//         amount of matrix work (no partial last round) and the workgroups meet their epilogues -- the HBM-bound
+//         part of a layer -- at different times.  A piece that covers only part of an item's K leaves its partial
+//         outputs in the workspace; conv_wino_fixup_kernel sums the pieces of such items in K order and applies the
+//         epilogue (deterministic, no atomics, no waiting inside the kernel).
+template <int ACT, bool RES, int NW, bool SK>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_wino_kernel(const WinoArgs p) {
+    constexpr int TILES = 8 * NW;                      // 2x2-output tiles per workgroup
+    constexpr int V_KS = TILES * 16, V_PS = 4 * V_KS;  // V: bytes between k quarters / position pairs
+    constexpr int SLAB = U_BYTES + 8 * V_PS;           // 48 KB (NW = 4) / 64 KB (NW = 8)
+    constexpr int NU = 2048 / (64 * NW);               // float4 of weights each thread stages per slab
+    constexpr bool DB = NW == 8;
+#ifndef WINO_LDS_DIRECT
+#define WINO_LDS_DIRECT 0   // measured 1-2 % slower than staging the weights through registers
+#endif
+    constexpr bool DMA = DB && WINO_LDS_DIRECT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lid = mydet_xcd_remap(blockIdx.x, SK ? p.nwg : p.nblk);
+    const int tpi = p.TH * p.TW;                       // tiles per image
+    const int nk = p.Cin >> 3;
+    const int64_t total = (int64_t)p.nblk * nk;
+    int64_t it = SK ? sk_begin(lid, total, p.nwg) : (int64_t)lid * nk;
+    const int64_t it_end = SK ? sk_begin(lid + 1, total, p.nwg) : it + nk;
+    const int wc = wave & 3, wt = wave >> 2;           // compute role: channels 16*wc.., tiles 32*wt..32*wt+31
+    const int fr = lane & 15, fq = lane >> 4;
+    const int slot = wave * 8 + (lane >> 3), kc = lane & 7;   // staging role: tile, channel of the slab
+  while (it < it_end) {
+    const int item = (int)(it / nk), k_lo = (int)(it - (int64_t)item * nk);
+    const int k_hi = (int64_t)nk - k_lo < it_end - it ? nk : k_lo + (int)(it_end - it);
+    const int m0 = (item / p.ntn) * TILES, n0 = (item % p.ntn) * CH;
+    const int b0 = m0 / tpi;
+
+    // ---- staging: every thread brings one channel of one tile's patch (16 dwords) and NU float4 of weights
+    const int64_t img = (int64_t)p.H * p.W * p.ldx;
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x + b0 * img, (p.B - b0) * img * 4);
+    const __amdgpu_buffer_rsrc_t ur = make_rsrc(p.u, (int64_t)p.Cin * 16 * p.CoutP * 4);
+    // a wave covers 8 tiles x the 8 channels of the slab: one 32-byte run per patch pixel and load instruction
+    unsigned off[16];
+    {
+        const int mt = m0 + slot;
+        const int mm = mt < p.MT ? mt : p.MT - 1;
+        const int b = mm / tpi, r = mm - b * tpi, ty = r / p.TW, tx = r - ty * p.TW;
+        const int iy0 = 2 * ty - 1, ix0 = 2 * tx - 1;
+        const int base = (int)(((((int64_t)(b - b0) * p.H + iy0) * p.W + ix0) * p.ldx + kc) * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = mt < p.MT && (unsigned)(iy0 + i) < (unsigned)p.H && (unsigned)(ix0 + j) < (unsigned)p.W;
+                off[i * 4 + j] = ok ? (unsigned)(base + (int)(((int64_t)i * p.W + j) * p.ldx * 4)) : OOB;
+            }
     }
+    // V slab element (pair, quarter kq = kc/2, tile): this thread owns components {2s, 2s+1}, s = kc & 1.  The tile
+    // column is XOR-swizzled with 2*kq: the ds_write_b64 lane groups (2 tiles x 8 channels) and the ds_read_b128
+    // lane groups (8 + 8 tiles of two adjacent quarters) then both touch every bank once.
+    const unsigned wr_v = U_BYTES + (unsigned)((kc >> 1) * V_KS + ((slot ^ (kc & 6)) * 16) + (kc & 1) * 8);
+    // U slab float4 q*64*NW + tid: global and LDS order coincide
+    const unsigned uoff = (unsigned)(((tid >> 6) * p.CoutP + n0 + (tid & 63)) * 16);
+    const unsigned ustep = __builtin_amdgcn_readfirstlane(16u * NW * (unsigned)p.CoutP);   // bytes between q and q+1
+    const unsigned wr_u = (unsigned)tid * 16u;
+
+    // ---- compute role: wave owns channels 16*wc.. and tiles 32*wt..32*wt+31 (two 16x16 blocks)
+    const unsigned rd_u = (unsigned)(fq * CH + wc * 16 + fr) * 16u;                  // + position pair * 4*CH*16
+    const unsigned rd_v = U_BYTES + (unsigned)(fq * V_KS + ((wt * 32 + fr) ^ (2 * fq)) * 16);   // + pair * V_PS, + 256: block 1
+
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) acc[q][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float gv[16];
+    f32x4 gu[DMA ? 1 : NU];
+    // DB: the weights go global -> LDS directly (buffer_load_dwordx4 ... lds: lane i of a wave lands at base + 16*i,
+    // and the slab order in memory IS the LDS order), into the slab that was released at the previous barrier;
+    // otherwise through registers, stored after the barrier that frees the only slab.
+    auto load_slab = [&](int kt, char *next) {
+        const unsigned sv = (unsigned)kt * 32u, su = (unsigned)kt * (512u * (unsigned)p.CoutP);
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            gv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off[q], sv, 0));
+        if constexpr (DMA) {
+            char *dst = next + __builtin_amdgcn_readfirstlane(wave) * 1024;
+#pragma unroll
+            for (int q = 0; q < NU; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (__attribute__((address_space(3))) void *)(dst + q * (1024 * NW)),
+                                                         16, uoff, su + q * ustep, 0, 0);
+        } else {
+#pragma unroll
+            for (int q = 0; q < NU; ++q)
+                gu[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, uoff, su + q * ustep, 0));
+        }
+    };
+    auto store_slab = [&](char *slab) {
+        float t[16];                                   // V = Bt d B (rows, then columns) of this thread's channel
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[j] = gv[j] - gv[8 + j]; t[4 + j] = gv[4 + j] + gv[8 + j];
+            t[8 + j] = gv[8 + j] - gv[4 + j]; t[12 + j] = gv[4 + j] - gv[12 + j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float t0 = t[4 * i], t1 = t[4 * i + 1], t2 = t[4 * i + 2], t3 = t[4 * i + 3];
+            *reinterpret_cast<f32x2 *>(slab + wr_v + (2 * i) * V_PS) = f32x2{t0 - t2, t1 + t2};
+            *reinterpret_cast<f32x2 *>(slab + wr_v + (2 * i + 1) * V_PS) = f32x2{t2 - t1, t1 - t3};
+        }
+        if constexpr (!DMA) {
+#pragma unroll
+            for (int q = 0; q < NU; ++q) *reinterpret_cast<f32x4 *>(slab + wr_u + q * (1024 * NW)) = gu[q];
+        }
+    };
+    // MFMAs of position pairs [p0, p1) of one slab; the fragments of pair pp+1 are read under pair pp's MFMAs
+    f32x4 fu[2], fv[2][2];
+    auto read_frag = [&](const char *slab, int pp, int st) {
+        fu[st] = *reinterpret_cast<const f32x4 *>(slab + rd_u + pp * (4 * CH * 16));
+        fv[st][0] = *reinterpret_cast<const f32x4 *>(slab + rd_v + pp * V_PS);
+        fv[st][1] = *reinterpret_cast<const f32x4 *>(slab + rd_v + pp * V_PS + 256);
+    };
+    auto mma_pair = [&](int pp, int st) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+                    acc[2 * pp + e][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                        fu[st][2 * s + e], fv[st][blk][2 * s + e], acc[2 * pp + e][blk], 0, 0, 0);
+    };
+
+    load_slab(k_lo, smem + (DB ? (k_lo & 1) * SLAB : 0));
+    store_slab(smem + (DB ? (k_lo & 1) * SLAB : 0));
+    if (DMA) __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): the LDS-direct weight loads have landed
+    __syncthreads();
+    for (int kt = k_lo; kt < k_hi; ++kt) {
+        const char *cur = smem + (DB ? (kt & 1) * SLAB : 0);
+        load_slab(kt + 1 < k_hi ? kt + 1 : kt, smem + (DB ? ((kt + 1) & 1) * SLAB : 0));   // past the end: re-load, never consumed
+        __builtin_amdgcn_sched_barrier(0);
+        read_frag(cur, 0, 0);
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) {
+            if (pp + 1 < 8) read_frag(cur, pp + 1, (pp + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);         // keeps the reads above this pair's MFMAs
+            if (DB && pp == 4) {                       // the other slab was last read before the previous barrier
+#pragma unroll
+                for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(gv[q]));  // pins the transform to this point
+                store_slab(smem + ((kt + 1) & 1) * SLAB);
+            }
+            mma_pair(pp, pp & 1);
+        }
+        if (DMA) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): next slab's LDS-direct weight loads have landed
+        __syncthreads();                               // every wave is done with the slab
+        if (!DB) {
+            if (kt + 1 < k_hi) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(gv[q]));  // pins the transform below the MFMAs
+                store_slab(smem);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- output transform: lane = tile 32*wt + fr (+16 for block 1), components = channels n0+16wc+4fq+(0..3)
+    f32x4 out[2][4];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        f32x4 s0[4], s1[4];                            // At M: rows (m0+m1+m2), (m1-m2-m3) per column j
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s0[j] = acc[j][blk] + acc[4 + j][blk] + acc[8 + j][blk];
+            s1[j] = acc[4 + j][blk] - acc[8 + j][blk] - acc[12 + j][blk];
+        }
+        out[blk][0] = s0[0] + s0[1] + s0[2];
+        out[blk][1] = s0[1] - s0[2] - s0[3];
+        out[blk][2] = s1[0] + s1[1] + s1[2];
+        out[blk][3] = s1[1] - s1[2] - s1[3];
+    }
+    if (!SK || (k_lo == 0 && k_hi == nk)) {
+        wino_epilogue<ACT, RES>(p, out, m0, n0, b0, wc, wt, fr, fq);
+    } else {                                           // partial K: [float4 j][thread], summed by the fixup launch
+        f32x4 *dst = reinterpret_cast<f32x4 *>(p.ws) + (int64_t)(2 * lid + (k_lo == 0 ? 1 : 0)) * 8 * (64 * NW) + tid;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[j * (64 * NW)] = out[j >> 2][j & 3];
+    }
+    it += k_hi - k_lo;
+  }
+}
+
+// Items whose K range was cut by the stream-K schedule: sum the pieces in K order, then the usual epilogue.
+// One workgroup per schedule boundary; the first boundary inside an item owns it, the others exit.
+template <int ACT, bool RES, int NW>
+__global__ __launch_bounds__(64 * NW) void conv_wino_fixup_kernel(const WinoArgs p) {
+    constexpr int TILES = 8 * NW, NT = 64 * NW;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int w = blockIdx.x + 1;                      // boundary between workgroups w-1 and w
+    const int nk = p.nk;
+    const int64_t total = (int64_t)p.nblk * nk;
+    const int64_t cut = sk_begin(w, total, p.nwg);
+    const int item = (int)(cut / nk);
+    const int64_t first = (int64_t)item * nk;
+    if (cut == first || sk_begin(w - 1, total, p.nwg) > first) return;   // no cut here / not the first cut of the item
+    const f32x4 *ws = reinterpret_cast<const f32x4 *>(p.ws) + tid;
+    f32x4 out[2][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j >> 2][j & 3] = ws[((int64_t)(2 * (w - 1) + 1) * 8 + j) * NT];   // starts the item
+    for (int v = w; v < p.nwg && sk_begin(v, total, p.nwg) < first + nk; ++v)                           // later pieces
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[j >> 2][j & 3] += ws[((int64_t)(2 * v) * 8 + j) * NT];
+    const int m0 = (item / p.ntn) * TILES, n0 = (item % p.ntn) * CH;
+    wino_epilogue<ACT, RES>(p, out, m0, n0, m0 / (p.TH * p.TW), wave & 3, wave >> 2, lane & 15, lane >> 4);
 }
 
 // U = G g Gt in float64, rounded once; layout [Cin/8][8 position pairs][4 k quarters][CoutP][4] with the float4 =
@@ -279,18 +365,45 @@ __global__ void wino_weights_kernel(const float *w, int Cout, int Cin, int CoutP
     }
 }
 
+int forced_sk() {
+    static int v = -2;
+    if (v == -2) {
+        const char *e = getenv("MYDET_WINO_SK");     // tuning only: 0 = never use the stream-K schedule
+        v = e ? atoi(e) : -1;
+    }
+    return v;
+}
+
 template <int ACT, bool RES, int NW>
 int launch_nw(WinoArgs a, hipStream_t stream) {
-    constexpr int TILES = 8 * NW;
+    constexpr int TILES = 8 * NW, NT = 64 * NW;
     constexpr int LDS = (U_BYTES + 8 * 4 * TILES * 16) * (NW == 8 ? 2 : 1);
-    auto kern = &conv_wino_kernel<ACT, RES, NW>;
     static bool attr_set = false;                  // > 64 KiB of dynamic LDS needs the opt-in once
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino_kernel<ACT, RES, NW, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino_kernel<ACT, RES, NW, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     a.nblk = (int)(((int64_t)a.MT + TILES - 1) / TILES) * a.ntn;
-    hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(64 * NW), LDS, stream, a);
+    a.nk = a.Cin >> 3;
+    // stream-K when the grid is at least two resident rounds (below that the plain grid is already one round or
+    // its prologue/epilogue overlap is what matters) and the caller gave room for the partial tiles
+    const int resident = 256 * (NW == 8 ? 1 : 2);
+    const size_t need = (size_t)2 * resident * 8 * NT * sizeof(f32x4);
+    // (measured: pays on the 64-tile shape, whose single workgroup per CU exposes the partial last round; not on the
+    // 32-tile shape, MYDET_WINO_SK=1 forces it there)
+    if (forced_sk() != 0 && (NW == 8 || forced_sk() == 1) && a.ws && need <= a.ws_bytes && a.nblk >= 2 * resident) {
+        a.nwg = resident;
+        hipLaunchKernelGGL((conv_wino_kernel<ACT, RES, NW, true>), dim3(resident), dim3(NT), LDS, stream, a);
+        int rc = mydet_launch_status();
+        if (rc) return rc;
+        hipLaunchKernelGGL((conv_wino_fixup_kernel<ACT, RES, NW>), dim3(resident - 1), dim3(NT), 0, stream, a);
+        return mydet_launch_status();
+    }
+    a.nwg = 0;
+    hipLaunchKernelGGL((conv_wino_kernel<ACT, RES, NW, false>), dim3(a.nblk), dim3(NT), LDS, stream, a);
     return mydet_launch_status();
 }
 
@@ -327,8 +440,9 @@ extern "C" int mydet_wino_weights_f32(const float *w, int Cout, int Cin, float *
 }
 
 extern "C" int mydet_conv2d_wino_f32(const float *x, int64_t ldx, const float *u, const float *scale,
-                                     const float *shift, const float *residual, int64_t ldr, float *y, int64_t ldy,
-                                     int B, int H, int W, int Cin, int Cout, int act, void *stream) {
+                                     const float *shift, const float *residual, int64_t ldr, void *workspace,
+                                     int64_t workspace_bytes, float *y, int64_t ldy, int B, int H, int W, int Cin,
+                                     int Cout, int act, void *stream) {
     if (!x || !u || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || act < 0 || act > 2)
         return MYDET_E_BADARG;
     if ((ldx & 3) || ldx < Cin || ldy < Cout || (residual && ldr < Cout)) return MYDET_E_BADARG;
@@ -339,6 +453,9 @@ extern "C" int mydet_conv2d_wino_f32(const float *x, int64_t ldx, const float *u
     WinoArgs a;
     a.x = x; a.u = u; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
     a.ldx = ldx; a.ldr = residual ? ldr : ldy; a.ldy = ldy;
+    a.ws = ((uintptr_t)workspace & 15) ? nullptr : (float *)workspace;
+    a.ws_bytes = workspace_bytes > 0 ? (size_t)workspace_bytes : 0;
+    a.nwg = 0; a.nk = 0; a.nblk = 0;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.CoutP = (Cout + 63) / 64 * 64;
     a.TH = (H + 1) / 2; a.TW = (W + 1) / 2;
     const int64_t MT = (int64_t)B * a.TH * a.TW;

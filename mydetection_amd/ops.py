@@ -151,9 +151,11 @@ def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None
         assert residual.shape == out.shape
     if (wino is not None and WINOGRAD and gate is None and k == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1)
             and ldy % 4 == 0 and ldr % 4 == 0):
+        ws = conv_workspace(x.device)
         t0 = TIMER.start() if TIMER else None
         code = _lib.lib().mydet_conv2d_wino_f32(_ptr(x), ldx, _ptr(wino), _ptr(scale), _ptr(shift), _ptr(residual), ldr,
-                                                _ptr(out), ldy, B, H, W, Cin, Cout, act, _stream())
+                                                _ptr(ws), ws.numel() * 4, _ptr(out), ldy, B, H, W, Cin, Cout, act,
+                                                _stream())
         if t0:      # priced with the direct form's flops: the algorithmic work of the layer
             name = f'conv_wino {Cin}->{Cout} k3s1 {H}x{W}' if TIMER_DETAIL else 'conv_wino'
             TIMER.stop(name, t0, 2.0 * B * Ho * Wo * Cout * 9 * Cin,

@@ -74,6 +74,9 @@ def test_conv_igemm_vs_fp64(dev, case):
     dict(B=1, Cin=88, Cout=88, H=10, W=10, act=0, bias_only=True),     # Cout % 64 != 0 (zero-padded U rows)
     dict(B=2, Cin=88, Cout=84, H=5, W=5, act=2),                       # ragged everything, swish
     dict(B=32, Cin=64, Cout=128, H=40, W=40, act=1, residual=True),    # big grid (XCD remap path)
+    dict(B=32, Cin=128, Cout=256, H=40, W=40, act=1, residual=True),   # stream-K, 64-tile shape: 3.125 items/workgroup
+    dict(B=16, Cin=64, Cout=128, H=80, W=80, act=1),                   # stream-K, 32-tile shape
+    dict(B=24, Cin=136, Cout=200, H=37, W=37, act=2, residual=True),   # stream-K with ragged tiles, channels and K=17 slabs
 ])
 def test_conv_winograd_vs_fp64(dev, case):
     """Fused Winograd F(2x2,3x3) kernel (3x3, stride 1, pad 1) against the same float64 reference and tolerance

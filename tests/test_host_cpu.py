@@ -29,7 +29,7 @@ def test_argument_errors_are_reported_before_launch():
                                       1, 1, 0, null) == -1
     assert lib.mydet_postprocess_f32(null, null, null, 1, 1 << 17, 0.5, 0.5, 512, null, null, null, null, null, null,
                                      null) == -2
-    assert lib.mydet_conv2d_wino_f32(null, 0, null, null, null, null, 0, null, 0, 1, 8, 8, 8, 8, 0, null) == -1
+    assert lib.mydet_conv2d_wino_f32(null, 0, null, null, null, null, 0, null, 0, null, 0, 1, 8, 8, 8, 8, 0, null) == -1
     assert lib.mydet_wino_weights_floats(64, 12) == 0 and lib.mydet_wino_weights_floats(70, 16) == 16 * 16 * 128
     with pytest.raises(_lib.MydetError):
         _lib.check(-1, 'x')
