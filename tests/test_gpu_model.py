@@ -231,3 +231,67 @@ def test_device_preprocess_and_batched_detector(model):
         one = det.detect_one(pil_img=img, **kw)
         assert len(one) == len(d) > 0 and d.img_hw == (240, 320)
         assert torch.equal(one.cats, d.cats) and torch.equal(one.scores, d.scores) and torch.equal(one.bboxes, d.bboxes)
+
+
+def test_full_size_properties_batch32_640(model):
+    """BASELINE configs[1] size (batch 32, 640x640; the stream-K Winograd schedule and every conv tile shape of the
+    benchmark are live here), through properties that need no CPU forward:
+      * the same batch twice gives the same bits (the split-K / stream-K schedules sum in a fixed order, no atomics);
+      * permuting the images permutes the candidates (no cross-image coupling) -- to 1e-5, not bit for bit: where a
+        tile's K range is cut depends on the tile's position in the schedule;
+      * the Winograd layers agree with the same network on the direct implicit-GEMM kernel within the tolerance;
+      * NMS output invariants per image: count <= 512, score >= conf, class ascending / score descending inside a
+        class, kept boxes of one class pairwise IoU <= thr, every kept index unique and pointing at its candidate;
+      * post-processing is idempotent on its own output (re-running filter + NMS on the kept set keeps it all);
+      * the batched records equal the oracle's post_process on the GPU candidates for a sample of images."""
+    from mydetection_amd import ops, synth
+    from mydetection_amd.utils.structures import batched_post_process
+    from mydetection_amd.utils.bbox_ops import bboxes_iou
+    from oracle import postprocess as pp
+    m, cfg = model
+    conf, thr = 0.005, 0.45
+    x = synth.make_images(32, 640, seed=11).cuda()
+    perm = torch.randperm(32, generator=torch.Generator().manual_seed(1)).cuda()
+    with torch.no_grad():
+        bb, ci, sc = m.forward_candidates(x)
+        b2, c2, s2 = m.forward_candidates(x)
+        bp, cp, sp = m.forward_candidates(x[perm].contiguous())
+        assert ops.WINOGRAD
+        ops.WINOGRAD = False
+        try:
+            bd, cd, sd_ = m.forward_candidates(x)
+        finally:
+            ops.WINOGRAD = True
+    assert bb.shape == (32, 25200, 4)
+    assert torch.equal(b2, bb) and torch.equal(c2, ci) and torch.equal(s2, sc)
+    np.testing.assert_allclose(sp.cpu().numpy(), sc[perm].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(bp.cpu().numpy(), bb[perm].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    assert (cp != ci[perm]).float().mean().item() < 1e-4
+    np.testing.assert_allclose(sc.cpu().numpy(), sd_.cpu().numpy(), rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(bb.cpu().numpy(), bd.cpu().numpy(), rtol=RTOL, atol=ATOL)
+    assert (ci != cd).float().mean().item() < 1e-4          # argmax flips only between numerically tied classes
+
+    rec = batched_post_process(bb, ci, sc, conf, thr)
+    cnt = rec['count'].cpu().numpy()
+    assert (cnt <= 512).all() and cnt.sum() > 0
+    for i in range(32):
+        k = int(cnt[i])
+        idx = rec['index'][i, :k].long()
+        cls, s, b = rec['class_idx'][i, :k], rec['score'][i, :k], rec['bbox'][i, :k]
+        assert idx.unique().numel() == k
+        assert torch.equal(b, bb[i][idx]) and torch.equal(cls, ci[i][idx]) and torch.equal(s, sc[i][idx])
+        assert (s >= conf).all()
+        same = cls[1:] == cls[:-1]
+        assert (cls[1:] >= cls[:-1]).all() and (s[1:][same] <= s[:-1][same]).all()
+        if k > 1:
+            iou = bboxes_iou(b, b, xyxy=False)
+            clash = (iou > thr + 1e-5) & (cls[:, None] == cls[None, :])      # margin: NMS forms the IoU in xyxy
+            clash.fill_diagonal_(False)
+            assert not clash.any()
+        again = batched_post_process(b[None], cls[None], s[None], conf, thr)
+        assert int(again['count'][0]) == k and torch.equal(again['bbox'][0, :k], b)
+    for i in (0, 13, 31):
+        ob, oc, os_, src = pp.post_process(bb[i].cpu().numpy(), ci[i].cpu().numpy(), sc[i].cpu().numpy(), conf, thr)
+        k = int(cnt[i])
+        assert k == len(src)
+        np.testing.assert_array_equal(rec['index'][i, :k].cpu().numpy().astype(np.int64), src)
