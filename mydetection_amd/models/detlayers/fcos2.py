@@ -5,23 +5,15 @@ from ... import ops
 from ._common import alloc_outputs, pack_pixel_major
 
 
-class FCOS_ATSS_Layer(nn.Module):
+class _FCOSInference(nn.Module):
     '''
-    Inference branch of the reference FCOS_ATSS_Layer (models/detlayers/fcos2.py:193-251; ATSS only changes
-    training): ltrb = exp(t)*stride around the cell centre x*stride + stride/2, corners clamped to the
-    image, converted to cxcywh; score = sqrt(sigmoid(centerness) * max_c sigmoid(cls_c)); order (y, x).
-    One fused HIP kernel; outputs stay in HBM.  Training (ATSS assignment, :253-405) is out of scope.
+    The inference branch shared by the reference's three FCOS-style layers (fcos.py:21-68, fcos2.py:24-69,
+    fcos2.py:222-251 are the same arithmetic; they differ in training-time assignment only):
+    ltrb = exp(t)*stride around the cell centre x*stride + stride/2, corners clamped to the image, converted to
+    cxcywh; score = sqrt(sigmoid(centerness) * max_c sigmoid(cls_c)); order (y, x).
+    One fused HIP kernel; outputs stay in HBM.  `conf_key` names the centerness entry of the raw dict.
     '''
-    def __init__(self, level_i: int, cfg: dict):
-        super().__init__()
-        self.strides_all = cfg['model.fpn.out_strides']
-        self.stride = cfg['model.fpn.out_strides'][level_i]
-        self.n_cls = cfg['general.num_class']
-        self.anchors_all = cfg['model.atss.anchors']
-        self.anchor = self.anchors_all[level_i]
-        self.topk = cfg['model.atss.topk_per_level']
-        self.ltrb_setting = 'exp_sl1'
-        self.ignore_thre = cfg['model.fcos2.ignored_threshold']
+    conf_key = 'conf'
 
     def forward(self, raw, img_size, labels=None, _out=None):
         if labels is not None:
@@ -31,7 +23,7 @@ class FCOS_ATSS_Layer(nn.Module):
         nH, nW = int(img_h / stride), int(img_w / stride)
         nCls = self.n_cls
         assert isinstance(raw, dict)
-        t_ltrb, conf_logits, cls_logits = raw['bbox'], raw['conf'], raw['class']
+        t_ltrb, conf_logits, cls_logits = raw['bbox'], raw[self.conf_key], raw['class']
         nB = t_ltrb.shape[0]
         assert t_ltrb.shape == (nB, nH, nW, 4)
         assert conf_logits.shape == (nB, nH, nW, 1)
@@ -67,3 +59,35 @@ class FCOS_ATSS_Layer(nn.Module):
         return {'mode': ops.DECODE_FCOS, 'layout': (bas, bc0, cas, cc0, conf0), 'A': 1, 'C': self.n_cls,
                 'level': {'box': box, 'ldbox': ldb, 'cls': cls, 'ldcls': ldc, 'anchors_wh': None,
                           'H': nH, 'W': nW, 'stride': self.stride}}
+
+
+class FCOSLayer(_FCOSInference):
+    '''
+    'FCOS2' (reference: models/detlayers/fcos2.py:11-69).  Training (:70-190) is out of scope.
+    '''
+    def __init__(self, level_i: int, cfg: dict):
+        super().__init__()
+        self.anch_min = cfg['model.fcos.anchors'][level_i]
+        self.anch_max = cfg['model.fcos.anchors'][level_i + 1]
+        self.stride = cfg['model.fpn.out_strides'][level_i]
+        self.n_cls = cfg['general.num_class']
+        self.center_region = 0.5
+        self.ltrb_setting = 'exp_sl1'
+        self.ignore_thre = cfg['model.fcos2.ignored_threshold']
+        self.bb_format = cfg['general.pred_bbox_format']
+
+
+class FCOS_ATSS_Layer(_FCOSInference):
+    '''
+    'FCOS2_ATSS' (reference: models/detlayers/fcos2.py:193-251; ATSS only changes training, :253-405, out of scope).
+    '''
+    def __init__(self, level_i: int, cfg: dict):
+        super().__init__()
+        self.strides_all = cfg['model.fpn.out_strides']
+        self.stride = cfg['model.fpn.out_strides'][level_i]
+        self.n_cls = cfg['general.num_class']
+        self.anchors_all = cfg['model.atss.anchors']
+        self.anchor = self.anchors_all[level_i]
+        self.topk = cfg['model.atss.topk_per_level']
+        self.ltrb_setting = 'exp_sl1'
+        self.ignore_thre = cfg['model.fcos2.ignored_threshold']

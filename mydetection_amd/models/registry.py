@@ -77,6 +77,9 @@ def get_rpn(cfg: dict):
     elif rpn_name == 'effrpn':
         from .rpns import EfDetHead
         rpn = EfDetHead(cfg)
+    elif rpn_name == 'effrpn_ct':
+        from .rpns import EfDetHead_wCenter
+        rpn = EfDetHead_wCenter(cfg)
     else:
         raise NotImplementedError()
     return rpn
@@ -93,6 +96,12 @@ def get_det_layer(cfg: dict):
     elif det_layer_name == 'RetinaNet':
         from .detlayers.retinanet import RetinaLayer
         return RetinaLayer
+    elif det_layer_name == 'FCOS':
+        from .detlayers.fcos import FCOSLayer
+        return FCOSLayer
+    elif det_layer_name == 'FCOS2':
+        from .detlayers.fcos2 import FCOSLayer
+        return FCOSLayer
     elif det_layer_name == 'FCOS2_ATSS':
         from .detlayers.fcos2 import FCOS_ATSS_Layer
         return FCOS_ATSS_Layer

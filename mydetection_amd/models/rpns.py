@@ -66,10 +66,11 @@ def spconv3x3_bn_swish(inout_ch):
 
 
 class _LastConv(nn.Conv2d):
-    """Dense 3x3 `cls_last` conv (reference: models/rpns.py:155-158) as one implicit-GEMM launch."""
-    def forward(self, x):
+    """Dense 3x3 last conv of a head branch (reference: models/rpns.py:155-158, 245-266) as one implicit-GEMM
+    launch; `out` lets several branches write channel ranges of one pixel-major tensor."""
+    def forward(self, x, out=None):
         w, scale, shift = prepare_conv(self, 'main', self, None)
-        return ops.conv2d(x, w, scale, shift, 3, 1, (1, 1, 1, 1), ops.ACT_NONE)
+        return ops.conv2d(x, w, scale, shift, 3, 1, (1, 1, 1, 1), ops.ACT_NONE, out=out)
 
 
 class EfDetHead(nn.Module):
@@ -146,5 +147,74 @@ class EfDetHead(nn.Module):
                 assert cls_v.shape[-1] == self.n_cls
                 raw['class'] = cls_v
             raw.packed = packed
+            all_level_preds.append(raw)
+        return all_level_preds
+
+
+class EfDetHead_wCenter(nn.Module):
+    '''
+    EfficientDet head for FCOS with its own centerness branch (reference: models/rpns.py:232-312): per level a
+    class tower (repeat x sepconv-BN-swish, dense 3x3 to n_cls [+1]), a box tower (repeat x sepconv-BN-swish) feeding
+    a dense 3x3 to 4 box logits and, through one more sepconv-BN-swish, a dense 3x3 to the centerness logit.
+    The class and centerness convs write channel ranges of ONE pixel-major tensor, which the decode kernel reads
+    in place.  Output dict per level: 'bbox' [B,H,W,4], 'center' [B,H,W,1], 'class' [B,H,W,n_cls] (+ 'conf').
+    '''
+    def __init__(self, cfg: dict):
+        super().__init__()
+        n_cls = cfg['general.num_class']
+        n_anch = cfg['model.effrpn.num_anchor_per_level']
+        feature_chs = cfg['model.fpn.out_channels']
+        repeat = cfg['model.effrpn.repeat_num']
+        bb_param = cfg.get('general.bbox_param', 4)
+        enable_conf = cfg.get('model.effrpn.enable_conf', False)
+        assert n_anch == 1
+        assert cfg['model.effrpn.enable_centerscore']
+        self.class_nets = nn.ModuleList()
+        self.bbox_nets = nn.ModuleList()
+        self.bbox_lasts = nn.ModuleList()
+        self.center_nets = nn.ModuleList()
+        for ch in feature_chs:
+            self.bbox_nets.append(nn.Sequential(*[spconv3x3_bn_swish(ch) for _ in range(repeat)]))
+            self.bbox_lasts.append(_LastConv(ch, n_anch * bb_param, 3, 1, padding=1))
+            # final biases -log((1 - 0.05) / 0.05): initial confidences close to 0.05 (reference :250-264)
+            ct_last = _LastConv(ch, 1, kernel_size=3, stride=1, padding=1)
+            ct_last.weight.data.normal_(mean=0, std=0.01)
+            ct_last.bias.data.fill_(-np.log((1 - 0.05) / 0.05))
+            self.center_nets.append(nn.Sequential(spconv3x3_bn_swish(ch), ct_last))
+            cls_net = [spconv3x3_bn_swish(ch) for _ in range(repeat)]
+            cls_last = _LastConv(ch, n_anch * (1 + n_cls) if enable_conf else n_anch * n_cls, 3, 1, padding=1)
+            cls_last.weight.data.normal_(mean=0, std=0.01)
+            cls_last.bias.data.fill_(-np.log((1 - 0.05) / 0.05))
+            cls_net.append(cls_last)
+            self.class_nets.append(nn.Sequential(*cls_net))
+        self.n_cls = n_cls
+        self.enable_conf = enable_conf
+
+    def forward(self, features: list):
+        all_level_preds = []
+        cls_ch = self.n_cls + 1 if self.enable_conf else self.n_cls
+        for i, x in enumerate(features):
+            nB, _, nH, nW = x.shape
+            # [B,H,W,ld]: channels [0, cls_ch) class (+conf) logits, channel cls_ch the centerness logit
+            both, ld = ops.empty_nhwc(nB, cls_ch + 1, nH, nW, x.device)
+            t = x
+            for m in list(self.class_nets[i])[:-1]:
+                t = m(t)
+            self.class_nets[i][-1](t, out=both[:, :cls_ch])
+            bbox_feats = self.bbox_nets[i](x)
+            bbox_pred = self.bbox_lasts[i](bbox_feats)
+            self.center_nets[i][1](self.center_nets[i][0](bbox_feats), out=both[:, cls_ch:cls_ch + 1])
+            assert bbox_pred.shape[1] == 4
+            cls_v = both.permute(0, 2, 3, 1)
+            raw = RawPreds()
+            raw['bbox'] = bbox_pred.permute(0, 2, 3, 1)
+            raw['center'] = cls_v[..., cls_ch:cls_ch + 1]
+            if self.enable_conf:
+                raw['conf'] = cls_v[..., 0:1]
+                raw['class'] = cls_v[..., 1:cls_ch]
+            else:
+                raw['class'] = cls_v[..., :cls_ch]
+            raw.packed = {'box': (bbox_pred, ops.nhwc_ld(bbox_pred), 4, 0),
+                          'cls': (both, ld, cls_ch + 1, 1 if self.enable_conf else 0, cls_ch)}
             all_level_preds.append(raw)
         return all_level_preds

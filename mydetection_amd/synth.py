@@ -62,11 +62,12 @@ _EFDET_LAST_FEATURE_RMS = 0.6
 
 
 def _efdet_last(key, shape):
-    """Final layers of EfDetHead (models/rpns.py:139-160): rpn.{class,bbox}_nets.{lvl}.3[.pointwise].{weight,bias}.
+    """Final layers of EfDetHead / EfDetHead_wCenter (models/rpns.py:139-160, 245-266):
+    rpn.{class,bbox}_nets.{lvl}.3[.pointwise].{weight,bias}, rpn.bbox_lasts.{lvl}.*, rpn.center_nets.{lvl}.1.*.
     Class/conf logits: std 1.5, bias -7 (long-tailed scores; the reference initialises the bias to -4.595);
-    box logits: std 0.5."""
+    box logits: std 0.5; centerness logits: std 1.5, bias 0."""
     is_cls = key.startswith('rpn.class_nets.')
-    tgt = 1.5 if is_cls else 0.5
+    tgt = 1.5 if is_cls or key.startswith('rpn.center_nets.') else 0.5
     if key.endswith('.bias'):
         return np.float32(-7.0 if is_cls else 0.0) + _normal(key, shape, std=0.05)
     fan_in = shape[1] * shape[2] * shape[3]
@@ -82,7 +83,8 @@ def load_calibration(config_name):
     activations run away; the EfficientDet-family configs therefore ship calibrated statistics."""
     import os
     if config_name not in _CALIB_CACHE:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'calib', f'{config_name}.npz')
+        stem = {'d1_fcs2': 'd1_fcs2_atss'}.get(config_name, config_name)      # same network, same statistics
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'calib', f'{stem}.npz')
         _CALIB_CACHE[config_name] = dict(np.load(path)) if os.path.exists(path) else {}
     return _CALIB_CACHE[config_name]
 
@@ -96,6 +98,9 @@ def make_tensor(key: str, shape, dtype=torch.float32) -> torch.Tensor:
         arr = _yolo_head(key, shape)
     elif key.startswith(('rpn.class_nets.', 'rpn.bbox_nets.')) and '.3.' in key and (
             'pointwise' in key or len(key.split('.')) == 5):
+        arr = _efdet_last(key, shape)
+    elif key.startswith('rpn.bbox_lasts.') or (key.startswith('rpn.center_nets.') and len(key.split('.')) == 5
+                                               and key.split('.')[3] == '1'):
         arr = _efdet_last(key, shape)
     elif key.endswith('.weights'):                           # BiFPN fusion weights (models/fpns.py:425)
         arr = _uniform(key, shape, 0.5, 1.5)

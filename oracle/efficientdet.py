@@ -167,6 +167,25 @@ def head(feats, sd, repeat=3, p='rpn'):
     return outs
 
 
+def head_with_center(feats, sd, repeat=3, p='rpn'):
+    """EfDetHead_wCenter (models/rpns.py:232-312): per level (class [B,K,H,W], bbox [B,4,H,W], center [B,1,H,W])."""
+    outs = []
+    for lvl, x in enumerate(feats):
+        def tower(net, t, n):
+            for r in range(n):
+                q = f'{p}.{net}.{lvl}.{r}'
+                t = _swish(_bn(sepconv(t, sd, q + '.0'), sd, q + '.1'))
+            return t
+        c = tower('class_nets', x, repeat)
+        c = F.conv2d(c, sd[f'{p}.class_nets.{lvl}.{repeat}.weight'], sd[f'{p}.class_nets.{lvl}.{repeat}.bias'], 1, 1)
+        bf = tower('bbox_nets', x, repeat)
+        b = F.conv2d(bf, sd[f'{p}.bbox_lasts.{lvl}.weight'], sd[f'{p}.bbox_lasts.{lvl}.bias'], 1, 1)
+        ct = tower('center_nets', bf, 1)
+        ct = F.conv2d(ct, sd[f'{p}.center_nets.{lvl}.1.weight'], sd[f'{p}.center_nets.{lvl}.1.bias'], 1, 1)
+        outs.append((c, b, ct))
+    return outs
+
+
 def raw_dicts(head_outs, n_anchor, n_cls, enable_conf):
     raws = []
     for cls, box in head_outs:
@@ -182,9 +201,17 @@ def raw_dicts(head_outs, n_anchor, n_cls, enable_conf):
 
 
 def forward(x, sd, config):
-    """config in {'efficientdet-d1', 'd1_fcs2_atss'} -> (bbox [B,N,4], class_idx [B,N], score [B,N])."""
+    """config in {'efficientdet-d1', 'd1_fcs2_atss', 'd1_fcs2', 'd1_fcs'} -> (bbox [B,N,4], class_idx [B,N],
+    score [B,N]).  d1_fcs2 is d1_fcs2_atss at inference (models/detlayers/fcos2.py:24-69 == :222-251)."""
     img = tuple(x.shape[2:4])
-    atss = config == 'd1_fcs2_atss'
+    if config == 'd1_fcs':          # EfDetHead_wCenter + FCOSLayer (models/detlayers/fcos.py:21-68)
+        feats = bifpn(backbone(x, sd, c6c7='maxpool'), sd)
+        outs = []
+        for lvl, (c, b, ct) in enumerate(head_with_center(feats, sd)):
+            raw = {'bbox': b.permute(0, 2, 3, 1), 'conf': ct.permute(0, 2, 3, 1), 'class': c.permute(0, 2, 3, 1)}
+            outs.append(decoders.fcos_decode(raw, img, STRIDES[lvl]))
+        return tuple(torch.cat([o[j] for o in outs], dim=1) for j in range(3))
+    atss = config in ('d1_fcs2_atss', 'd1_fcs2')
     feats = bifpn(backbone(x, sd, c6c7='conv' if atss else 'maxpool'), sd)
     raws = raw_dicts(head(feats, sd), 1 if atss else 9, 80, atss)
     outs = []

@@ -289,3 +289,6 @@ if __name__ == '__main__':
     if 'efficientdet' in which:
         gen_efficientdet('efficientdet-d1')
         gen_efficientdet('d1_fcs2_atss')
+    if 'fcos_variants' in which:        # registry plug-ins 'FCOS2' and 'effrpn_ct' + 'FCOS' 
+        gen_efficientdet('d1_fcs2')
+        gen_efficientdet('d1_fcs')

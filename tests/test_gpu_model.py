@@ -130,8 +130,8 @@ def test_detector_api(model, tmp_path):
         det.detect_one(pil_img=PIL.Image.fromarray(img), preprocessing='bogus')
 
 
-# ------------------------------------------------------------------ EfficientDet-D1 / D1-FCOS2-ATSS
-@pytest.fixture(scope='module', params=['efficientdet-d1', 'd1_fcs2_atss'])
+# ------------------- EfficientDet-D1 / D1-FCOS2-ATSS, and the registry plug-ins 'FCOS2' (d1_fcs2), 'effrpn_ct' + 'FCOS' (d1_fcs)
+@pytest.fixture(scope='module', params=['efficientdet-d1', 'd1_fcs2_atss', 'd1_fcs2', 'd1_fcs'])
 def effdet(request):
     assert torch.cuda.is_available()
     from mydetection_amd import synth

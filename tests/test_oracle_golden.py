@@ -129,7 +129,7 @@ def test_yolov3_post_process_matches_reference(yolov3_oracle_run):
         np.testing.assert_allclose(b, g[f'pp_{tag}_bboxes_0'], rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize('config', ['efficientdet-d1', 'd1_fcs2_atss'])
+@pytest.mark.parametrize('config', ['efficientdet-d1', 'd1_fcs2_atss', 'd1_fcs2', 'd1_fcs'])
 def test_efficientdet_family_matches_reference(golden, config):
     """Oracle restatement of EfficientNet-B1 + BiFPN + EfDetHead + decode vs the imported reference."""
     from mydetection_amd.models.general import state_dict_template
@@ -138,7 +138,7 @@ def test_efficientdet_family_matches_reference(golden, config):
     sd = synth.make_state_dict(state_dict_template(config), config)
     x = synth.make_normalized_images(int(g['batch']), int(g['size']), seed=int(g['image_seed']))
     torch.set_num_threads(8)
-    atss = config == 'd1_fcs2_atss'
+    atss = config in ('d1_fcs2_atss', 'd1_fcs2')       # C6/C7 by conv (configs' model.efficientnet.C6C7_downsample)
     with torch.no_grad():
         c = oe.backbone(x, sd, c6c7='conv' if atss else 'maxpool')
         p0 = oe.bifpn5(c, sd, 'fpn.0')
