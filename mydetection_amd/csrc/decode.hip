@@ -252,6 +252,7 @@ extern "C" int mydet_decode_levels_f32(int mode, int nlevels, const mydet_decode
                (p.same || (size_t)pix * p.qb <= MAXV_B * 256);
     };
     p.PIX = 32;
+    if (const char *e = getenv("MYDET_DECODE_PIX")) p.PIX = atoi(e);      // tuning knob
     while (p.PIX > 1 && !fits(p.PIX)) p.PIX >>= 1;
     if (!fits(p.PIX)) return MYDET_E_UNSUPP;
     while (p.PIX * A < 256 && fits(p.PIX * 2)) p.PIX <<= 1;
@@ -283,10 +284,10 @@ extern "C" int mydet_decode_levels_f32(int mode, int nlevels, const mydet_decode
     const size_t lds = ((size_t)p.PIX * p.row + 4) * sizeof(float);     // + dump slot for clamped staging lanes
     int max_tiles = 0;
     for (int l = 0; l < nlevels; ++l) max_tiles = p.lv[l].ntiles > max_tiles ? p.lv[l].ntiles : max_tiles;
-    // one resident round of workgroups per level (256 CUs x workgroups per CU by LDS / 4 waves per SIMD): the
+    // one resident round of workgroups per level (256 CUs x workgroups per CU, bounded by LDS): the
     // big level's workgroups then all run concurrently and loop over equal shares of its tiles
     int per_cu = (int)((160 * 1024) / (lds + 512));
-    per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
+    per_cu = per_cu > 3 ? 3 : (per_cu < 1 ? 1 : per_cu);                  // 3 measured best (2: -15 %, 4: -2 %)
     if (const char *e = getenv("MYDET_DECODE_GX")) per_cu = atoi(e);      // tuning knob
     const int resident = 256 * per_cu;
     const int gx = max_tiles < resident ? max_tiles : resident;
