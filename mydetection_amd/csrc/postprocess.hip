@@ -16,9 +16,10 @@
 //   4. suppression matrix: bit j of row i set iff j > i, same class, (double)IoU > thr --
 //      IoU in the exact float32 operation order of torchvision's CPU nms kernel (this file
 //      is built with -ffp-contract=off).
-//   5. greedy pass by one wave, 64 boxes at a time: inside a chunk the dependent chain stays on the scalar
-//      unit (bit test, v_readlane of the diagonal word, scalar OR); survivors of the chunk then OR their rows
-//      into the later words by wave reduction.  Rank-by-popcount compaction of survivors follows.
+//   5. greedy selection as a fixed point: removed <- OR of the rows of the boxes not removed, all 16 waves per
+//      round, until nothing changes (the greedy recursion has one solution, so the fixed point is it; real
+//      detections settle in a few rounds); inputs that do not settle in 12 rounds take the sequential form
+//      (one wave, 64 boxes at a time, dependent chain on the scalar unit).  Rank-by-popcount compaction follows.
 // Replaces ImageObjects.post_process / non_max_suppression (utils/structures.py:92-173).
 #include "common.h"
 
@@ -69,11 +70,28 @@ __global__ __launch_bounds__(NT) void postprocess_kernel(const PPArgs p) {
     if (tid == 0) { s_n = 0; s_nsel = 0; }
     __syncthreads();
     // 1. filter (>= in float32, as `self.scores >= conf_thres`)
-    for (int i = tid; i < N; i += NT) {
-        const float s = sc[i];
-        if (s >= p.conf) {
-            const int pos = atomicAdd(&s_n, 1);
-            keys[pos] = ((unsigned long long)sortable(s) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+    //    Eight independent loads in flight per thread; a wave reserves its slots with ONE LDS atomic (ballot +
+    //    popcount ranks), so the strip order varies between runs but the key set does not -- and only the set is used.
+    for (int base = 0; base < N; base += 8 * NT) {
+        float s8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * NT + tid;
+            s8[u] = i < N ? sc[i] : -INFINITY;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * NT + tid;
+            const bool pass = i < N && s8[u] >= p.conf;
+            const unsigned long long m = __ballot(pass);
+            if (m) {                                            // wave-uniform
+                int start = 0;
+                if ((tid & 63) == 0) start = atomicAdd(&s_n, __popcll(m));
+                start = __shfl(start, 0);
+                if (pass)
+                    keys[start + __popcll(m & ((1ull << (tid & 63)) - 1ull))] =
+                        ((unsigned long long)sortable(s8[u]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+            }
         }
     }
     __syncthreads();
@@ -190,11 +208,59 @@ __global__ __launch_bounds__(NT) void postprocess_kernel(const PPArgs p) {
     }
     __syncthreads();
 
-    // 5. greedy scan (wave 0; lane w < 8 owns word w of the removed set)
-    // One wave, 64 boxes at a time.  Lane l holds row 64c+l.  Inside a chunk the dependent chain runs on the
-    // scalar unit only (bit test on a 64-bit scalar, v_readlane of the diagonal word, scalar OR); the chunk's
-    // survivors then OR their rows into the later words with one wave reduction per word.
-    if (tid < 64) {
+    // 5. greedy selection.  kept[i] = no kept j < i suppresses i, and that recursion has exactly one solution, so
+    //    any fixed point of  removed <- OR of the rows of the boxes not in removed  IS the greedy result.  Starting
+    //    from removed = 0, round t fixes every box whose chain of (suppressor of suppressor of ...) is shorter than
+    //    t -- a handful of rounds on real detections -- and each round is one parallel OR-reduction of the 512 x 8
+    //    mask words by all 16 waves.  Inputs that have not settled after MAX_ROUNDS fall back to the sequential scan.
+    constexpr int MAX_ROUNDS = 12;
+    __shared__ unsigned long long s_part[NT / 64][8];
+    __shared__ int s_changed;
+    bool settled = false;
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        // rows r = tid and tid + 512 (two half-rows per thread would not balance; a thread owns 4 words of a row)
+        const int row = tid >> 1, w0 = (tid & 1) * 4;
+        unsigned long long mine[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) mine[w] = row < nsel ? s_mask[row * 8 + w0 + w] : 0ull;
+        if (tid < 8) s_removed[tid] = 0ull;
+        __syncthreads();
+        for (int round = 0; round < MAX_ROUNDS; ++round) {
+            const bool kept = row < nsel && !((s_removed[row >> 6] >> (row & 63)) & 1ull);
+            unsigned long long acc[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                unsigned lo = kept ? (unsigned)mine[w] : 0u, hi = kept ? (unsigned)(mine[w] >> 32) : 0u;
+                // lanes with the same parity hold the same four words: reduce over stride-2 partners
+#pragma unroll
+                for (int off = 32; off >= 2; off >>= 1) {
+                    lo |= __shfl_xor(lo, off);
+                    hi |= __shfl_xor(hi, off);
+                }
+                acc[w] = ((unsigned long long)hi << 32) | lo;
+            }
+            if (lane < 2) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) s_part[wave][lane * 4 + w] = acc[w];
+            }
+            if (tid == 0) s_changed = 0;
+            __syncthreads();
+            if (tid < 8) {
+                unsigned long long r = 0ull;
+#pragma unroll
+                for (int v = 0; v < NT / 64; ++v) r |= s_part[v][tid];
+                if (r != s_removed[tid]) { s_removed[tid] = r; s_changed = 1; }
+            }
+            __syncthreads();
+            if (!s_changed) { settled = true; break; }         // uniform: read after the barrier by every thread
+            __syncthreads();                                    // s_changed is reset at the top of the next round
+        }
+    }
+    // sequential form (wave 0; lane w < 8 owns word w of the removed set): one wave, 64 boxes at a time.  Lane l
+    // holds row 64c+l.  Inside a chunk the dependent chain runs on the scalar unit only (bit test on a 64-bit scalar,
+    // v_readlane of the diagonal word, scalar OR); the chunk's survivors then OR their rows into the later words.
+    if (!settled && tid < 64) {
         const int lane = tid;
         unsigned long long removed[8];
 #pragma unroll
