@@ -248,6 +248,34 @@ def test_post_process_batched_random_vs_oracle(dev):
         np.testing.assert_array_equal(rec['bbox'][i, :k].cpu().numpy(), ob)
 
 
+def test_post_process_suppression_chains_vs_oracle(dev):
+    """Greedy selection by fixed-point rounds: chains where box i only overlaps box i+1 need one round per link, so
+    a 400-box chain exhausts the round budget and takes the sequential form; short chains and a chain broken into
+    classes settle early.  All must equal the oracle's sequential greedy NMS."""
+    from mydetection_amd import ops
+    from oracle import postprocess as pp
+    n = 400
+    b = np.zeros((4, n, 4), np.float32)
+    b[..., 0] = 100 + 12.0 * np.arange(n, dtype=np.float32)      # 20-wide boxes shifted by 12: IoU(i,i+1)=0.25, (i,i+2)=0
+    b[..., 1], b[..., 2], b[..., 3] = 50, 20, 20
+    b[1, :, 0] = 100 + 6.0 * np.arange(n, dtype=np.float32)      # shift 6: IoU(i,i+1)=0.54, (i,i+2)=0.25, (i,i+3)=0.05
+    s = np.tile(np.linspace(0.99, 0.5, n, dtype=np.float32), (4, 1))
+    c = np.zeros((4, n), np.int64)
+    c[2] = np.arange(n) // 7                                     # image 2: the chain of image 0 cut into 58 classes
+    b[3] = b[1]
+    c[3] = np.arange(n) % 3                                      # image 3: three interleaved chains
+    for thr in (0.2, 0.5):
+        rec = ops.postprocess(torch.from_numpy(b).to(dev), torch.from_numpy(c).to(dev), torch.from_numpy(s).to(dev), 0.3, thr)
+        for i in range(4):
+            ob, oc, os_, src = pp.post_process(b[i], c[i], s[i], 0.3, thr)
+            k = int(rec['count'][i])
+            assert k == len(src), (thr, i, k, len(src))
+            np.testing.assert_array_equal(rec['index'][i, :k].cpu().numpy().astype(np.int64), src)
+    # sanity of the construction: image 0 at thr 0.2 keeps every other box (a 400-link dependency chain)
+    assert int(ops.postprocess(torch.from_numpy(b[:1]).to(dev), torch.from_numpy(c[:1]).to(dev),
+                               torch.from_numpy(s[:1]).to(dev), 0.3, 0.2)['count'][0]) == n // 2
+
+
 def test_nms_standalone_and_to_original(dev, golden):
     from mydetection_amd.utils.structures import ImageObjects
     from oracle import postprocess as pp
