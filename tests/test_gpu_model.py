@@ -295,3 +295,22 @@ def test_full_size_properties_batch32_640(model):
         k = int(cnt[i])
         assert k == len(src)
         np.testing.assert_array_equal(rec['index'][i, :k].cpu().numpy().astype(np.int64), src)
+
+
+def test_hipgraph_replay_equals_eager(model):
+    """GraphedPath (one hipGraph for forward + post-process, incl. the split-K / stream-K workspace traffic and the
+    fixup launches): replays equal the eager records bit for bit, for the captured batch and for a new one."""
+    from mydetection_amd import synth
+    from mydetection_amd.graph import GraphedPath
+    from mydetection_amd.utils.structures import batched_post_process
+    m, cfg = model
+    x0 = synth.make_images(4, 320, seed=21).cuda()
+    x1 = synth.make_images(4, 320, seed=22).cuda()
+    run = GraphedPath(m, x0, 0.005, 0.45)
+    for x in (x0, x1, x0):
+        rec = {k: v.clone() for k, v in run(x).items()}
+        with torch.no_grad():
+            ref = batched_post_process(*m.forward_candidates(x), 0.005, 0.45)
+        assert int(ref['count'].sum()) > 0
+        for k in ('count', 'index', 'class_idx', 'score', 'bbox'):
+            assert torch.equal(rec[k], ref[k]), k
