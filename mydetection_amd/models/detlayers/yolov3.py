@@ -37,17 +37,19 @@ class YOLOLayer(nn.Module):
         assert t_xywh.shape[1] == nA and t_xywh.shape[-1] == 4
         assert self.n_cls > 0
         packed = getattr(raw, 'packed', None)
-        if packed is not None:
-            head, ld, per, _ = packed['box']
+        if packed is not None:          # the head's own pixel-major tensors (YOLOHead: one; EfDetHead: box + class)
+            box, ldb, bas, bc0 = packed['box']
+            cls, ldc, cas, cc0, conf0 = packed['cls']
         else:
-            head, ld, per = pack_pixel_major([raw['bbox'], raw['conf'], raw['class']], nA)
+            box, ldb, bas = pack_pixel_major([raw['bbox'], raw['conf'], raw['class']], nA)
+            cls, ldc, cas, bc0, cc0, conf0 = box, ldb, bas, 0, 5, 4
         n = nA * nH * nW
         if _out is None:
-            bbox, cls_idx, score = alloc_outputs(nB, n, head.device)
+            bbox, cls_idx, score = alloc_outputs(nB, n, box.device)
             n_off = 0
         else:
             bbox, cls_idx, score, n_off = _out
-        ops.decode(ops.DECODE_YOLO, head, ld, per, 0, head, ld, per, 5, 4, self.anchors.numpy(), nA, self.n_cls,
+        ops.decode(ops.DECODE_YOLO, box, ldb, bas, bc0, cls, ldc, cas, cc0, conf0, self.anchors.numpy(), nA, self.n_cls,
                    nB, nH, nW, self.stride, tuple(img_size), bbox, cls_idx, score, n_off)
         preds = {
             'bbox': bbox[:, n_off:n_off + n],
@@ -61,8 +63,9 @@ class YOLOLayer(nn.Module):
         packed = getattr(raw, 'packed', None)
         if packed is None:
             return None
-        head, ld, per, _ = packed['box']
+        box, ldb, bas, bc0 = packed['box']
+        cls, ldc, cas, cc0, conf0 = packed['cls']
         nH, nW = raw['bbox'].shape[2:4]
-        return {'mode': ops.DECODE_YOLO, 'layout': (per, 0, per, 5, 4), 'A': self.num_anchors, 'C': self.n_cls,
-                'level': {'box': head, 'ldbox': ld, 'cls': head, 'ldcls': ld, 'anchors_wh': self.anchors.numpy(),
+        return {'mode': ops.DECODE_YOLO, 'layout': (bas, bc0, cas, cc0, conf0), 'A': self.num_anchors, 'C': self.n_cls,
+                'level': {'box': box, 'ldbox': ldb, 'cls': cls, 'ldcls': ldc, 'anchors_wh': self.anchors.numpy(),
                           'H': nH, 'W': nW, 'stride': self.stride}}

@@ -200,6 +200,12 @@ def raw_dicts(head_outs, n_anchor, n_cls, enable_conf):
     return raws
 
 
+# configs/d1_yv3.json:31-41 (anchor_indices are consecutive triples)
+D1_YV3_ANCHORS = [[12.6, 13.2], [23.5, 38.1], [57.3, 32.3], [42.9, 75.5], [106.6, 61.2], [60.4, 123.5],
+                  [84.5, 191.6], [131.9, 123.9], [212.4, 85.6], [125.4, 278.9], [179.6, 196.4], [347.0, 107.1],
+                  [272.3, 199.2], [238.8, 321.5], [373.1, 258.9]]
+
+
 def forward(x, sd, config):
     """config in {'efficientdet-d1', 'd1_fcs2_atss', 'd1_fcs2', 'd1_fcs'} -> (bbox [B,N,4], class_idx [B,N],
     score [B,N]).  d1_fcs2 is d1_fcs2_atss at inference (models/detlayers/fcos2.py:24-69 == :222-251)."""
@@ -210,6 +216,13 @@ def forward(x, sd, config):
         for lvl, (c, b, ct) in enumerate(head_with_center(feats, sd)):
             raw = {'bbox': b.permute(0, 2, 3, 1), 'conf': ct.permute(0, 2, 3, 1), 'class': c.permute(0, 2, 3, 1)}
             outs.append(decoders.fcos_decode(raw, img, STRIDES[lvl]))
+        return tuple(torch.cat([o[j] for o in outs], dim=1) for j in range(3))
+    if config == 'd1_yv3':          # EfDetHead (3 anchors, conf = class channel 0) + YOLOLayer on 5 levels
+        feats = bifpn(backbone(x, sd, c6c7='maxpool'), sd)
+        outs = []
+        for lvl, raw in enumerate(raw_dicts(head(feats, sd), 3, 80, True)):
+            anch = torch.tensor(D1_YV3_ANCHORS[3 * lvl:3 * lvl + 3], dtype=torch.float32)
+            outs.append(decoders.yolo_decode_raw(raw, STRIDES[lvl], anch))
         return tuple(torch.cat([o[j] for o in outs], dim=1) for j in range(3))
     atss = config in ('d1_fcs2_atss', 'd1_fcs2')
     feats = bifpn(backbone(x, sd, c6c7='conv' if atss else 'maxpool'), sd)

@@ -292,3 +292,5 @@ if __name__ == '__main__':
     if 'fcos_variants' in which:        # registry plug-ins 'FCOS2' and 'effrpn_ct' + 'FCOS' 
         gen_efficientdet('d1_fcs2')
         gen_efficientdet('d1_fcs')
+    if 'd1_yv3' in which:               # EfDetHead decoded by the YOLO layer (registry composition)
+        gen_efficientdet('d1_yv3')

@@ -130,8 +130,8 @@ def test_detector_api(model, tmp_path):
         det.detect_one(pil_img=PIL.Image.fromarray(img), preprocessing='bogus')
 
 
-# ------------------- EfficientDet-D1 / D1-FCOS2-ATSS, and the registry plug-ins 'FCOS2' (d1_fcs2), 'effrpn_ct' + 'FCOS' (d1_fcs)
-@pytest.fixture(scope='module', params=['efficientdet-d1', 'd1_fcs2_atss', 'd1_fcs2', 'd1_fcs'])
+# ------------------- EfficientDet-D1 / D1-FCOS2-ATSS, and the registry plug-ins 'FCOS2' (d1_fcs2), 'effrpn_ct' + 'FCOS' (d1_fcs), EfDetHead + 'YOLO' (d1_yv3)
+@pytest.fixture(scope='module', params=['efficientdet-d1', 'd1_fcs2_atss', 'd1_fcs2', 'd1_fcs', 'd1_yv3'])
 def effdet(request):
     assert torch.cuda.is_available()
     from mydetection_amd import synth
@@ -190,18 +190,21 @@ def test_effdet_family_vs_oracle_640(effdet):
         ob, oc, os_ = oe.forward(x, sd, name)
         ob64, _, os64 = oe.forward(x.double(), sd64, name)
         bb, ci, sc = m.forward_candidates(x.cuda())
-    assert bb.shape == ob.shape and bb.shape[1] == (76725 if name == 'efficientdet-d1' else 8525)
+    assert bb.shape == ob.shape and bb.shape[1] == {'efficientdet-d1': 76725, 'd1_yv3': 25575}.get(name, 8525)
     sc, bb = sc.cpu().double(), bb.cpu().double()
+    # box errors relative to the box scale: the YOLO decode (d1_yv3) is exp(t)*anchor, unclamped, and a few synthetic
+    # logits make boxes of 1e6 pixels whose float32 round-off alone is pixels wide
+    bscale = 1.0 + ob64.abs() / 640.0
     err_gpu_s, err_cpu_s = (sc - os64).abs().max().item(), (os_.double() - os64).abs().max().item()
-    err_gpu_b, err_cpu_b = (bb - ob64).abs().max().item(), (ob.double() - ob64).abs().max().item()
+    err_gpu_b, err_cpu_b = ((bb - ob64).abs() / bscale).max().item(), ((ob.double() - ob64).abs() / bscale).max().item()
     # max errors are extreme-value statistics of round-off noise: 3x slack on the max, 1.5x on the rms
     assert err_gpu_s <= max(ATOL, 3.0 * err_cpu_s), (err_gpu_s, err_cpu_s)
     assert err_gpu_b <= max(2e-3, 3.0 * err_cpu_b), (err_gpu_b, err_cpu_b)
     rms = lambda t: t.pow(2).mean().sqrt().item()                # noqa: E731
     assert rms(sc - os64) <= 1.5 * rms(os_.double() - os64) + 1e-7
-    assert rms(bb - ob64) <= 1.5 * rms(ob.double() - ob64) + 1e-6
+    assert rms((bb - ob64) / bscale) <= 1.5 * rms((ob.double() - ob64) / bscale) + 1e-6
     bad = ((sc - os_.double()).abs() > ATOL + RTOL * os_.double().abs()).sum().item()
-    assert bad <= 8, f'{bad} scores differ from the float32 oracle by more than 1e-4'
+    assert bad <= max(8, sc.numel() // 2500), f'{bad} scores differ from the float32 oracle by more than 1e-4'
     assert (ci.cpu() != oc).sum().item() <= bb.shape[1] // 2000 + 2
 
 

@@ -129,7 +129,7 @@ def test_yolov3_post_process_matches_reference(yolov3_oracle_run):
         np.testing.assert_allclose(b, g[f'pp_{tag}_bboxes_0'], rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize('config', ['efficientdet-d1', 'd1_fcs2_atss', 'd1_fcs2', 'd1_fcs'])
+@pytest.mark.parametrize('config', ['efficientdet-d1', 'd1_fcs2_atss', 'd1_fcs2', 'd1_fcs', 'd1_yv3'])
 def test_efficientdet_family_matches_reference(golden, config):
     """Oracle restatement of EfficientNet-B1 + BiFPN + EfDetHead + decode vs the imported reference."""
     from mydetection_amd.models.general import state_dict_template
