@@ -154,19 +154,23 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_wino_kernel(con
     const int wc = wave & 3, wt = wave >> 2;           // compute role: channels 16*wc.., tiles 32*wt..32*wt+31
     const int fr = lane & 15, fq = lane >> 4;
     const int slot = wave * 8 + (lane >> 3), kc = lane & 7;   // staging role: tile, channel of the slab
-  while (it < it_end) {
-    const int item = (int)(it / nk), k_lo = (int)(it - (int64_t)item * nk);
-    const int k_hi = (int64_t)nk - k_lo < it_end - it ? nk : k_lo + (int)(it_end - it);
-    const int m0 = (item / p.ntn) * TILES, n0 = (item % p.ntn) * CH;
-    const int b0 = m0 / tpi;
-
-    // ---- staging: every thread brings one channel of one tile's patch (16 dwords) and NU float4 of weights
-    const int64_t img = (int64_t)p.H * p.W * p.ldx;
-    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x + b0 * img, (p.B - b0) * img * 4);
+    // Per-piece state.  `setup` derives it for the piece starting at slab iteration `at`; the stream-K loop calls it for
+    // the NEXT piece before the epilogue of the current one, so that piece's first slab is already in flight.
+    int item, k_lo, k_hi, m0, n0, b0;
+    __amdgpu_buffer_rsrc_t xr;
     const __amdgpu_buffer_rsrc_t ur = make_rsrc(p.u, (int64_t)p.Cin * 16 * p.CoutP * 4);
-    // a wave covers 8 tiles x the 8 channels of the slab: one 32-byte run per patch pixel and load instruction
-    unsigned off[16];
-    {
+    unsigned off[16], uoff;
+    auto setup = [&](int64_t at) {
+        item = (int)(at / nk);
+        k_lo = (int)(at - (int64_t)item * nk);
+        k_hi = (int64_t)nk - k_lo < it_end - at ? nk : k_lo + (int)(it_end - at);
+        m0 = (item / p.ntn) * TILES;
+        n0 = (item % p.ntn) * CH;
+        b0 = m0 / tpi;
+        // staging: every thread brings one channel of one tile's patch (16 dwords) and NU float4 of weights; a wave
+        // covers 8 tiles x the 8 channels of the slab: one 32-byte run per patch pixel and load instruction
+        const int64_t img = (int64_t)p.H * p.W * p.ldx;
+        xr = make_rsrc(p.x + b0 * img, (p.B - b0) * img * 4);
         const int mt = m0 + slot;
         const int mm = mt < p.MT ? mt : p.MT - 1;
         const int b = mm / tpi, r = mm - b * tpi, ty = r / p.TW, tx = r - ty * p.TW;
@@ -179,13 +183,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_wino_kernel(con
                 const bool ok = mt < p.MT && (unsigned)(iy0 + i) < (unsigned)p.H && (unsigned)(ix0 + j) < (unsigned)p.W;
                 off[i * 4 + j] = ok ? (unsigned)(base + (int)(((int64_t)i * p.W + j) * p.ldx * 4)) : OOB;
             }
-    }
+        uoff = (unsigned)(((tid >> 6) * p.CoutP + n0 + (tid & 63)) * 16);   // U slab float4 q*64*NW + tid
+    };
     // V slab element (pair, quarter kq = kc/2, tile): this thread owns components {2s, 2s+1}, s = kc & 1.  The tile
     // column is XOR-swizzled with 2*kq: the ds_write_b64 lane groups (2 tiles x 8 channels) and the ds_read_b128
     // lane groups (8 + 8 tiles of two adjacent quarters) then both touch every bank once.
     const unsigned wr_v = U_BYTES + (unsigned)((kc >> 1) * V_KS + ((slot ^ (kc & 6)) * 16) + (kc & 1) * 8);
-    // U slab float4 q*64*NW + tid: global and LDS order coincide
-    const unsigned uoff = (unsigned)(((tid >> 6) * p.CoutP + n0 + (tid & 63)) * 16);
+    // (U slab float4 q*64*NW + tid: global and LDS order coincide)
     const unsigned ustep = __builtin_amdgcn_readfirstlane(16u * NW * (unsigned)p.CoutP);   // bytes between q and q+1
     const unsigned wr_u = (unsigned)tid * 16u;
 
@@ -194,10 +198,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_wino_kernel(con
     const unsigned rd_v = U_BYTES + (unsigned)(fq * V_KS + ((wt * 32 + fr) ^ (2 * fq)) * 16);   // + pair * V_PS, + 256: block 1
 
     f32x4 acc[16][2];
-#pragma unroll
-    for (int q = 0; q < 16; ++q)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) acc[q][e] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     float gv[16];
     f32x4 gu[DMA ? 1 : NU];
@@ -257,7 +257,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_wino_kernel(con
                         fu[st][2 * s + e], fv[st][blk][2 * s + e], acc[2 * pp + e][blk], 0, 0, 0);
     };
 
+    setup(it);
     load_slab(k_lo, smem + (DB ? (k_lo & 1) * SLAB : 0));
+  while (true) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) acc[q][e] = f32x4{0.f, 0.f, 0.f, 0.f};
     store_slab(smem + (DB ? (k_lo & 1) * SLAB : 0));
     if (DMA) __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): the LDS-direct weight loads have landed
     __syncthreads();
@@ -304,14 +310,22 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_wino_kernel(con
         out[blk][2] = s1[0] + s1[1] + s1[2];
         out[blk][3] = s1[1] - s1[2] - s1[3];
     }
-    if (!SK || (k_lo == 0 && k_hi == nk)) {
-        wino_epilogue<ACT, RES>(p, out, m0, n0, b0, wc, wt, fr, fq);
+    const bool whole = !SK || (k_lo == 0 && k_hi == nk), starts = k_lo == 0;
+    const int cm0 = m0, cn0 = n0, cb0 = b0;
+    it += k_hi - k_lo;
+    const bool more = SK && it < it_end;
+    if (more) {                                        // next piece: its first slab flies under this epilogue
+        setup(it);
+        load_slab(k_lo, smem + (DB ? (k_lo & 1) * SLAB : 0));
+    }
+    if (whole) {
+        wino_epilogue<ACT, RES>(p, out, cm0, cn0, cb0, wc, wt, fr, fq);
     } else {                                           // partial K: [float4 j][thread], summed by the fixup launch
-        f32x4 *dst = reinterpret_cast<f32x4 *>(p.ws) + (int64_t)(2 * lid + (k_lo == 0 ? 1 : 0)) * 8 * (64 * NW) + tid;
+        f32x4 *dst = reinterpret_cast<f32x4 *>(p.ws) + (int64_t)(2 * lid + (starts ? 1 : 0)) * 8 * (64 * NW) + tid;
 #pragma unroll
         for (int j = 0; j < 8; ++j) dst[j * (64 * NW)] = out[j >> 2][j & 3];
     }
-    it += k_hi - k_lo;
+    if (!more) break;
   }
 }
 
