@@ -126,10 +126,11 @@ __device__ __forceinline__ void wino_epilogue(const WinoArgs &p, const f32x4 (&o
 //         current slab's MFMAs, so in steady state the matrix pipe only idles across that barrier.
 //
 // SK = false: one workgroup per item (item = 8*NW tiles x 64 channels), all of K.
-// SK = true : stream-K.  The grid is one resident round of persistent workgroups; workgroup w owns the slab
-//         iterations [w*T/G, (w+1)*T/G) of the item-major, K-minor sequence, so every workgroup does the same
-//         amount of matrix work (no partial last round) and the workgroups meet their epilogues -- the HBM-bound
-//         part of a layer -- at different times.  A piece that covers only part of an item's K leaves its partial
+// SK = true : data-parallel rounds + stream-K tail.  The grid is one resident round of G persistent workgroups;
+//         each takes floor(items / G) whole items in grid order, and the remaining items (the partial last round
+//         of the plain grid) are cut along K: workgroup w owns the slab iterations [w*T/G, (w+1)*T/G) of their
+//         item-major, K-minor sequence, so every workgroup does the same amount of matrix work.
+//         A piece that covers only part of an item's K leaves its partial
 //         outputs in the workspace; conv_wino_fixup_kernel sums the pieces of such items in K order and applies the
 //         epilogue (deterministic, no atomics, no waiting inside the kernel).
 template <int ACT, bool RES, int NW, bool SK>
@@ -148,9 +149,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_wino_kernel(con
     const int lid = mydet_xcd_remap(blockIdx.x, SK ? p.nwg : p.nblk);
     const int tpi = p.TH * p.TW;                       // tiles per image
     const int nk = p.Cin >> 3;
-    const int64_t total = (int64_t)p.nblk * nk;
-    int64_t it = SK ? sk_begin(lid, total, p.nwg) : (int64_t)lid * nk;
-    const int64_t it_end = SK ? sk_begin(lid + 1, total, p.nwg) : it + nk;
+    // SK: `rounds` whole items per workgroup in grid order (item = round * G + lid: the workgroups of an XCD then work
+    // on neighbouring items at the same time, as in the plain grid, and share their patches / weights in its L2), then
+    // an equal share [it, it_end) of the slab iterations of the remaining `nblk - rounds * G` items
+    const int rounds = SK ? p.nblk / p.nwg : 1;
+    const int tail0 = SK ? rounds * p.nwg : 0;                            // first item of the stream-K tail
+    const int64_t total = (int64_t)(p.nblk - tail0) * nk;
+    int64_t it = SK ? sk_begin(lid, total, p.nwg) : 0;
+    const int64_t it_end = SK ? sk_begin(lid + 1, total, p.nwg) : 0;
+    int round = 0;
     const int wc = wave & 3, wt = wave >> 2;           // compute role: channels 16*wc.., tiles 32*wt..32*wt+31
     const int fr = lane & 15, fq = lane >> 4;
     const int slot = wave * 8 + (lane >> 3), kc = lane & 7;   // staging role: tile, channel of the slab
@@ -160,10 +167,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_wino_kernel(con
     __amdgpu_buffer_rsrc_t xr;
     const __amdgpu_buffer_rsrc_t ur = make_rsrc(p.u, (int64_t)p.Cin * 16 * p.CoutP * 4);
     unsigned off[16], uoff;
-    auto setup = [&](int64_t at) {
-        item = (int)(at / nk);
-        k_lo = (int)(at - (int64_t)item * nk);
-        k_hi = (int64_t)nk - k_lo < it_end - at ? nk : k_lo + (int)(it_end - at);
+    auto setup = [&]() -> bool {                       // next piece of this workgroup, false when there is none
+        if (round < rounds) {
+            item = SK ? round * p.nwg + lid : lid;
+            k_lo = 0; k_hi = nk;
+            ++round;
+        } else if (SK && it < it_end) {
+            const int ti = (int)(it / nk);
+            item = tail0 + ti;
+            k_lo = (int)(it - (int64_t)ti * nk);
+            k_hi = (int64_t)nk - k_lo < it_end - it ? nk : k_lo + (int)(it_end - it);
+            it += k_hi - k_lo;
+        } else {
+            return false;
+        }
         m0 = (item / p.ntn) * TILES;
         n0 = (item % p.ntn) * CH;
         b0 = m0 / tpi;
@@ -184,6 +201,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_wino_kernel(con
                 off[i * 4 + j] = ok ? (unsigned)(base + (int)(((int64_t)i * p.W + j) * p.ldx * 4)) : OOB;
             }
         uoff = (unsigned)(((tid >> 6) * p.CoutP + n0 + (tid & 63)) * 16);   // U slab float4 q*64*NW + tid
+        return true;
     };
     // V slab element (pair, quarter kq = kc/2, tile): this thread owns components {2s, 2s+1}, s = kc & 1.  The tile
     // column is XOR-swizzled with 2*kq: the ds_write_b64 lane groups (2 tiles x 8 channels) and the ds_read_b128
@@ -257,7 +275,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_wino_kernel(con
                         fu[st][2 * s + e], fv[st][blk][2 * s + e], acc[2 * pp + e][blk], 0, 0, 0);
     };
 
-    setup(it);
+    if (!setup()) return;                              // (stream-K grids are never larger than the item count)
     load_slab(k_lo, smem + (DB ? (k_lo & 1) * SLAB : 0));
   while (true) {
 #pragma unroll
@@ -312,12 +330,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_wino_kernel(con
     }
     const bool whole = !SK || (k_lo == 0 && k_hi == nk), starts = k_lo == 0;
     const int cm0 = m0, cn0 = n0, cb0 = b0;
-    it += k_hi - k_lo;
-    const bool more = SK && it < it_end;
-    if (more) {                                        // next piece: its first slab flies under this epilogue
-        setup(it);
+    const bool more = SK && setup();
+    if (more)                                          // next piece: its first slab flies under this epilogue
         load_slab(k_lo, smem + (DB ? (k_lo & 1) * SLAB : 0));
-    }
     if (whole) {
         wino_epilogue<ACT, RES>(p, out, cm0, cn0, cb0, wc, wt, fr, fq);
     } else {                                           // partial K: [float4 j][thread], summed by the fixup launch
@@ -337,10 +352,11 @@ __global__ __launch_bounds__(64 * NW) void conv_wino_fixup_kernel(const WinoArgs
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int w = blockIdx.x + 1;                      // boundary between workgroups w-1 and w
     const int nk = p.nk;
-    const int64_t total = (int64_t)p.nblk * nk;
+    const int tail0 = (p.nblk / p.nwg) * p.nwg;        // the stream-K tail starts after the whole rounds
+    const int64_t total = (int64_t)(p.nblk - tail0) * nk;
     const int64_t cut = sk_begin(w, total, p.nwg);
-    const int item = (int)(cut / nk);
-    const int64_t first = (int64_t)item * nk;
+    const int item = tail0 + (int)(cut / nk);
+    const int64_t first = (cut / nk) * nk;
     if (cut == first || sk_begin(w - 1, total, p.nwg) > first) return;   // no cut here / not the first cut of the item
     const f32x4 *ws = reinterpret_cast<const f32x4 *>(p.ws) + tid;
     f32x4 out[2][4];
