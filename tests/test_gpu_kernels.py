@@ -391,3 +391,37 @@ def test_conv_igemm_split_k_tail(dev, B, Cin, Cout, k, HW):
     assert (y.cpu() - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
     y2 = ops.conv2d(*args, residual=res.to(dev).contiguous(memory_format=torch.channels_last))
     assert torch.equal(y, y2)                                  # deterministic
+
+
+def test_post_process_randomised_sweep_vs_oracle(dev):
+    """40 random workloads (candidate count 0..30 000, 1..90 classes, clustered boxes so that many IoUs sit near the
+    threshold, quantised scores so that ties are common, thresholds drawn at random): kept indices, order and
+    count equal the oracle's bit for bit."""
+    from mydetection_amd import ops
+    from oracle import postprocess as pp
+    rng = np.random.Generator(np.random.PCG64(2024))
+    for trial in range(40):
+        N = int(rng.choice([0, 1, 7, 513, 2000, 9000, 30000]))
+        B = int(rng.integers(1, 4))
+        n_cls = int(rng.choice([1, 3, 20, 90]))
+        n_clusters = int(rng.integers(1, 40))
+        centres = rng.random((n_clusters, 2), dtype=np.float32) * 600
+        which = rng.integers(0, n_clusters, size=(B, N))
+        b = np.empty((B, N, 4), np.float32)
+        b[..., :2] = centres[which] + rng.normal(0, 6, size=(B, N, 2)).astype(np.float32)
+        b[..., 2:] = rng.choice(np.array([24, 32, 48], np.float32), size=(B, N, 2)) + rng.normal(0, 2, size=(B, N, 2)).astype(np.float32)
+        b[..., 2:] = np.abs(b[..., 2:])
+        c = rng.integers(0, n_cls, size=(B, N)).astype(np.int64)
+        s = rng.random((B, N), dtype=np.float32)
+        if trial % 3 == 0:
+            s = np.round(s * 64) / 64                       # heavy score ties
+        conf = float(rng.choice([0.0, 0.005, 0.3, 0.9]))
+        thr = float(rng.choice([0.0, 0.3, 0.45, 0.5, 0.7, 1.0]))
+        rec = ops.postprocess(torch.from_numpy(b).to(dev), torch.from_numpy(c).to(dev), torch.from_numpy(s.astype(np.float32)).to(dev),
+                              conf, thr)
+        for i in range(B):
+            ob, oc, os_, src = pp.post_process(b[i], c[i], s[i].astype(np.float32), conf, thr)
+            k = int(rec['count'][i])
+            assert k == len(src), (trial, i, N, n_cls, conf, thr, k, len(src))
+            np.testing.assert_array_equal(rec['index'][i, :k].cpu().numpy().astype(np.int64), src)
+            np.testing.assert_array_equal(rec['score'][i, :k].cpu().numpy(), os_)
