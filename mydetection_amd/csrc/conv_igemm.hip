@@ -476,6 +476,7 @@ extern "C" int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *
     if ((Cin % 32) != 0 && K <= 256) return launch_cfg(6, a, s);
     if (Cout <= 32) return launch_cfg(2, a, s);
     if (Cout <= 64) return launch_cfg(KH * KW > 1 ? 6 : 1, a, s);
-    if (K <= 1024 || blocks128 < 1024) return launch_cfg(3, a, s);
+    // (3x3 layers with K >= 512 and a big grid already prefer the 8-wave tile: 64->128 stride 2 @320^2 +7 %)
+    if ((K <= 1024 && !(KH * KW > 1 && K >= 512)) || blocks128 < 1024) return launch_cfg(3, a, s);
     return launch_cfg(8, a, s);
 }
