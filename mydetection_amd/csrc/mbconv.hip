@@ -11,6 +11,8 @@
 //                   through nearest 2x upsampling or the 3x3/2 max pool on the fly  models/fpns.py:398-418,433-439
 // Each thread moves one float4 of channels; every tensor byte is read and written once per kernel.
 // Built with -ffp-contract=off so the fusion / gate arithmetic rounds like the reference's separate ops.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -55,6 +57,50 @@ __device__ __forceinline__ void dw_strip(const DwArgs &p, const float *xq, const
     }
 }
 
+// Stride-1 block of TW x 2 outputs (rows oh, oh+1) for one channel quad: K+1 input rows instead of 2K, and each
+// weight row is loaded once and serves both output rows (kept in registers for the next input row).
+template <int K, int TW>
+__device__ __forceinline__ void dw_block2(const DwArgs &p, const float *xq, const float *wq, int oh, int ow0,
+                                          f32x4 (&acc)[2][TW]) {
+    constexpr int NC = TW - 1 + K;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int t = 0; t < TW; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ih0 = oh - p.pad_t, iw0 = ow0 - p.pad_l;
+    f32x4 wprev[K];
+#pragma unroll
+    for (int r = 0; r <= K; ++r) {                     // input row ih0 + r: tap row r of output row 0, r-1 of row 1
+        f32x4 wcur[K];
+        if (r < K) {
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) wcur[kw] = *reinterpret_cast<const f32x4 *>(wq + (r * K + kw) * p.C);
+        }
+        const int ih = ih0 + r;
+        if ((unsigned)ih < (unsigned)p.H) {
+            const float *row = xq + (int64_t)ih * p.W * p.ldx;
+            f32x4 col[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int iw = iw0 + c;
+                col[c] = (unsigned)iw < (unsigned)p.W ? *reinterpret_cast<const f32x4 *>(row + (int64_t)iw * p.ldx)
+                                                      : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                for (int t = 0; t < TW; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (r < K) acc[0][t][j] = fmaf(col[t + kw][j], wcur[kw][j], acc[0][t][j]);
+                        if (r > 0) acc[1][t][j] = fmaf(col[t + kw][j], wprev[kw][j], acc[1][t][j]);
+                    }
+        }
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) wprev[kw] = wcur[kw];
+    }
+}
+
 __device__ __forceinline__ f32x4 dw_epilogue(const DwArgs &p, f32x4 v, int q) {
     if (p.scale) {
         const f32x4 sc = *reinterpret_cast<const f32x4 *>(p.scale + q * 4);
@@ -73,32 +119,43 @@ __device__ __forceinline__ f32x4 dw_epilogue(const DwArgs &p, f32x4 v, int q) {
 }
 
 // plain form: flat grid-stride over (strip, quad) items
-template <int K, int ST, int TW>
+template <int K, int ST, int TW, int TH = 1>
 __global__ __launch_bounds__(256) void dwconv_kernel(const DwArgs p) {
-    const int Q = p.C >> 2, WG = p.Wo / TW;
+    const int Q = p.C >> 2, WG = p.Wo / TW, HG = p.Ho / TH;     // TH = 2: items are TW x 2 blocks (stride 1, Ho even)
     for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < p.total; it += (int64_t)gridDim.x * 256) {
         const int q = (int)(it % Q);
         const int64_t g = it / Q;
         const int owg = (int)(g % WG);
         const int64_t t = g / WG;
-        const int oh = (int)(t % p.Ho);
-        const int64_t b = t / p.Ho;
-        f32x4 acc[TW];
-        dw_strip<K, ST, TW>(p, p.x + (b * p.H * p.W) * p.ldx + q * 4, p.w + q * 4, oh, owg * TW, acc);
-        float *yp = p.y + ((b * p.Ho + oh) * p.Wo + owg * TW) * p.ldy + q * 4;
+        const int ohg = (int)(t % HG);
+        const int64_t b = t / HG;
+        if constexpr (TH == 2) {
+            f32x4 acc[2][TW];
+            dw_block2<K, TW>(p, p.x + (b * p.H * p.W) * p.ldx + q * 4, p.w + q * 4, ohg * 2, owg * TW, acc);
 #pragma unroll
-        for (int tt = 0; tt < TW; ++tt) *reinterpret_cast<f32x4 *>(yp + tt * p.ldy) = dw_epilogue(p, acc[tt], q);
+            for (int r = 0; r < 2; ++r) {
+                float *yp = p.y + ((b * p.Ho + ohg * 2 + r) * p.Wo + owg * TW) * p.ldy + q * 4;
+#pragma unroll
+                for (int tt = 0; tt < TW; ++tt) *reinterpret_cast<f32x4 *>(yp + tt * p.ldy) = dw_epilogue(p, acc[r][tt], q);
+            }
+        } else {
+            f32x4 acc[TW];
+            dw_strip<K, ST, TW>(p, p.x + (b * p.H * p.W) * p.ldx + q * 4, p.w + q * 4, ohg, owg * TW, acc);
+            float *yp = p.y + ((b * p.Ho + ohg) * p.Wo + owg * TW) * p.ldy + q * 4;
+#pragma unroll
+            for (int tt = 0; tt < TW; ++tt) *reinterpret_cast<f32x4 *>(yp + tt * p.ldy) = dw_epilogue(p, acc[tt], q);
+        }
     }
 }
 
 // squeeze-fused form: workgroup (s, b) owns slice s of image b's strips, all channels; besides y it writes
 // partial[b][s][c] = sum of its outputs (deterministic: fixed thread->strip map, fixed reduction order).
-template <int K, int ST, int TW>
+template <int K, int ST, int TW, int TH = 1>
 __global__ __launch_bounds__(256) void dwconv_sum_kernel(const DwArgs p) {
     __shared__ f32x4 red[256];
     const int Q = p.C >> 2, WG = p.Wo / TW;
     const int b = blockIdx.y, s = blockIdx.x;
-    const int NG = p.Ho * WG;
+    const int NG = (p.Ho / TH) * WG;                   // TH = 2: a work item is a TW x 2 block (stride 1, Ho even)
     const int per = (NG + p.S - 1) / p.S;
     const int g0 = s * per, g1 = min(NG, g0 + per);
     const float *xb = p.x + ((int64_t)b * p.H * p.W) * p.ldx;
@@ -110,16 +167,32 @@ __global__ __launch_bounds__(256) void dwconv_sum_kernel(const DwArgs p) {
         f32x4 sum = {0.f, 0.f, 0.f, 0.f};
         if (ph < ph_n)
             for (int g = g0 + ph; g < g1; g += ph_n) {
-                const int oh = g / WG, owg = g - oh * WG;
-                f32x4 acc[TW];
-                dw_strip<K, ST, TW>(p, xb + q * 4, p.w + q * 4, oh, owg * TW, acc);
-                float *yp = yb + ((int64_t)oh * p.Wo + owg * TW) * p.ldy + q * 4;
+                const int ohg = g / WG, owg = g - ohg * WG;
+                if constexpr (TH == 2) {
+                    f32x4 acc[2][TW];
+                    dw_block2<K, TW>(p, xb + q * 4, p.w + q * 4, ohg * 2, owg * TW, acc);
 #pragma unroll
-                for (int tt = 0; tt < TW; ++tt) {
-                    const f32x4 v = dw_epilogue(p, acc[tt], q);
-                    *reinterpret_cast<f32x4 *>(yp + tt * p.ldy) = v;
+                    for (int r = 0; r < 2; ++r) {
+                        float *yp = yb + ((int64_t)(ohg * 2 + r) * p.Wo + owg * TW) * p.ldy + q * 4;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) sum[j] += v[j];
+                        for (int tt = 0; tt < TW; ++tt) {
+                            const f32x4 v = dw_epilogue(p, acc[r][tt], q);
+                            *reinterpret_cast<f32x4 *>(yp + tt * p.ldy) = v;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) sum[j] += v[j];
+                        }
+                    }
+                } else {
+                    f32x4 acc[TW];
+                    dw_strip<K, ST, TW>(p, xb + q * 4, p.w + q * 4, ohg, owg * TW, acc);
+                    float *yp = yb + ((int64_t)ohg * p.Wo + owg * TW) * p.ldy + q * 4;
+#pragma unroll
+                    for (int tt = 0; tt < TW; ++tt) {
+                        const f32x4 v = dw_epilogue(p, acc[tt], q);
+                        *reinterpret_cast<f32x4 *>(yp + tt * p.ldy) = v;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) sum[j] += v[j];
+                    }
                 }
             }
         red[threadIdx.x] = sum;
@@ -357,6 +430,15 @@ inline unsigned grid_for(int64_t total) {
 
 inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
+inline bool block2() {       // MYDET_DW_BLOCK2=0: single-row strips everywhere (tuning / A-B)
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("MYDET_DW_BLOCK2");
+        v = e ? (atoi(e) != 0) : 1;
+    }
+    return v != 0;
+}
+
 }  // namespace
 
 template <int K, int ST>
@@ -366,11 +448,15 @@ int launch_dw(const DwArgs &p0, int B, hipStream_t stream) {
     const int TW = strip4 ? 4 : 1;
     if (p.partial) {
         const dim3 grid(p.S, B);
-        if (strip4) hipLaunchKernelGGL((dwconv_sum_kernel<K, ST, 4>), grid, dim3(256), 0, stream, p);
+        if (strip4 && ST == 1 && (p.Ho & 1) == 0 && block2())
+            hipLaunchKernelGGL((dwconv_sum_kernel<K, 1, 4, 2>), grid, dim3(256), 0, stream, p);
+        else if (strip4) hipLaunchKernelGGL((dwconv_sum_kernel<K, ST, 4>), grid, dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((dwconv_sum_kernel<K, ST, 1>), grid, dim3(256), 0, stream, p);
     } else {
-        p.total = (int64_t)B * p.Ho * (p.Wo / TW) * (p.C >> 2);
-        if (strip4) hipLaunchKernelGGL((dwconv_kernel<K, ST, 4>), dim3(grid_for(p.total)), dim3(256), 0, stream, p);
+        const bool two = strip4 && ST == 1 && (p.Ho & 1) == 0 && block2();
+        p.total = (int64_t)B * (p.Ho / (two ? 2 : 1)) * (p.Wo / TW) * (p.C >> 2);
+        if (two) hipLaunchKernelGGL((dwconv_kernel<K, 1, 4, 2>), dim3(grid_for(p.total)), dim3(256), 0, stream, p);
+        else if (strip4) hipLaunchKernelGGL((dwconv_kernel<K, ST, 4>), dim3(grid_for(p.total)), dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((dwconv_kernel<K, ST, 1>), dim3(grid_for(p.total)), dim3(256), 0, stream, p);
     }
     return mydet_launch_status();
