@@ -93,7 +93,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs &p, f32x16 (&acc)[TM][TN
                 const int dr = (r & 3) + 8 * (r >> 2);
                 float v = acc[i][j][r] * scl + sft;
                 if (ACT == MYDET_ACT_LEAKY) v = v > 0.0f ? v : v * 0.1f;
-                if (ACT == MYDET_ACT_SWISH) v = v * mydet_sigmoid(v);
+                if (ACT == MYDET_ACT_SWISH) v = v * mydet_sigmoid_fast(v);
                 if (RES) v += rv[r];
                 const bool ok = FULL || (nok && mrow + dr < p.M);
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr,

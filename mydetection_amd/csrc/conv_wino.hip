@@ -112,7 +112,7 @@ __device__ __forceinline__ void wino_epilogue(const WinoArgs &p, const f32x4 (&o
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (ACT == MYDET_ACT_LEAKY) v[e] = v[e] > 0.0f ? v[e] : v[e] * 0.1f;
-                if (ACT == MYDET_ACT_SWISH) v[e] = v[e] * mydet_sigmoid(v[e]);
+                if (ACT == MYDET_ACT_SWISH) v[e] = v[e] * mydet_sigmoid_fast(v[e]);
             }
             if (RES) v += rv[blk][o];
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, yo[blk][o], 0, 0);

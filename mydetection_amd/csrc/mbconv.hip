@@ -110,7 +110,7 @@ __device__ __forceinline__ f32x4 dw_epilogue(const DwArgs &p, f32x4 v, int q) {
     }
     if (p.act == MYDET_ACT_SWISH) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = v[j] * mydet_sigmoid(v[j]);
+        for (int j = 0; j < 4; ++j) v[j] = v[j] * mydet_sigmoid_fast(v[j]);
     } else if (p.act == MYDET_ACT_LEAKY) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * 0.1f;
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void bifpn_fuse_kernel(const FuseArgs p) {
             for (int j = 0; j < 4; ++j) acc[j] = acc[j] + w2 * v2[j];
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = acc[j] * mydet_sigmoid(acc[j]);
+        for (int j = 0; j < 4; ++j) acc[j] = acc[j] * mydet_sigmoid_fast(acc[j]);
         *reinterpret_cast<f32x4 *>(p.y + pix * p.ldy + q * 4) = acc;
     }
 }
