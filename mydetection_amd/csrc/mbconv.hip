@@ -284,23 +284,43 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float *partial, int 
     for (int c = tid; c < C; c += 256) mean[c] = mb[c];
     __syncthreads();
     const int wave = tid >> 6, lane = tid & 63;
-    for (int o = wave; o < Cse; o += 4) {             // reduce conv: wave per output channel
-        const float *wr = w1 + (int64_t)o * C;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    // reduce conv: a wave per output channel, four output channels in flight at a time (independent load / fma
+    // streams; each channel's own summation order is what it was one at a time)
+    for (int o0 = wave; o0 < Cse; o0 += 16) {
+        float a[4][4];
+        const float *wr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int o = o0 + 4 * u < Cse ? o0 + 4 * u : o0;          // surplus slots redo o0, result discarded
+            wr[u] = w1 + (int64_t)o * C;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) a[u][v] = 0.f;
+        }
         int c = lane;
         for (; c + 192 < C; c += 256) {
-            a0 = fmaf(wr[c], mean[c], a0);
-            a1 = fmaf(wr[c + 64], mean[c + 64], a1);
-            a2 = fmaf(wr[c + 128], mean[c + 128], a2);
-            a3 = fmaf(wr[c + 192], mean[c + 192], a3);
-        }
-        for (; c < C; c += 64) a0 = fmaf(wr[c], mean[c], a0);
-        float acc = (a0 + a1) + (a2 + a3);
+            const float m0 = mean[c], m1 = mean[c + 64], m2 = mean[c + 128], m3 = mean[c + 192];
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-        if (lane == 0) {
-            acc += b1[o];
-            hid[o] = acc * mydet_sigmoid(acc);
+            for (int u = 0; u < 4; ++u) {
+                a[u][0] = fmaf(wr[u][c], m0, a[u][0]);
+                a[u][1] = fmaf(wr[u][c + 64], m1, a[u][1]);
+                a[u][2] = fmaf(wr[u][c + 128], m2, a[u][2]);
+                a[u][3] = fmaf(wr[u][c + 192], m3, a[u][3]);
+            }
+        }
+        for (; c < C; c += 64) {
+            const float m0 = mean[c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u][0] = fmaf(wr[u][c], m0, a[u][0]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float acc = (a[u][0] + a[u][1]) + (a[u][2] + a[u][3]);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+            if (lane == 0 && o0 + 4 * u < Cse) {
+                acc += b1[o0 + 4 * u];
+                hid[o0 + 4 * u] = acc * mydet_sigmoid(acc);
+            }
         }
     }
     __syncthreads();
