@@ -6,9 +6,9 @@
 // design goal is few dependent steps:
 //   1. filter: one coalesced sweep of score[N]; passing candidates become unique 64-bit
 //      keys (sortable score bits << 32 | ~index) compacted into an HBM scratch strip.
-//   2. top-k (only if more than k pass): the k-th largest key is found bit by bit (ballot/popcount
-//      counting, stops as soon as a threshold cuts off exactly k keys) -- no sort of the N candidates.  Key order = score desc, index asc,
-//      which fixes the tie order torch.topk leaves unspecified.
+//   2. top-k (only if more than k pass): the k-th largest key is found by 4096-bin histogram rounds over its bits
+//      from the top, then bit by bit on the few keys left -- no sort of the N candidates.  Key order = score desc,
+//      index asc, which fixes the tie order torch.topk leaves unspecified.
 //   3. bitonic sort of the <= 512 selected in LDS by (class asc, score desc, index asc):
 //      this is the reference's output order (per-class loop over sorted unique labels,
 //      utils/structures.py:158-167, each class in stable score order), and it makes
@@ -99,48 +99,132 @@ __global__ __launch_bounds__(NT) void postprocess_kernel(const PPArgs p) {
     // scratch written above is re-read by other threads of this workgroup only
     __threadfence_block();
 
-    // 2. k-th largest key, built bit by bit from the top: with candidate = prefix | bit, count(key >= candidate)
-    //    says whether the k-th largest has that bit.  Counting is a ballot + popcount per wave and ONE LDS add per
-    //    wave (no histogram: scores share their exponent bytes, a byte histogram would serialise on a few bins).
-    //    Stops as soon as a candidate cuts off exactly k keys.  The first 16 keys of a thread stay in registers.
+    // 2. k-th largest key (only if more than k pass).  4096-bin histogram rounds fix its bits twelve at a time from the
+    //    top (one LDS atomic per key that still matches, a block-wide suffix scan finds the bin holding the wanted
+    //    rank) until at most 1024 keys share the prefix -- two rounds for distinct scores, up to five when thousands
+    //    of candidates tie on one score and only the index bits tell them apart.  Those keys are compacted into LDS
+    //    and the remaining bits are built bit by bit on the list (ballot + popcount counting, stops as soon as a
+    //    candidate cuts off exactly the wanted number).  The first 16 keys of a thread stay in registers; the others
+    //    are re-read with eight loads in flight.
     unsigned long long kth = 0;
     if (n > p.topk) {
-        constexpr int RK = 16;
+        constexpr int RK = 16, LIST = 1024;
+        __shared__ int s_wtot[NT / 64], s_sel[3], s_m;
+        unsigned *hist = reinterpret_cast<unsigned *>(s_mask);                 // 4096 bins (s_mask is free until step 4)
+        unsigned long long *list = s_mask + 2048;                              // LIST keys behind the histogram
         unsigned long long rk[RK];
 #pragma unroll
         for (int j = 0; j < RK; ++j) rk[j] = tid + j * NT < n ? keys[tid + j * NT] : 0ull;
+        const int wave = tid >> 6, lane = tid & 63;
+        // keys beyond the register-resident ones: eight independent loads in flight, then `f` on each
+        auto for_tail = [&](auto &&f) {
+            for (int base = tid + RK * NT; base < n; base += 8 * NT) {
+                unsigned long long kk[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) kk[u] = base + u * NT < n ? keys[base + u * NT] : 0ull;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (base + u * NT < n) f(kk[u]);
+            }
+        };
+        unsigned long long prefix = 0;
+        int need = p.topk;                                  // rank of the wanted key among the keys matching `prefix`
+        int low = 64;                                       // bits of `prefix` not fixed yet
+        for (int level = 0; level < 5; ++level) {
+            const int shift = 52 - 12 * level;
+            for (int i = tid; i < 4096; i += NT) hist[i] = 0u;
+            __syncthreads();
+            auto tally = [&](unsigned long long k) {
+                if (level == 0 || (k >> low) == (prefix >> low)) atomicAdd(&hist[(unsigned)(k >> shift) & 4095u], 1u);
+            };
+#pragma unroll
+            for (int j = 0; j < RK; ++j)
+                if (tid + j * NT < n) tally(rk[j]);
+            for_tail(tally);
+            __syncthreads();
+            // thread t owns bins 4t..4t+3; suffix sums over the threads above it locate the bin of rank `need`
+            const unsigned c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+            const int own = (int)(c0 + c1 + c2 + c3);
+            int suf = own;                                   // inclusive suffix sum inside the wave
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_down(suf, off);
+                if (lane + off < 64) suf += v;
+            }
+            if (lane == 0) s_wtot[wave] = suf;
+            __syncthreads();
+            int above = suf - own;                           // keys in bins above this thread's four
+            for (int w = wave + 1; w < NT / 64; ++w) above += s_wtot[w];
+            if (above < need && above + own >= need) {       // exactly one thread
+                const unsigned c[4] = {c0, c1, c2, c3};
+                int a = above, bsel = 0;
+#pragma unroll
+                for (int q = 3; q >= 0; --q) {
+                    if (a < need && a + (int)c[q] >= need) { bsel = q; break; }
+                    a += (int)c[q];
+                }
+                s_sel[0] = 4 * tid + bsel;
+                s_sel[1] = a;
+                s_sel[2] = (int)c[bsel];
+            }
+            __syncthreads();
+            prefix |= (unsigned long long)(unsigned)s_sel[0] << shift;
+            need -= s_sel[1];
+            low = shift;
+            const int in_bin = s_sel[2];
+            __syncthreads();
+            if (in_bin <= LIST) break;                       // uniform; after five rounds low = 4: at most 16 keys match
+        }
+        // keys sharing the fixed prefix -> LDS list (at most LIST of them)
+        if (tid == 0) s_m = 0;
         if (tid < 3) s_cnt[tid] = 0;
         __syncthreads();
-        unsigned long long prefix = 0;
-        for (int bit = 63, it = 0; bit >= 0; --bit, ++it) {
-            const unsigned long long cand = prefix | (1ull << bit);
-            int c = 0;
+        auto collect = [&](unsigned long long k) {
+            if ((k >> low) == (prefix >> low)) {
+                const int pos = atomicAdd(&s_m, 1);
+                list[pos < LIST ? pos : LIST - 1] = k;
+            }
+        };
 #pragma unroll
-            for (int j = 0; j < RK; ++j) c += rk[j] >= cand ? 1 : 0;
-            for (int i = tid + RK * NT; i < n; i += NT) c += keys[i] >= cand ? 1 : 0;
+        for (int j = 0; j < RK; ++j)
+            if (tid + j * NT < n) collect(rk[j]);
+        for_tail(collect);
+        __syncthreads();
+        const int m = s_m;
+        const unsigned long long lk = tid < m ? list[tid] : 0ull;
+        for (int bit = low - 1, it = 0; bit >= 0; --bit, ++it) {
+            const unsigned long long cand = prefix | (1ull << bit);
+            int c = tid < m && lk >= cand ? 1 : 0;
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
-            if ((tid & 63) == 0) atomicAdd(&s_cnt[it % 3], c);
+            if (lane == 0) atomicAdd(&s_cnt[it % 3], c);
             if (tid == 0) s_cnt[(it + 1) % 3] = 0;
             __syncthreads();
             const int cnt = s_cnt[it % 3];
-            if (cnt >= p.topk) prefix = cand;
-            if (cnt == p.topk) break;
+            if (cnt >= need) prefix = cand;
+            if (cnt == need) break;
         }
         kth = prefix;
+        __syncthreads();                                    // s_mask is reused by step 4
     }
 
     // 3. gather the selected, build (class, ~score, index) keys, sort
     for (int i = tid; i < KMAX; i += NT) s_key[i] = ~0ull;
     __syncthreads();
-    for (int i = tid; i < n; i += NT) {
-        const unsigned long long k = keys[i];
-        if (k >= kth) {
-            const int pos = atomicAdd(&s_nsel, 1);
-            const unsigned idx = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
-            const unsigned su = (unsigned)(k >> 32);
-            const unsigned long long c = (unsigned long long)ci[idx] & 0x7FFFull;
-            s_key[pos] = (c << 49) | ((unsigned long long)(~su) << IDX_BITS) | (unsigned long long)idx;
+    for (int base = tid; base < n; base += 8 * NT) {         // eight independent key loads in flight
+        unsigned long long kk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) kk[u] = base + u * NT < n ? keys[base + u * NT] : 0ull;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned long long k = kk[u];
+            if (base + u * NT < n && k >= kth) {
+                const int pos = atomicAdd(&s_nsel, 1);
+                const unsigned idx = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
+                const unsigned su = (unsigned)(k >> 32);
+                const unsigned long long c = (unsigned long long)ci[idx] & 0x7FFFull;
+                s_key[pos] = (c << 49) | ((unsigned long long)(~su) << IDX_BITS) | (unsigned long long)idx;
+            }
         }
     }
     __syncthreads();
