@@ -20,7 +20,7 @@ class Detector():
     '''Wrapper for image object detectors
 
     Args:
-        model_name: str, see the configs/ folder for available names
+        model_name: str, see mydetection_amd.configs.NAMES for available names
         model_and_cfg: (model, cfg) built elsewhere
         weights_path: checkpoint with a 'model' state_dict (reference key names)
         cpu: must be False -- this package has no CPU path

@@ -10,8 +10,14 @@ from ..utils.structures import ImageObjects
 
 
 def load_config(model_name):
-    from .. import PROJECT_ROOT
-    return json.load(open(f'{PROJECT_ROOT}/configs/{model_name}.json', 'r'))
+    """The flat cfg dict of `model_name`: a maintainer's own `configs/<model_name>.json` under the project root when
+    there is one (the reference's convention, models/general.py:12-16), otherwise the built-in table."""
+    import os
+    from .. import PROJECT_ROOT, configs
+    path = f'{PROJECT_ROOT}/configs/{model_name}.json'
+    if os.path.exists(path):
+        return json.load(open(path, 'r'))
+    return configs.get(model_name)
 
 
 def name_to_model(model_name):

@@ -1,109 +1,106 @@
 """String-keyed plug-in factories: the seam the HIP path hides behind.
 
-Mirrors models/registry.py of the reference: same function names, same cfg keys read,
-the same four cfg keys written in place ('model.backbone.out_channels'/'out_strides',
-'model.fpn.out_channels'/'out_strides'), same exceptions on unknown names.
-Pretrained files the reference hard-requires (weights/dark53_imgnet.pth,
-models/registry.py:15) are loaded when present and skipped with a notice otherwise.
+Same four entry points as the reference's models/registry.py -- `get_backbone`, `get_fpn`, `get_rpn`,
+`get_det_layer` --, reading the same cfg keys, writing the same four derived keys in place
+('model.backbone.out_channels' / 'out_strides', 'model.fpn.out_channels' / 'out_strides') and raising the same
+exceptions for names they do not know (bare `Exception('Unknown ...')` for backbone / FPN, `NotImplementedError`
+for head / decode layer; models/registry.py:36,71,115,146).  Dispatch is by table: name -> (module, attribute),
+imported on first use.
 """
+import importlib
 import os
 
 import torch
 
+_HEADS = {                                   # cfg['model.rpn.name']            reference: models/registry.py:100-116
+    'yolov3': ('rpns', 'YOLOHead'),
+    'effrpn': ('rpns', 'EfDetHead'),
+    'effrpn_ct': ('rpns', 'EfDetHead_wCenter'),
+}
+_DECODE_LAYERS = {                           # cfg['model.pred_layer']          reference: models/registry.py:119-146
+    'YOLO': ('detlayers.yolov3', 'YOLOLayer'),
+    'RetinaNet': ('detlayers.retinanet', 'RetinaLayer'),
+    'FCOS': ('detlayers.fcos', 'FCOSLayer'),
+    'FCOS2': ('detlayers.fcos2', 'FCOSLayer'),
+    'FCOS2_ATSS': ('detlayers.fcos2', 'FCOS_ATSS_Layer'),
+}
+
+
+def _resolve(entry):
+    module, attr = entry
+    return getattr(importlib.import_module(f'{__package__}.{module}'), attr)
+
+
+def _darknet53(cfg):
+    """Darknet-53 with the three taps of the reference (models/registry.py:10-24).  The ImageNet checkpoint the
+    reference hard-requires (weights/dark53_imgnet.pth, :15) is loaded when present and skipped with a notice
+    otherwise -- it does not exist offline."""
+    from .. import PROJECT_ROOT
+    assert cfg['model.backbone.num_levels'] == 3
+    net = _resolve(('backbones', 'Darknet53'))(cfg)
+    path = f'{PROJECT_ROOT}/weights/dark53_imgnet.pth'
+    if os.path.exists(path):
+        print("Using backbone Darknet-53. Loading ImageNet weights....")
+        net.load_state_dict(torch.load(path), strict=True)
+    else:
+        print(f"Using backbone Darknet-53. No ImageNet weights at {path}; keeping initial weights.")
+    return net, (256, 512, 1024), (8, 16, 32)
+
+
+def _efficientnet(cfg):
+    """EfficientNet-B* with the C1..C5 taps (+ C6/C7); the reference downloads ImageNet weights here
+    (models/registry.py:25-34), which is not possible offline."""
+    net = _resolve(('backbones', 'EfNetBackbone'))(cfg)
+    return net, net.feature_chs, net.feature_strides
+
 
 def get_backbone(cfg: dict):
     '''
-    Get backbone network (reference: models/registry.py:4-40)
+    Backbone network for cfg['model.backbone.name']; records its output channels and strides in cfg
+    (reference: models/registry.py:4-40)
     '''
-    backbone_name = cfg['model.backbone.name']
-    if backbone_name == 'dark53':
-        from .backbones import Darknet53
-        from .. import PROJECT_ROOT
-        assert cfg['model.backbone.num_levels'] == 3
-        backbone = Darknet53(cfg)
-        path = f'{PROJECT_ROOT}/weights/dark53_imgnet.pth'
-        if os.path.exists(path):
-            print("Using backbone Darknet-53. Loading ImageNet weights....")
-            backbone.load_state_dict(torch.load(path), strict=True)
-        else:
-            print(f"Using backbone Darknet-53. No ImageNet weights at {path}; keeping initial weights.")
-        out_feature_channels = (256, 512, 1024)
-        out_strides = (8, 16, 32)
-    elif backbone_name.startswith('efficientnet'):
-        from .backbones import EfNetBackbone
-        backbone = EfNetBackbone(cfg)            # the reference downloads ImageNet weights here; none offline
-        out_feature_channels = backbone.feature_chs
-        out_strides = backbone.feature_strides
-    else:
+    name = cfg['model.backbone.name']
+    build = _darknet53 if name == 'dark53' else _efficientnet if name.startswith('efficientnet') else None
+    if build is None:
         raise Exception('Unknown backbone name')
-
-    cfg['model.backbone.out_channels'] = out_feature_channels
-    cfg['model.backbone.out_strides'] = out_strides
+    backbone, cfg['model.backbone.out_channels'], cfg['model.backbone.out_strides'] = build(cfg)
     return backbone
 
 
 def get_fpn(cfg: dict):
     '''
-    Get feature pyramid network (reference: models/registry.py:43-75)
+    Feature pyramid for cfg['model.fpn.name']; records the pyramid's channels and strides in cfg
+    (reference: models/registry.py:43-75)
     '''
-    fpn_name = cfg['model.fpn.name']
-    if fpn_name == 'yolov3':
-        from .fpns import YOLOv3FPN
-        fpn = YOLOv3FPN(cfg)
-        out_feature_channels = cfg['model.backbone.out_channels']
-        out_strides = cfg['model.backbone.out_strides']
-    elif fpn_name == 'bifpn':
-        from .fpns import get_bifpn
-        fpn = get_bifpn(cfg)
-        ch = cfg['model.bifpn.out_ch']
-        out_feature_channels = [ch for _ in cfg['model.backbone.out_channels']]
-        out_strides = cfg['model.backbone.out_strides']
+    name = cfg['model.fpn.name']
+    strides = cfg['model.backbone.out_strides']
+    if name == 'yolov3':
+        fpn, channels = _resolve(('fpns', 'YOLOv3FPN'))(cfg), cfg['model.backbone.out_channels']
+    elif name == 'bifpn':
+        fpn = _resolve(('fpns', 'get_bifpn'))(cfg)
+        channels = [cfg['model.bifpn.out_ch']] * len(cfg['model.backbone.out_channels'])
     else:
         raise Exception('Unknown FPN name')
-
-    cfg['model.fpn.out_channels'] = out_feature_channels
-    cfg['model.fpn.out_strides'] = out_strides
+    cfg['model.fpn.out_channels'], cfg['model.fpn.out_strides'] = channels, strides
     return fpn
 
 
 def get_rpn(cfg: dict):
     '''
-    Get the detection head (reference: models/registry.py:100-116)
+    Detection head for cfg['model.rpn.name'] (reference: models/registry.py:100-116)
     '''
-    rpn_name = cfg['model.rpn.name']
-    if rpn_name == 'yolov3':
-        from .rpns import YOLOHead
-        rpn = YOLOHead(cfg)
-    elif rpn_name == 'effrpn':
-        from .rpns import EfDetHead
-        rpn = EfDetHead(cfg)
-    elif rpn_name == 'effrpn_ct':
-        from .rpns import EfDetHead_wCenter
-        rpn = EfDetHead_wCenter(cfg)
-    else:
+    entry = _HEADS.get(cfg['model.rpn.name'])
+    if entry is None:
         raise NotImplementedError()
-    return rpn
+    return _resolve(entry)(cfg)
 
 
 def get_det_layer(cfg: dict):
     '''
-    Get the final decode layer CLASS (reference: models/registry.py:119-146)
+    The decode layer CLASS for cfg['model.pred_layer']; the caller instantiates it per level
+    (reference: models/registry.py:119-146, models/general.py:35-38)
     '''
-    det_layer_name = cfg['model.pred_layer']
-    if det_layer_name == 'YOLO':
-        from .detlayers.yolov3 import YOLOLayer
-        return YOLOLayer
-    elif det_layer_name == 'RetinaNet':
-        from .detlayers.retinanet import RetinaLayer
-        return RetinaLayer
-    elif det_layer_name == 'FCOS':
-        from .detlayers.fcos import FCOSLayer
-        return FCOSLayer
-    elif det_layer_name == 'FCOS2':
-        from .detlayers.fcos2 import FCOSLayer
-        return FCOSLayer
-    elif det_layer_name == 'FCOS2_ATSS':
-        from .detlayers.fcos2 import FCOS_ATSS_Layer
-        return FCOS_ATSS_Layer
-    else:
+    entry = _DECODE_LAYERS.get(cfg['model.pred_layer'])
+    if entry is None:
         raise NotImplementedError()
+    return _resolve(entry)
