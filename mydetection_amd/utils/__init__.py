@@ -1,0 +1,1 @@
+"""Part of the MI355X-native detection path."""
