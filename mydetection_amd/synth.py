@@ -56,22 +56,119 @@ def _yolo_head(key, shape, n_cls=80):
     return w * (tgt / (np.sqrt(fan_in) * rms)).reshape(-1, 1, 1, 1).astype(np.float32)
 
 
-# rms of the tower output feeding the last conv of each EfDetHead branch (measured after BN
-# calibration, oracle forward at 512x512); used to set the final-layer gains.
-_EFDET_LAST_FEATURE_RMS = 0.6
+# ---------------------------------------------------------------- EfficientDet family (EfficientNet-B1 + BiFPN + EfDetHead)
+# These nets are ~110 layers deep.  Through conv -> BN -> swish a float32 round-off perturbation grows by
+# sqrt(E[swish'(z)^2] Var[z] / Var[swish(z)]) per non-linearity: 1.10 for z ~ N(0,1), i.e. exponentially with depth
+# (x70 over the trunk with the SURVEY 8d recipe: the float32 reference itself then sits 3e-4 from a float64
+# evaluation, outside north_star's 1e-4).  The recipe below keeps every layer non-linear but in the mildly
+# non-linear regime (z ~ N(1, 0.6^2): growth 1.01 per layer) and damps the residual branches like the Darknet
+# recipe does, so round-off accumulates additively (sqrt(depth) x 1.4e-7) and the 1e-4 gate is meaningful.
+_PRE_SWISH_GAMMA = (0.4, 0.8)
+_PRE_SWISH_BETA = (1.0, 0.25)        # mean, std
+_RESIDUAL_GAMMA = (0.1, 0.3)
+
+# Final-layer targets (long-tailed scores, well-spread classes).  Logit std / bias per output kind; the
+# measured spread of each final layer's output under unit gain is part of the calibration file
+# (oracle/calibrate_bn.py, key '__std__/<module>'), so the targets hold whatever the tower statistics are.
+_EFDET_TARGETS = {'class': (1.6, -5.5), 'conf': (2.0, 1.0), 'center': (2.0, 1.0),
+                  'class_only': (1.6, -7.0),       # RetinaNet: score = max over 80 classes, no objectness factor
+                  'ltrb': (0.4, 1.0),                               # anchor-free: log-distances to the four sides
+                  'anchor_xy': (0.03, 0.0), 'anchor_wh': (0.3, 0.0),   # RetinaNet: offsets in units of the anchor size
+                  'cell_xy': (1.0, 0.0), 'cell_wh': (0.3, 0.0)}        # YOLO: sigmoid offsets inside the cell
+_N_CLS = 80          # every configuration of the family has 80 classes (general.num_class)
 
 
-def _efdet_last(key, shape):
-    """Final layers of EfDetHead / EfDetHead_wCenter (models/rpns.py:139-160, 245-266):
-    rpn.{class,bbox}_nets.{lvl}.3[.pointwise].{weight,bias}, rpn.bbox_lasts.{lvl}.*, rpn.center_nets.{lvl}.1.*.
-    Class/conf logits: std 1.5, bias -7 (long-tailed scores; the reference initialises the bias to -4.595);
-    box logits: std 0.5; centerness logits: std 1.5, bias 0."""
-    is_cls = key.startswith('rpn.class_nets.')
-    tgt = 1.5 if is_cls or key.startswith('rpn.center_nets.') else 0.5
+def _efdet_last_kind(key):
+    """'class' | 'bbox' | 'center' for the final layers of EfDetHead / EfDetHead_wCenter (models/rpns.py:139-160,
+    245-266): rpn.{class,bbox}_nets.{lvl}.3[.pointwise|.depthwise].*, rpn.bbox_lasts.{lvl}.*, rpn.center_nets.{lvl}.1.*;
+    None for every other key."""
+    parts = key.split('.')
+    if key.startswith(('rpn.class_nets.', 'rpn.bbox_nets.')) and len(parts) >= 5 and parts[3] == '3':
+        return 'class' if parts[1] == 'class_nets' else 'bbox'
+    if key.startswith('rpn.bbox_lasts.'):
+        return 'bbox'
+    if key.startswith('rpn.center_nets.') and len(parts) == 5 and parts[3] == '1':
+        return 'center'
+    return None
+
+
+def _efdet_row_targets(kind, rows):
+    """Per-output-channel (logit std, bias).  With `enable_conf` the class conv has A*(1+80) channels and channel
+    a*81 is the objectness / centerness logit (models/rpns.py:186-195); an anchor-free bbox conv (4 channels) holds
+    log-distances to the four sides (models/detlayers/fcos2.py:222-251), biased so boxes span a few strides."""
+    std, bias = np.empty(rows, np.float32), np.empty(rows, np.float32)
+    if kind in _EFDET_TARGETS:
+        std[:], bias[:] = _EFDET_TARGETS[kind]
+    if kind == 'class' and rows == 9 * _N_CLS:
+        std[:], bias[:] = _EFDET_TARGETS['class_only']
+    if kind == 'class' and rows % (_N_CLS + 1) == 0:
+        conf = np.arange(rows) % (_N_CLS + 1) == 0
+        std[conf], bias[conf] = _EFDET_TARGETS['conf']
+    if kind == 'bbox':
+        # 4 channels: FCOS (models/detlayers/fcos2.py:222-251); 9 anchors: RetinaNet, cx = acx + tx * aw with anchors up
+        # to 1 149 px (models/detlayers/retinanet.py:21-28,63-70) -- a centre offset of a few percent of the anchor keeps
+        # float32 round-off of the box inside 1e-4 + 1e-4 |v|; otherwise the YOLO decode (models/detlayers/yolov3.py:41-47)
+        style = 'ltrb' if rows == 4 else None
+        if style:
+            std[:], bias[:] = _EFDET_TARGETS['ltrb']
+        else:
+            pre = 'anchor' if rows == 36 else 'cell'
+            xy = np.arange(rows) % 4 < 2
+            std[xy], bias[xy] = _EFDET_TARGETS[pre + '_xy']
+            std[~xy], bias[~xy] = _EFDET_TARGETS[pre + '_wh']
+    return std, bias
+
+
+def _efdet_last(key, shape, kind, calib):
+    """Final head layers: weights = unit-gain normal x (target std / spread measured under unit gain), bias =
+    target - gain x (the output channel's measured mean) so every channel has the target distribution whatever
+    the tower statistics are (both measurements are part of the calibration file, oracle/calibrate_bn.py)."""
+    if '.depthwise.' in key:                       # SeparableConv2d last layer: the gain sits on the pointwise conv
+        return _normal(key, shape, std=1.0 / 3.0)
+    module = key.rsplit('.', 2)[0] if '.pointwise.' in key else key.rsplit('.', 1)[0]
+    rows = shape[0]
+    std, bias = _efdet_row_targets(kind, rows)
+    measured = calib.get('__std__/' + module)
+    gain = std / np.float32(measured) if measured is not None else np.ones(rows, np.float32)
     if key.endswith('.bias'):
-        return np.float32(-7.0 if is_cls else 0.0) + _normal(key, shape, std=0.05)
+        mean = calib.get('__mean__/' + module)
+        shift = gain * mean.astype(np.float32) if mean is not None else np.float32(0.0)
+        return (bias - shift + _normal(key, shape, std=0.05)).astype(np.float32)
     fan_in = shape[1] * shape[2] * shape[3]
-    return _normal(key, shape, std=tgt / (np.sqrt(fan_in) * _EFDET_LAST_FEATURE_RMS))
+    return _normal(key, shape, std=1.0 / np.sqrt(fan_in)) * gain.reshape(-1, 1, 1, 1)
+
+
+def _efdet_bn(key, shape, damped):
+    """BatchNorm affine parameters of the EfficientDet family by the layer's role (running statistics come from
+    the calibration file)."""
+    pre_swish = ('._bn0.' in key or '._bn1.' in key                         # stem, expand, depthwise BNs
+                 or key.startswith(('fpn.', 'backbone.c5_to_c6.', 'backbone.c6_to_c7.'))   # feed fusion -> swish
+                 or key.startswith(('rpn.class_nets.', 'rpn.bbox_nets.', 'rpn.center_nets.')))
+    if key.endswith('.weight'):
+        if key in damped:
+            return _uniform(key, shape, *_RESIDUAL_GAMMA)
+        return _uniform(key, shape, *_PRE_SWISH_GAMMA) if pre_swish else _uniform(key, shape, 0.5, 1.5)
+    return _normal(key, shape, std=_PRE_SWISH_BETA[1], mean=_PRE_SWISH_BETA[0]) if pre_swish else _normal(key, shape, std=0.1)
+
+
+def is_efficientdet_key(key):
+    return key.startswith(('backbone.model.', 'backbone.c5_to_c6.', 'backbone.c6_to_c7.', 'rpn.class_nets.',
+                           'rpn.bbox_nets.', 'rpn.bbox_lasts.', 'rpn.center_nets.')) or (
+        key.startswith('fpn.') and key.split('.')[1].isdigit())
+
+
+def residual_project_bns(template):
+    """Keys of the project-conv BatchNorm weights of the MBConv blocks that have a skip connection (stride 1 and
+    Cin == Cout, external/efficientnet/model.py:94; in B0..B7 a stride-2 block always changes the width)."""
+    out = set()
+    for k, v in template.items():
+        if k.endswith('._project_conv.weight'):
+            p = k[:-len('._project_conv.weight')]
+            e = template.get(p + '._expand_conv.weight')
+            cin = e.shape[1] if e is not None else template[p + '._depthwise_conv.weight'].shape[0]
+            if cin == v.shape[0]:
+                out.add(p + '._bn2.weight')
+    return out
 
 
 _CALIB_CACHE = {}
@@ -89,19 +186,19 @@ def load_calibration(config_name):
     return _CALIB_CACHE[config_name]
 
 
-def make_tensor(key: str, shape, dtype=torch.float32) -> torch.Tensor:
-    """The synthetic value of parameter/buffer `key`."""
+def make_tensor(key: str, shape, dtype=torch.float32, calib=None, damped=()) -> torch.Tensor:
+    """The synthetic value of parameter/buffer `key`.  `calib`: the calibration dict of the configuration (final-layer
+    gains of the EfficientDet family); `damped`: BatchNorm weight keys of residual branches (residual_project_bns)."""
     shape = tuple(shape)
     if key.endswith('num_batches_tracked'):
         return torch.zeros(shape, dtype=torch.int64)
+    effdet = is_efficientdet_key(key)
     if key.startswith('rpn.heads.conv_'):
         arr = _yolo_head(key, shape)
-    elif key.startswith(('rpn.class_nets.', 'rpn.bbox_nets.')) and '.3.' in key and (
-            'pointwise' in key or len(key.split('.')) == 5):
-        arr = _efdet_last(key, shape)
-    elif key.startswith('rpn.bbox_lasts.') or (key.startswith('rpn.center_nets.') and len(key.split('.')) == 5
-                                               and key.split('.')[3] == '1'):
-        arr = _efdet_last(key, shape)
+    elif effdet and _efdet_last_kind(key) is not None:
+        arr = _efdet_last(key, shape, _efdet_last_kind(key), calib or {})
+    elif effdet and len(shape) == 1 and key.endswith(('.weight', '.bias')) and _is_bn_key(key):
+        arr = _efdet_bn(key, shape, damped)
     elif key.endswith('.weights'):                           # BiFPN fusion weights (models/fpns.py:425)
         arr = _uniform(key, shape, 0.5, 1.5)
     elif key.endswith('running_var'):
@@ -121,16 +218,30 @@ def make_tensor(key: str, shape, dtype=torch.float32) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(arr)).to(dtype)
 
 
+def _is_bn_key(key):
+    """EfficientDet-family 1-D '.weight'/'.bias' keys that belong to a BatchNorm2d (not a conv bias): _bn{0,1,2},
+    the '.1' member of a conv+BN pair (c5_to_c6, p*in_*, spconv_bn, tower entries)."""
+    parts = key.split('.')
+    mod = parts[-2]
+    if mod.startswith('_bn'):
+        return True
+    if mod == '1' and (key.startswith(('backbone.c5_to_c6.', 'backbone.c6_to_c7.', 'fpn.'))
+                       or (key.startswith(('rpn.class_nets.', 'rpn.bbox_nets.', 'rpn.center_nets.')) and len(parts) == 6)):
+        return True
+    return False
+
+
 def make_state_dict(template, config_name=None) -> dict:
     """template: mapping key -> tensor (only shape/dtype are used).  With `config_name`, BN running
     statistics come from mydetection_amd/calib/<config_name>.npz when that file exists."""
     calib = load_calibration(config_name) if config_name else {}
+    damped = residual_project_bns(template)
     out = {}
     for k, v in template.items():
         if k in calib:
             out[k] = torch.from_numpy(np.ascontiguousarray(calib[k])).to(v.dtype)
         else:
-            out[k] = make_tensor(k, v.shape, v.dtype)
+            out[k] = make_tensor(k, v.shape, v.dtype, calib, damped)
     return out
 
 

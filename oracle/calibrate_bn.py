@@ -37,10 +37,27 @@ def calibrate(name):
     for mod in model.modules():
         if isinstance(mod, torch.nn.BatchNorm2d):
             mod.register_forward_pre_hook(pre_hook)
+    # spread of every final head layer's output under unit gain (synth._efdet_last divides by it)
+    spread = {}
+
+    def out_hook(name):
+        def f(m, _i, o):
+            conv = m.pointwise if hasattr(m, 'pointwise') else m
+            o = o - conv.bias.view(1, -1, 1, 1)
+            spread['__std__/' + name] = np.float32(o.std(dim=(0, 2, 3), unbiased=False).pow(2).mean().sqrt().item())
+            spread['__mean__/' + name] = o.mean(dim=(0, 2, 3)).numpy().astype(np.float32)
+        return f
+    finals = {k.rsplit('.', 2)[0] if '.pointwise.' in k else k.rsplit('.', 1)[0]
+              for k in model.state_dict() if synth._efdet_last_kind(k) and '.depthwise.' not in k}
+    for mname, mod in model.named_modules():
+        if mname in finals:
+            mod.register_forward_hook(out_hook(mname))
     with torch.no_grad():
         model(x)
+    assert len(spread) == 2 * len(finals)
     out = {k: v.numpy().astype(np.float32) for k, v in model.state_dict().items()
            if k.endswith(('running_mean', 'running_var'))}
+    out.update(spread)
     os.makedirs(os.path.join(ROOT, 'mydetection_amd', 'calib'), exist_ok=True)
     np.savez_compressed(os.path.join(ROOT, 'mydetection_amd', 'calib', name + '.npz'), **out)
     synth._CALIB_CACHE.pop(name, None)

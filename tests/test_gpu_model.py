@@ -142,9 +142,19 @@ def effdet(request):
     return name, m.eval().cuda(), cfg
 
 
+def _assert_class_ids(got, ref, margin, what):
+    """Class ids are exact wherever the reference's two largest class probabilities differ by more than float32
+    round-off (the fixture stores that gap per candidate); such candidates must be all but a handful."""
+    safe = margin > 2e-5
+    assert safe.mean() > 0.995, f'{what}: fixture has too many tied classes'
+    np.testing.assert_array_equal(got[safe], ref[safe], err_msg=what)
+
+
 def test_effdet_family_vs_reference_golden(effdet, golden):
-    """Full path through the registry seam (EfficientNet-B1 -> 4x BiFPN -> EfDetHead -> Retina/FCOS decode ->
-    post_process) against the imported reference (batch 1, 256x256)."""
+    """Full path through the registry seam (EfficientNet-B1 -> 4x BiFPN -> EfDetHead -> Retina/FCOS/YOLO decode ->
+    post_process) against the imported reference (batch 1, 256x256): north_star's gate -- boxes/scores within 1e-4
+    (rtol and atol), class ids and detection counts exact -- at every stage, on every candidate and at all three
+    post-process settings (each keeps hundreds of detections)."""
     from mydetection_amd import synth
     name, m, cfg = effdet
     g = golden(name.replace('-', '_') + '_b1_256')
@@ -153,61 +163,134 @@ def test_effdet_family_vs_reference_golden(effdet, golden):
         c = m.backbone(x)
         p0 = m.fpn[0](c)
         p = m.fpn(c)
+        raws = m.rpn(p)
         dts = m(x)
     for key, feats in (('backbone', c), ('bifpn0', p0), ('fpn', p)):
         for lvl, f in enumerate(feats):
             assert tuple(g[f'{key}_{lvl}_shape']) == tuple(f.shape)
             f = f.contiguous().cpu().numpy()
-            np.testing.assert_allclose(f.reshape(-1)[g[f'{key}_{lvl}_idx']], g[f'{key}_{lvl}_val'], rtol=2e-4, atol=2e-4)
+            np.testing.assert_allclose(f.reshape(-1)[g[f'{key}_{lvl}_idx']], g[f'{key}_{lvl}_val'], rtol=RTOL, atol=ATOL)
+            np.testing.assert_allclose(np.sqrt((f.astype(np.float64) ** 2).sum()), g[f'{key}_{lvl}_l2'], rtol=1e-5)
+    for lvl, raw in enumerate(raws):                       # head logits through the reference-shaped views
+        for k in raw:
+            v = raw[k].contiguous().cpu().numpy().reshape(-1)
+            np.testing.assert_allclose(v[g[f'head_{lvl}_{k}_idx']], g[f'head_{lvl}_{k}_val'], rtol=RTOL, atol=ATOL)
     d = dts[0]
     n = g['bboxes_0'].shape[0]
     assert d.bboxes.shape == (n, 4)
     np.testing.assert_allclose(d.scores.cpu().numpy(), g['scores_0'], rtol=RTOL, atol=ATOL)
-    np.testing.assert_allclose(d.bboxes.cpu().numpy(), g['bboxes_0'], rtol=2e-4, atol=2e-3)
-    assert (d.cats.cpu().numpy() != g['cats_0']).sum() <= max(2, n // 2000)
+    np.testing.assert_allclose(d.bboxes.cpu().numpy(), g['bboxes_0'], rtol=RTOL, atol=ATOL)
+    _assert_class_ids(d.cats.cpu().numpy(), g['cats_0'], g['cls_margin_0'], name)
     for tag in ('ap', 'mid', 'demo'):
         r = d.post_process(float(g[f'pp_{tag}_conf']), float(g[f'pp_{tag}_nms']))
-        ref_c, ref_s = g[f'pp_{tag}_cats_0'], g[f'pp_{tag}_scores_0']
-        assert abs(len(r) - len(ref_c)) <= 1, f'{tag}: {len(r)} vs {len(ref_c)} detections'
-        if len(r) == len(ref_c):
-            np.testing.assert_array_equal(r.cats.cpu().numpy(), ref_c)
-            np.testing.assert_allclose(r.scores.cpu().numpy(), ref_s, rtol=RTOL, atol=ATOL)
+        ref_c, ref_s, ref_b = g[f'pp_{tag}_cats_0'], g[f'pp_{tag}_scores_0'], g[f'pp_{tag}_bboxes_0']
+        assert len(ref_c) >= 50, 'vacuous fixture'
+        assert len(r) == len(ref_c), f'{tag}: {len(r)} vs {len(ref_c)} detections'
+        np.testing.assert_array_equal(r.cats.cpu().numpy(), ref_c)
+        np.testing.assert_allclose(r.scores.cpu().numpy(), ref_s, rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(r.bboxes.cpu().numpy(), ref_b, rtol=RTOL, atol=ATOL)
 
 
 def test_effdet_family_vs_oracle_640(effdet):
-    """640x640 (benchmark resolution), batch 2.  These nets are ~110 layers deep with |logit| up to ~90 on the
-    synthetic weights, so float32 round-off alone moves a few scores by > 1e-4: the float32 CPU oracle (= the
-    reference's arithmetic) itself sits that far from an exact (float64) evaluation.  The gate is therefore:
-    the HIP path must be as close to the float64 oracle as the float32 CPU path is (rms within 1.5x, max within 3x), and within
-    1e-4 of the float32 oracle on 99.9 % of the elements."""
+    """640x640 (benchmark resolution), batch 2, against the float32 CPU oracle (= the reference's arithmetic,
+    tests/test_oracle_golden.py): every score and box within 1e-4 (rtol and atol), class ids exact wherever the
+    oracle's own top-2 class gap exceeds round-off, and the post-processed detections of every image identical
+    (count, classes, order) at the AP and demo thresholds."""
     from mydetection_amd import synth
-    from oracle import efficientdet as oe
+    from mydetection_amd.utils.structures import batched_post_process
+    from oracle import efficientdet as oe, postprocess as opp
     name, m, cfg = effdet
     x = synth.make_normalized_images(2, 640, seed=7)
     sd = {k: v.cpu() for k, v in m.state_dict().items()}
-    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
     with torch.no_grad():
         ob, oc, os_ = oe.forward(x, sd, name)
-        ob64, _, os64 = oe.forward(x.double(), sd64, name)
         bb, ci, sc = m.forward_candidates(x.cuda())
     assert bb.shape == ob.shape and bb.shape[1] == {'efficientdet-d1': 76725, 'd1_yv3': 25575}.get(name, 8525)
-    sc, bb = sc.cpu().double(), bb.cpu().double()
-    # box errors relative to the box scale: the YOLO decode (d1_yv3) is exp(t)*anchor, unclamped, and a few synthetic
-    # logits make boxes of 1e6 pixels whose float32 round-off alone is pixels wide
-    bscale = 1.0 + ob64.abs() / 640.0
-    err_gpu_s, err_cpu_s = (sc - os64).abs().max().item(), (os_.double() - os64).abs().max().item()
-    err_gpu_b, err_cpu_b = ((bb - ob64).abs() / bscale).max().item(), ((ob.double() - ob64).abs() / bscale).max().item()
-    # max errors are extreme-value statistics of round-off noise: 3x slack on the max, 1.5x on the rms
-    assert err_gpu_s <= max(ATOL, 3.0 * err_cpu_s), (err_gpu_s, err_cpu_s)
-    assert err_gpu_b <= max(2e-3, 3.0 * err_cpu_b), (err_gpu_b, err_cpu_b)
-    rms = lambda t: t.pow(2).mean().sqrt().item()                # noqa: E731
-    assert rms(sc - os64) <= 1.5 * rms(os_.double() - os64) + 1e-7
-    assert rms((bb - ob64) / bscale) <= 1.5 * rms((ob.double() - ob64) / bscale) + 1e-6
-    # ... and 99.9 % of the scores within 1e-4 of the float32 oracle (the tail beyond is the round-off noise bounded
-    # above; its size moves with every change of summation order through the SE gates)
-    bad = ((sc - os_.double()).abs() > ATOL + RTOL * os_.double().abs()).sum().item()
-    assert bad <= sc.numel() // 1000, f'{bad} of {sc.numel()} scores differ from the float32 oracle by more than 1e-4'
-    assert (ci.cpu() != oc).sum().item() <= bb.shape[1] // 2000 + 2
+    np.testing.assert_allclose(sc.cpu().numpy(), os_.numpy(), rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(bb.cpu().numpy(), ob.numpy(), rtol=RTOL, atol=ATOL)
+    flips = (ci.cpu() != oc)
+    assert flips.sum().item() <= 4, f'{flips.sum().item()} class-id differences'     # exact up to numerically tied classes
+    for conf in (0.005, 0.5):
+        rec = batched_post_process(bb, ci, sc, conf, cfg['test.nms_thres'])
+        for i in range(2):
+            rb, rc, rs, src = opp.post_process(ob[i].numpy(), oc[i].numpy(), os_[i].numpy(), conf, cfg['test.nms_thres'])
+            k = int(rec['count'][i])
+            assert len(src) >= 50
+            if flips[i][torch.from_numpy(src)].any():
+                continue                                    # a tied class id among the kept candidates: undefined order
+            assert k == len(src), f'{name} conf {conf} image {i}: {k} vs {len(src)} detections'
+            np.testing.assert_array_equal(rec['index'][i, :k].cpu().numpy().astype(np.int64), src)
+            np.testing.assert_array_equal(rec['class_idx'][i, :k].cpu().numpy(), rc)
+            np.testing.assert_allclose(rec['score'][i, :k].cpu().numpy(), rs, rtol=RTOL, atol=ATOL)
+            np.testing.assert_allclose(rec['bbox'][i, :k].cpu().numpy(), rb, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize('name,batch', [('efficientdet-d1', 16), ('d1_fcs2_atss', 32)])
+def test_effdet_full_size_properties_640(name, batch):
+    """BASELINE configs[2] and configs[3] at their benchmark size (efficientdet-d1 batch 16, d1_fcs2_atss batch 32,
+    640x640: the grouped pyramid launches, split-K tails and every tile shape of the benchmark are live), through
+    properties that need no CPU forward:
+      * the same batch twice gives the same bits;
+      * image i of the batch equals its solo run and permuting the images permutes the candidates (no cross-image
+        coupling), to 1e-5;
+      * the hipGraph replay of the step equals the eager records;
+      * NMS invariants per image (count <= 512, score >= conf, class ascending / score descending inside a class,
+        kept boxes of one class pairwise IoU <= thr, unique indices pointing at their candidates), idempotence;
+      * the batched records equal the oracle's post_process on the GPU candidates for a sample of images."""
+    from mydetection_amd import synth
+    from mydetection_amd.graph import GraphedPath
+    from mydetection_amd.models.general import name_to_model
+    from mydetection_amd.utils.bbox_ops import bboxes_iou
+    from mydetection_amd.utils.structures import batched_post_process
+    from oracle import postprocess as pp
+    m, cfg = name_to_model(name)
+    m.load_state_dict(synth.make_state_dict(m.state_dict(), name), strict=True)
+    m = m.eval().cuda()
+    conf, thr = cfg['test.ap_conf_thres'], cfg['test.nms_thres']
+    x = synth.make_normalized_images(batch, 640, seed=13).cuda()
+    perm = torch.randperm(batch, generator=torch.Generator().manual_seed(2)).cuda()
+    with torch.no_grad():
+        bb, ci, sc = m.forward_candidates(x)
+        b2, c2, s2 = m.forward_candidates(x)
+        bp, cp, sp = m.forward_candidates(x[perm].contiguous())
+        assert torch.equal(b2, bb) and torch.equal(c2, ci) and torch.equal(s2, sc)
+        # to 1e-5, not bit for bit: where a tile's K range is cut (split-K tail) depends on its position in the grid
+        np.testing.assert_allclose(sp.cpu().numpy(), sc[perm].cpu().numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(bp.cpu().numpy(), bb[perm].cpu().numpy(), rtol=1e-5, atol=1e-5)
+        assert (cp != ci[perm]).float().mean().item() < 1e-4
+        for i in (0, batch - 1):
+            b1, c1, s1 = m.forward_candidates(x[i:i + 1])
+            np.testing.assert_allclose(s1[0].cpu().numpy(), sc[i].cpu().numpy(), rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(b1[0].cpu().numpy(), bb[i].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    assert bb.shape[1] == (76725 if name == 'efficientdet-d1' else 8525)
+    assert torch.isfinite(sc).all() and torch.isfinite(bb).all()
+    rec = batched_post_process(bb, ci, sc, conf, thr)
+    graphed = GraphedPath(m, x, conf, thr)
+    rg = graphed(x)
+    for k in ('count', 'index', 'class_idx', 'score', 'bbox'):
+        assert torch.equal(rg[k], rec[k]), k
+    cnt = rec['count'].cpu().numpy()
+    assert (cnt <= 512).all() and (cnt >= 50).all()
+    for i in range(batch):
+        k = int(cnt[i])
+        idx = rec['index'][i, :k].long()
+        cls, s, b = rec['class_idx'][i, :k], rec['score'][i, :k], rec['bbox'][i, :k]
+        assert idx.unique().numel() == k
+        assert torch.equal(b, bb[i][idx]) and torch.equal(cls, ci[i][idx]) and torch.equal(s, sc[i][idx])
+        assert (s >= conf).all()
+        same = cls[1:] == cls[:-1]
+        assert (cls[1:] >= cls[:-1]).all() and (s[1:][same] <= s[:-1][same]).all()
+        iou = bboxes_iou(b, b, xyxy=False)
+        clash = (iou > thr + 1e-5) & (cls[:, None] == cls[None, :])
+        clash.fill_diagonal_(False)
+        assert not clash.any()
+        again = batched_post_process(b[None], cls[None], s[None], conf, thr)
+        assert int(again['count'][0]) == k and torch.equal(again['bbox'][0, :k], b)
+    for i in (0, batch // 2, batch - 1):
+        ob, oc, os_, src = pp.post_process(bb[i].cpu().numpy(), ci[i].cpu().numpy(), sc[i].cpu().numpy(), conf, thr)
+        k = int(cnt[i])
+        assert k == len(src)
+        np.testing.assert_array_equal(rec['index'][i, :k].cpu().numpy().astype(np.int64), src)
 
 
 def test_device_preprocess_and_batched_detector(model):

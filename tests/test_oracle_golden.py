@@ -148,12 +148,14 @@ def test_efficientdet_family_matches_reference(golden, config):
         for lvl, f in enumerate(feats):
             f = f.numpy()
             assert tuple(g[f'{key}_{lvl}_shape']) == f.shape
-            np.testing.assert_allclose(f.reshape(-1)[g[f'{key}_{lvl}_idx']], g[f'{key}_{lvl}_val'], rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(f.reshape(-1)[g[f'{key}_{lvl}_idx']], g[f'{key}_{lvl}_val'], rtol=1e-5, atol=1e-5)
     np.testing.assert_array_equal(ci[0].numpy(), g['cats_0'])
-    np.testing.assert_allclose(sc[0].numpy(), g['scores_0'], rtol=1e-4, atol=1e-7)
-    np.testing.assert_allclose(bb[0].numpy(), g['bboxes_0'], rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(sc[0].numpy(), g['scores_0'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(bb[0].numpy(), g['bboxes_0'], rtol=1e-5, atol=1e-5)
     for tag in ('ap', 'mid', 'demo'):
         b, cc, s, _ = pp.post_process(bb[0].numpy(), ci[0].numpy(), sc[0].numpy(), float(g[f'pp_{tag}_conf']),
                                       float(g[f'pp_{tag}_nms']))
+        assert len(cc) >= 50, 'vacuous fixture'
         np.testing.assert_array_equal(cc, g[f'pp_{tag}_cats_0'])
-        np.testing.assert_allclose(s, g[f'pp_{tag}_scores_0'], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(s, g[f'pp_{tag}_scores_0'], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(b, g[f'pp_{tag}_bboxes_0'], rtol=1e-5, atol=1e-5)
