@@ -1,31 +1,38 @@
 """Benchmark of the detection inference hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N ranks, one per GPU, over RCCL)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...      (the driver's launcher: same ranks)
 
 One step = one pass of the hot path over one batch resident in HBM:
     images [32,3,640,640] -> Darknet-53 -> YOLOv3 FPN -> head -> decode -> conf filter (0.005)
-    -> top-512 -> class-aware NMS (0.45) [-> all-gather of detection records when N>1]
-Workload = BASELINE.json configs[1] (yolov3_80, batch 32 per GPU, 640x640, synthetic weights/images).
-Metric: images/sec over all GPUs (weak scaling: 32 images per GPU).
+    -> top-512 -> class-aware NMS (0.45) [-> ONE all-gather of the fixed-size detection records when N > 1]
+Workload = BASELINE.json configs[1] (yolov3_80, batch 32 per GPU, 640x640, synthetic weights/images); `--config
+efficientdet-d1 --batch 16` and `--config d1_fcs2_atss` are configs[2] and [3].  ONE global batch of N x batch
+images (image i is a pure function of i) is cut into contiguous shards (parallel.shard_range), so `--verify` can
+compare the gathered records with a 1-GPU pass over the same images.
+Metric: images/sec over all GPUs (weak scaling: `--batch` images per GPU).
 
 The JSON line also carries
-  roofline     -- the dominant kernel (the conv family with the most time per step: fused Winograd or
-                  implicit GEMM, both on FP32 MFMA): algorithmic FLOPs of its launches / their HIP-event
-                  durations measured inside the timed region, against the 157.3 TFLOP/s FP32 matrix
-                  peak (MI355X_MICROARCH.md); `mfma_frac` = multiplies actually issued / peak
-  cpu_baseline -- the CPU oracle (port of the reference path) timed on this host's cores on a
-                  bounded sample (rank 0, N=1 only)
+  roofline     -- the dominant kernel family (most time per step).  YOLOv3: a conv family on FP32 MFMA --
+                  `frac` = multiplies actually issued on the matrix pipe / the 157.3 TFLOP/s FP32-MFMA peak;
+                  `algorithmic_frac` = direct-form FLOPs / peak (exceeds `frac` by 2.25x for the Winograd kernel,
+                  which removes multiplies instead of executing them).  EfficientDet family: HBM-bound --
+                  `frac` = algorithmic bytes / HIP-event time / 8 TB/s.  Times are HIP events on the launch
+                  stream inside the timed region; `traffic` = PMC bytes per launch from a committed rocprofv3
+                  pass (profiles/), tagged with the file it came from, or null.
+  cpu_baseline -- the CPU oracle (port of the reference path) timed on this host's cores on a bounded sample
+                  (rank 0, N=1 only): forward and post-process separately, median of 5
   stages       -- per-kernel-family time per step, incl. the NMS launch (latency-bound; p50 reported)
+`--nms-worst` measures the isolated NMS worst cases of SURVEY 8d instead (512 boxes in 1 / in 80 classes).
 """
 import argparse
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -33,13 +40,68 @@ if ROOT not in sys.path:
 
 PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+DEFAULT_BATCH = {'yolov3_80': 32, 'efficientdet-d1': 16, 'd1_fcs2_atss': 32}
+WORKLOADS = {
+    'yolov3_80': 'yolov3_80 (Darknet-53 + YOLOv3 FPN/head + decode + conf 0.005/top-512/NMS 0.45)',
+    'efficientdet-d1': 'efficientdet-d1 (EfficientNet-B1 + 4x BiFPN + EfDetHead + RetinaNet decode + conf 0.005/top-512/NMS 0.5)',
+    'd1_fcs2_atss': 'd1_fcs2_atss (EfficientNet-B1 + 4x BiFPN + EfDetHead + FCOS decode + conf 0.005/top-512/NMS 0.5)',
+}
 
 
-def cpu_baseline(cfg, size, sample_batch, repeats, max_threads=16):
-    """Oracle forward + post-process on the host cores (reported baseline, not the target)."""
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: the BASELINE batch of --config)')
+    ap.add_argument('--size', type=int, default=640)
+    ap.add_argument('--config', default='yolov3_80', help='yolov3_80 (headline) | efficientdet-d1 | d1_fcs2_atss')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', action='store_true', help='replay the step from a captured hipGraph')
+    ap.add_argument('--verify', action='store_true',
+                    help='after the timed region: the gathered records must equal a 1-GPU pass over the same global batch')
+    ap.add_argument('--nms-worst', action='store_true', help='isolated NMS worst cases (512 boxes, 1 and 80 classes)')
+    ap.add_argument('--cpu-sample-batch', type=int, default=2)
+    ap.add_argument('--cpu-repeats', type=int, default=5)
+    ap.add_argument('--cpu-threads', type=int, default=16)
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher: start N ranks (one process per GPU) BEFORE this process touches the GPU and
+    exit with their return code.  torch.cuda.device_count() does not initialise HIP; nothing else here does either."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write(f'bench.py: --gpus {args.gpus} but this machine exposes {have} GPU(s); nothing was run\n')
+        return 2
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def cpu_model_name():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(config, cfg, size, sample_batch, repeats, max_threads=16):
+    """Oracle forward + post-process on the host cores (reported baseline, not the target): median of `repeats`
+    after one warm-up, forward and per-image post_process timed separately."""
+    import torch
     from mydetection_amd import synth
     from mydetection_amd.models.general import state_dict_template
-    from oracle import postprocess as opp, yolov3 as oy
+    from oracle import postprocess as opp
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
@@ -47,50 +109,87 @@ def cpu_baseline(cfg, size, sample_batch, repeats, max_threads=16):
         pass
     cores = min(cores, max_threads)         # a 1-GPU box owns a 16-CPU share of the host, not all of it
     torch.set_num_threads(cores)
-    sd = synth.make_state_dict(state_dict_template('yolov3_80'))
-    x = synth.make_images(sample_batch, size, seed=0)
+    sd = synth.make_state_dict(state_dict_template(config), config)
+    x = synth.make_image_set(0, sample_batch, size, cfg['general.input_format'])
+    if config == 'yolov3_80':
+        from oracle import yolov3 as oy
+        fwd = lambda: oy.forward(x, sd)                                   # noqa: E731
+    else:
+        from oracle import efficientdet as oe
+        fwd = lambda: oe.forward(x, sd, config)                           # noqa: E731
+    conf, nms = cfg['test.ap_conf_thres'], cfg['test.nms_thres']
 
     def once():
+        t0 = time.perf_counter()
         with torch.no_grad():
-            bb, ci, sc = oy.forward(x, sd)
+            bb, ci, sc = fwd()
+        t1 = time.perf_counter()
         for b in range(sample_batch):
-            opp.post_process(bb[b].numpy(), ci[b].numpy(), sc[b].numpy(), cfg['test.ap_conf_thres'], cfg['test.nms_thres'])
+            opp.post_process(bb[b].numpy(), ci[b].numpy(), sc[b].numpy(), conf, nms)
+        return t1 - t0, time.perf_counter() - t1
     once()
-    times = []
-    for _ in range(repeats):
-        t = time.perf_counter()
-        once()
-        times.append(time.perf_counter() - t)
-    med = statistics.median(times)
-    return {'value': round(sample_batch / med, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': f'oracle/ (torch-CPU restatement of the reference path + C NMS), yolov3_80 batch {sample_batch} '
-                      f'{size}x{size}, forward + per-image post_process, median of {repeats} after 1 warm-up'}
+    runs = [once() for _ in range(repeats)]
+    f_med = statistics.median(r[0] for r in runs)
+    p_med = statistics.median(r[1] for r in runs)
+    tot = statistics.median(r[0] + r[1] for r in runs)
+    return {'value': round(sample_batch / tot, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'cpu': cpu_model_name(),
+            'forward_ms_per_image': round(f_med / sample_batch * 1e3, 2),
+            'post_process_ms_per_image': round(p_med / sample_batch * 1e3, 3),
+            'sample': f'oracle/ (torch-CPU restatement of the reference path + C NMS), {config} batch {sample_batch} '
+                      f'{size}x{size}, forward and per-image post_process timed separately, median of {repeats} after 1 warm-up'}
+
+
+def nms_worst_cases(dev, iters=200, warm=20):
+    """exactly 512 boxes per image in 1 class and spread over 80 classes, B = 1 and B = 32; p50 / p95 of
+    the post-process launch over `iters` stream-synchronised iterations (HIP events around each launch)."""
+    import numpy as np
+    import torch
+    from mydetection_amd import ops
+    out = {}
+    rng = np.random.Generator(np.random.PCG64(5))
+    for n_cls in (1, 80):
+        for B in (1, 32):
+            cx = rng.random((B, 512), dtype=np.float32) * 600 + 20
+            cy = rng.random((B, 512), dtype=np.float32) * 600 + 20
+            wh = rng.random((B, 512, 2), dtype=np.float32) * 120 + 20
+            bb = torch.from_numpy(np.concatenate([cx[..., None], cy[..., None], wh], axis=-1)).to(dev)
+            ci = torch.from_numpy(rng.integers(0, n_cls, size=(B, 512)).astype(np.int64)).to(dev)
+            sc = torch.from_numpy((rng.random((B, 512), dtype=np.float32) * 0.9 + 0.05)).to(dev)
+            for _ in range(warm):
+                rec = ops.postprocess(bb, ci, sc, 0.005, 0.45)
+            torch.cuda.synchronize()
+            spans = []
+            for _ in range(iters):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rec = ops.postprocess(bb, ci, sc, 0.005, 0.45)
+                e1.record()
+                torch.cuda.synchronize()
+                spans.append(e0.elapsed_time(e1))
+            spans.sort()
+            out[f'{n_cls}_class_B{B}'] = {'p50_ms': round(spans[len(spans) // 2], 4), 'p95_ms': round(spans[int(len(spans) * 0.95)], 4),
+                                          'kept_per_image': round(float(rec['count'].float().mean()), 1), 'iterations': iters}
+    return out
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=32, help='images per GPU')
-    ap.add_argument('--size', type=int, default=640)
-    ap.add_argument('--config', default='yolov3_80', help='yolov3_80 (headline) | efficientdet-d1 | d1_fcs2_atss')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--graph', action='store_true', help='replay the step from a captured hipGraph')
-    ap.add_argument('--cpu-sample-batch', type=int, default=2)
-    ap.add_argument('--cpu-repeats', type=int, default=3)
-    ap.add_argument('--cpu-threads', type=int, default=16)
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(self_launch(args))
 
+    import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if world != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}')
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     rehearse = world == 1 and 'RANK' in os.environ and os.environ.get('MYDET_REHEARSE_RCCL') == '1'
-    if world > 1 or rehearse:      # (rehearse: one-rank RCCL group, exercises the collective path on a 1-GPU box)
+    dist_on = world > 1 or rehearse       # (rehearse: one-rank RCCL group, exercises the collective path on a 1-GPU box)
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=dev)          # nccl == RCCL on ROCm
@@ -100,6 +199,11 @@ def main():
     from mydetection_amd.utils.structures import batched_post_process
     _lib.lib()                                                   # loud failure if the HIP library is missing
 
+    if args.nms_worst:
+        print(json.dumps({'metric': 'NMS worst-case latency (filter + top-512 + class-aware NMS 0.45), 512 boxes per image',
+                          'unit': 'ms', 'cases': nms_worst_cases(dev)}))
+        return
+
     import contextlib
     import io
     with contextlib.redirect_stdout(io.StringIO()):
@@ -107,25 +211,29 @@ def main():
     model.load_state_dict(synth.make_state_dict(model.state_dict(), args.config), strict=True)
     model = model.eval().to(dev)
     conf, nms = cfg['test.ap_conf_thres'], cfg['test.nms_thres']
-    # each rank owns its shard of the global batch; resident in HBM before the timed region
-    make = synth.make_images if cfg['general.input_format'] == 'RGB_1' else synth.make_normalized_images
-    x = make(args.batch, args.size, seed=rank).to(dev)
+    batch = args.batch or DEFAULT_BATCH.get(args.config, 32)
+    total = world * batch
+    # ONE global batch, sharded contiguously; this rank's shard is resident in HBM before the timed region
+    lo, hi = parallel.shard_range(total, rank, world)
+    x = synth.make_image_set(lo, hi, args.size, cfg['general.input_format']).to(dev)
 
     graphed = None
     if args.graph:
         from mydetection_amd.graph import GraphedPath
         graphed = GraphedPath(model, x, conf, nms)
 
-    def step():
-        if graphed is not None:
-            return parallel.gather_detections(graphed(), always=rehearse)
+    def local_records(inp=None):
+        if graphed is not None and inp is None:
+            return graphed()
         with torch.no_grad():
-            bb, ci, sc = model.forward_candidates(x)
-            rec = batched_post_process(bb, ci, sc, conf, nms)
-            return parallel.gather_detections(rec, always=rehearse)
+            bb, ci, sc = model.forward_candidates(x if inp is None else inp)
+            return batched_post_process(bb, ci, sc, conf, nms)
+
+    def step():
+        return parallel.gather_detections(local_records(), always=rehearse, total=total)
 
     def barrier():
-        if world > 1 or rehearse:
+        if dist_on:
             torch.distributed.barrier()
 
     for _ in range(args.warmup):
@@ -145,102 +253,133 @@ def main():
     timer, ops.TIMER = ops.TIMER, None
     if timer is None:        # graph replay hides the launches from the event timer: price the kernels eagerly, after
         ops.TIMER = ops.KernelTimer()
-        with torch.no_grad():
-            for _ in range(args.steps):
-                bb, ci, sc = model.forward_candidates(x)
-                batched_post_process(bb, ci, sc, conf, nms)
+        for _ in range(args.steps):
+            local_records(x)
         torch.cuda.synchronize()
         timer, ops.TIMER = ops.TIMER, None
 
-    if world > 1 or rehearse:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    summ = timer.summary()
-    if args.config != 'yolov3_80':          # secondary configs: per-kernel-family table only
+    verify = None
+    if args.verify:
+        # rank 0 runs every shard's images through its own GPU, in the shard composition the ranks used, and the
+        # gathered records must equal that bit for bit (count, candidate indices, classes, scores, boxes)
+        ok, checked = True, 0
         if rank == 0:
-            tot = sum(v[1] for v in summ.values()) / args.steps
-            print(json.dumps({'metric': f'images/sec, {args.config}, batch {args.batch}/GPU, {args.size}x{args.size}',
-                              'value': round(world * args.batch * args.steps / elapsed, 2), 'unit': 'images/sec',
-                              'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-                              'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'kernel_ms_per_step': round(tot, 3),
-                              'dtype': 'f32', 'data': 'synthetic',
-                              'stages': {k: {'launches_per_step': v[0] / args.steps, 'ms_per_step': round(v[1] / args.steps, 4),
-                                             'work_per_s': round(v[2] / (v[1] * 1e-3) / 1e9, 1)} for k, v in summ.items()}}))
-        if world > 1:
-            torch.distributed.destroy_process_group()
-        return
+            got = {k: v.clone() for k, v in rec.items() if k != 'records'}
+            for r in range(world):
+                rlo, rhi = parallel.shard_range(total, r, world)
+                xr = x if r == 0 else synth.make_image_set(rlo, rhi, args.size, cfg['general.input_format']).to(dev)
+                ref = local_records(xr)
+                for k in ('count', 'index', 'class_idx', 'score', 'bbox'):
+                    ok = ok and torch.equal(got[k][rlo:rhi], ref[k])
+                checked += rhi - rlo
+            ok = ok and got['count'].shape[0] == total and int(got['count'].sum()) > 0
+        verify = {'ok': bool(ok), 'images': checked, 'against': '1-GPU pass over the same global batch (rank 0)'}
+
+    summ = timer.summary()
     stages = {k: {'launches_per_step': v[0] / args.steps, 'ms_per_step': round(v[1] / args.steps, 4)} for k, v in summ.items()}
-    pp_spans = [a.elapsed_time(b) for a, b, _ in timer.spans['postprocess']]
+    kernel_ms = sum(v[1] for v in summ.values()) / args.steps
+    pp_spans = sorted(a.elapsed_time(b) for a, b, _ in timer.spans['postprocess'])
     stages['postprocess']['p50_ms'] = round(statistics.median(pp_spans), 4)
+    stages['postprocess']['p95_ms'] = round(pp_spans[min(len(pp_spans) - 1, int(len(pp_spans) * 0.95))], 4)
     stages['postprocess']['mean_detections_per_image'] = round(float(rec['count'].float().mean()), 1)
     dec_ms, dec_bytes = summ['decode'][1], summ['decode'][2]
     stages['decode']['achieved_GBs'] = round(dec_bytes / (dec_ms * 1e-3) / 1e9, 1)
     stages['decode']['frac_hbm_peak'] = round(dec_bytes / (dec_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
-    # Dominant kernel = the conv family with the most time per step.  `achieved` prices its launches with the
-    # ALGORITHMIC flops of the layers (2*MACs of the direct form); the Winograd kernel issues 2.25x
-    # fewer multiplies than that, so its matrix-pipe occupancy is reported next to it as `mfma_frac`.
-    kernels = {'conv_igemm': ('conv_igemm_kernel (implicit GEMM, v_mfma_f32_32x32x2_f32)', 1.0),
-               'conv_wino': ('conv_wino_kernel (fused Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32)', 2.25)}
-    fams = {k: summ[k] for k in kernels if k in summ}
-    dom = max(fams, key=lambda k: fams[k][1])
-    n_conv, conv_ms, conv_flops = fams[dom]
-    achieved = conv_flops / (conv_ms * 1e-3) / 1e12
-    for k, (n_k, ms_k, fl_k) in fams.items():
-        stages[k]['algorithmic_TFLOPs'] = round(fl_k / (ms_k * 1e-3) / 1e12, 2)
-        stages[k]['mfma_frac'] = round(fl_k / kernels[k][1] / (ms_k * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
-    # HBM/fabric bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command,
-    # corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE x2 for 16-byte-per-lane loads, WRITE_SIZE exact);
-    # measured offline because counters need the profiler, committed under profiles/
-    traffic = None
-    pmc_path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_b32_640.json')
-    if args.batch == 32 and args.size == 640 and os.path.exists(pmc_path):
-        pmc = json.load(open(pmc_path)).get(dom)
-        if pmc:
-            traffic = round(pmc['hbm_read_bytes_per_launch_x2corr'] + pmc['hbm_write_bytes_per_launch'])
-    alg_bytes = round(timer.bytes.get(dom, 0.0) / n_conv) if n_conv else None
+    for k, v in summ.items():                                    # algorithmic bytes / time per family
+        if timer.bytes.get(k):
+            stages[k]['algorithmic_GBs'] = round(timer.bytes[k] / (v[1] * 1e-3) / 1e9, 1)
 
-    total_images = world * args.batch * args.steps
+    if args.config == 'yolov3_80':
+        # Dominant kernel = the conv family with the most time per step, priced with the ALGORITHMIC flops of its layers
+        # (2*MACs of the direct form).  The Winograd kernel issues 2.25x fewer multiplies than that.
+        kernels = {'conv_igemm': ('conv_igemm_kernel (implicit GEMM, v_mfma_f32_32x32x2_f32)', 1.0),
+                   'conv_wino': ('conv_wino_kernel (fused Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32)', 2.25)}
+        fams = {k: summ[k] for k in kernels if k in summ}
+        dom = max(fams, key=lambda k: fams[k][1])
+        n_k, ms_k, flops_k = fams[dom]
+        alg = flops_k / (ms_k * 1e-3) / 1e12
+        for k, (n_f, ms_f, fl_f) in fams.items():
+            stages[k]['algorithmic_TFLOPs'] = round(fl_f / (ms_f * 1e-3) / 1e12, 2)
+            stages[k]['mfma_frac'] = round(fl_f / kernels[k][1] / (ms_f * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
+        roofline = {'bound': 'mfma', 'kernel': kernels[dom][0],
+                    'achieved': round(alg / kernels[dom][1], 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(alg / kernels[dom][1] / PEAK_FP32_MFMA_TFLOPS, 4),
+                    'algorithmic_achieved': round(alg, 2),
+                    'algorithmic_frac': round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
+                    'note': 'achieved/frac = multiplies issued on the matrix pipe (algorithmic direct-form FLOPs / '
+                            f'{kernels[dom][1]}) / HIP-event time vs the FP32-MFMA peak; algorithmic_* = direct-form FLOPs / time',
+                    'algorithmic_gflop_per_launch': round(flops_k / n_k / 1e9, 3)}
+    else:
+        fams = {k: summ[k] for k in summ if timer.bytes.get(k)}
+        dom = max(fams, key=lambda k: fams[k][1])
+        n_k, ms_k, _ = fams[dom]
+        gbs = timer.bytes[dom] / (ms_k * 1e-3) / 1e9
+        step_bytes = sum(timer.bytes.values()) / args.steps
+        roofline = {'bound': 'hbm', 'kernel': {'conv_igemm': 'conv_igemm_kernel (pointwise / dense convs, FP32 MFMA)',
+                                               'dwconv': 'dwconv kernels (depthwise k3/k5 + BN + swish)'}.get(dom, dom),
+                    'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
+                    'note': 'achieved = algorithmic bytes of the family (operands once + result once) / HIP-event time',
+                    'step_algorithmic_bytes': round(step_bytes),
+                    'step_achieved_GBs': round(step_bytes / (kernel_ms * 1e-3) / 1e9, 1),
+                    'step_frac': round(step_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+    # HBM/fabric bytes per launch from committed rocprofv3 --pmc passes of this same command (FETCH_SIZE / WRITE_SIZE in
+    # separate passes, corrected per kernel as MI355X_MICROARCH.md prescribes); offline because counters need the profiler
+    traffic, traffic_src = None, None
+    tag = {'yolov3_80': 'yolov3', 'efficientdet-d1': 'd1', 'd1_fcs2_atss': 'fcos'}.get(args.config, args.config)
+    for rnd in ('r02', 'r01'):
+        name = f'{rnd}_pmc_traffic_{tag}_b{batch}_{args.size}.json' if rnd != 'r01' else 'r01_pmc_traffic_b32_640.json'
+        path = os.path.join(ROOT, 'profiles', name)
+        if os.path.exists(path) and (rnd != 'r01' or (args.config == 'yolov3_80' and batch == 32 and args.size == 640)):
+            pmc = json.load(open(path)).get(dom)
+            if pmc:
+                traffic = round(pmc.get('hbm_bytes_per_launch', pmc.get('hbm_read_bytes_per_launch_x2corr', 0) + pmc.get('hbm_write_bytes_per_launch', 0)))
+                traffic_src = f'profiles/{name} (offline rocprofv3 --pmc passes' + (', previous round' if rnd == 'r01' else '') + ')'
+                break
+    roofline.update({'traffic': traffic, 'traffic_source': traffic_src,
+                     'algorithmic_bytes_per_launch': round(timer.bytes.get(dom, 0.0) / n_k) if n_k else None,
+                     'launches_per_step': n_k / args.steps, 'avg_launch_ms': round(ms_k / n_k, 4)})
+
+    images = total * args.steps
+    headline = args.config == 'yolov3_80'
     out = {
-        'metric': f'images/sec at batch {args.batch}, {args.size}x{args.size}, YOLOv3-80 (backbone -> FPN -> head -> decode -> NMS)',
-        'value': round(total_images / elapsed, 2),
+        'metric': (f'images/sec at batch {batch}, {args.size}x{args.size}, YOLOv3-80 (backbone -> FPN -> head -> decode -> NMS)'
+                   if headline else f'images/sec at batch {batch}, {args.size}x{args.size}, {args.config} (backbone -> BiFPN -> head -> decode -> NMS)'),
+        'value': round(images / elapsed, 2),
         'unit': 'images/sec',
         'n_gpus': world,
         'steps': args.steps,
         'warmup': args.warmup,
         'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+        'kernel_ms_per_step': round(kernel_ms, 3),
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
         'dtype': 'f32',
         'data': 'synthetic',
-        'config': {'workload': f'yolov3_80 (Darknet-53 + YOLOv3 FPN/head + decode + conf 0.005/top-512/NMS 0.45), '
-                               f'batch {args.batch}/GPU, {args.size}x{args.size}, random-init calibrated weights',
-                   'global_batch': world * args.batch, 'image_size': args.size, 'parallelism': f'dp{world}',
-                   'exchange': 'all-gather of 14 340 B detection records' if world > 1 else 'none'},
-        'roofline': {'bound': 'mfma', 'kernel': kernels[dom][0],
-                     'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                     'mfma_frac': round(achieved / kernels[dom][1] / PEAK_FP32_MFMA_TFLOPS, 4),
-                     'note': 'achieved = algorithmic (direct-form) FLOPs / HIP-event time; mfma_frac = multiplies actually '
-                             'issued on the matrix pipe / peak (Winograd issues 1/2.25 of the algorithmic count)',
-                     'traffic': traffic,
-                     'traffic_unit': 'bytes per launch (PMC, profiles/r01_pmc_traffic_b32_640.json)',
-                     'algorithmic_bytes_per_launch': alg_bytes,
-                     'launches_per_step': n_conv / args.steps,
-                     'avg_launch_ms': round(conv_ms / n_conv, 4),
-                     'algorithmic_gflop_per_launch': round(conv_flops / n_conv / 1e9, 3)},
+        'config': {'workload': f'{WORKLOADS.get(args.config, args.config)}, batch {batch}/GPU, {args.size}x{args.size}, '
+                               'random-init calibrated weights' + (', hipGraph replay' if args.graph else ''),
+                   'global_batch': total, 'image_size': args.size, 'parallelism': f'dp{world}',
+                   'exchange': f'one all-gather of {parallel.WORDS * 4} B detection records per image' if world > 1 else 'none'},
+        'roofline': roofline,
         'stages': stages,
         'nms_p50_ms': stages['postprocess']['p50_ms'],
     }
+    if verify is not None:
+        out['verify'] = verify
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(cfg, args.size, args.cpu_sample_batch, args.cpu_repeats, args.cpu_threads)
+        out['cpu_baseline'] = cpu_baseline(args.config, cfg, args.size, args.cpu_sample_batch, args.cpu_repeats, args.cpu_threads)
         out['cpu_baseline']['gpu_over_cpu'] = round(out['value'] / out['cpu_baseline']['value'], 1)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1 or rehearse:
+    if dist_on:
         torch.distributed.destroy_process_group()
+    if verify is not None and rank == 0 and not verify['ok']:
+        sys.exit(3)
 
 
 if __name__ == '__main__':

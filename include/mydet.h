@@ -198,7 +198,7 @@ int mydet_decode_f32(int mode,
  *   topk highest (ties: lowest candidate index); per class ascending: greedy NMS on
  *   x1y1x2y2 = (cx-w/2, cy-h/2, cx+w/2, cy+h/2), suppress when (double)IoU > nms_thres;
  *   survivors ordered class ascending, score descending (ties: lowest index).
- * In : bbox [B,N,4], class_idx [B,N] i64, score [B,N].   N < 2^17, classes < 2^15.
+ * In : bbox [B,N,4], class_idx [B,N] i64, score [B,N].   N < 2^20, class ids < 2^12.
  * Out: count [B] i32; out_bbox [B,topk,4]; out_class [B,topk] i64; out_score [B,topk];
  *      out_index [B,topk] i32 = candidate index in [0,N) of each survivor (rows >= count
  *      are zero-filled).
@@ -208,6 +208,25 @@ int mydet_postprocess_f32(const float *bbox, const int64_t *class_idx, const flo
                           int B, int64_t N, float conf_thres, double nms_thres, int topk,
                           int32_t *count, float *out_bbox, int64_t *out_class, float *out_score,
                           int32_t *out_index, void *scratch, void *stream);
+
+/* Same post-processing (topk = 512), written as ONE fixed-size record per image -- the wire format of the
+ * multi-GPU exchange (one all-gather of these records; no reference counterpart), so nothing is
+ * packed or unpacked between the kernel and the collective.  A record is MYDET_REC_WORDS int32 words
+ * (16 400 B, rows 16-byte aligned):
+ *   [COUNT] count i32, 3 zero words | [BBOX] 512 x (cx,cy,w,h) f32 | [SCORE] 512 f32 |
+ *   [CLASS] 512 i64 | [INDEX] 512 i32          (entries >= count are zero)
+ * records: B * MYDET_REC_WORDS words, 16-byte aligned.  scratch: B*N*8 bytes.
+ */
+#define MYDET_REC_TOPK   512
+#define MYDET_REC_COUNT  0
+#define MYDET_REC_BBOX   4
+#define MYDET_REC_SCORE  (MYDET_REC_BBOX + 4 * MYDET_REC_TOPK)
+#define MYDET_REC_CLASS  (MYDET_REC_SCORE + MYDET_REC_TOPK)
+#define MYDET_REC_INDEX  (MYDET_REC_CLASS + 2 * MYDET_REC_TOPK)
+#define MYDET_REC_WORDS  (MYDET_REC_INDEX + MYDET_REC_TOPK)
+int mydet_postprocess_records_f32(const float *bbox, const int64_t *class_idx, const float *score,
+                                  int B, int64_t N, float conf_thres, double nms_thres,
+                                  int32_t *records, void *scratch, void *stream);
 
 /* Pairwise IoU [Na,Nb]; utils/bbox_ops.py:6-49 (xyxy != 0: corner format, else cxcywh). */
 int mydet_bboxes_iou_f32(const float *a, int Na, const float *b, int Nb, int xyxy,

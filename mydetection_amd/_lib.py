@@ -35,6 +35,7 @@ SIGNATURES = {
                          c_int, c_int, c_int, c_f32, c_int, c_int, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr],
     'mydet_postprocess_f32': [c_ptr, c_ptr, c_ptr, c_int, c_i64, c_f32, c_f64, c_int, c_ptr, c_ptr, c_ptr, c_ptr,
                               c_ptr, c_ptr, c_ptr],
+    'mydet_postprocess_records_f32': [c_ptr, c_ptr, c_ptr, c_int, c_i64, c_f32, c_f64, c_ptr, c_ptr, c_ptr],
     'mydet_bboxes_iou_f32': [c_ptr, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr],
     'mydet_preprocess_u8_f32': [c_ptr, c_int, c_int, c_int, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr],
     'mydet_bboxes_to_original_f32': [c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_ptr],
@@ -43,6 +44,14 @@ SIGNATURES = {
 
 
 RETURNS_I64 = {'mydet_wino_weights_floats'}
+
+# detection record layout (MYDET_REC_* of include/mydet.h), in int32 words
+REC_TOPK = 512
+REC_COUNT, REC_BBOX = 0, 4
+REC_SCORE = REC_BBOX + 4 * REC_TOPK
+REC_CLASS = REC_SCORE + REC_TOPK
+REC_INDEX = REC_CLASS + 2 * REC_TOPK
+REC_WORDS = REC_INDEX + REC_TOPK
 
 
 class DecodeLevel(ctypes.Structure):

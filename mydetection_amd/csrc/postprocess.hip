@@ -27,7 +27,8 @@ namespace {
 
 constexpr int KMAX = 512;
 constexpr int NT = 1024;
-constexpr int IDX_BITS = 17;
+constexpr int IDX_BITS = 20;      // sort key = class (12 bits) | ~score (32) | candidate index (20)
+constexpr int CLS_SHIFT = 32 + IDX_BITS;
 
 struct PPArgs {
     const float *bbox;
@@ -42,6 +43,9 @@ struct PPArgs {
     int64_t *ocls;
     float *oscore;
     int32_t *oidx;
+    // per-image strides of the five outputs, in elements of each (dense arrays, or fields of one wire record)
+    int64_t count_st, obox_st, ocls_st, oscore_st, oidx_st;
+    int count_pad;                    // zero words written behind the count (record header padding)
     unsigned long long *scratch;
 };
 
@@ -222,8 +226,8 @@ __global__ __launch_bounds__(NT) void postprocess_kernel(const PPArgs p) {
                 const int pos = atomicAdd(&s_nsel, 1);
                 const unsigned idx = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
                 const unsigned su = (unsigned)(k >> 32);
-                const unsigned long long c = (unsigned long long)ci[idx] & 0x7FFFull;
-                s_key[pos] = (c << 49) | ((unsigned long long)(~su) << IDX_BITS) | (unsigned long long)idx;
+                const unsigned long long c = (unsigned long long)ci[idx] & 0xFFFull;
+                s_key[pos] = (c << CLS_SHIFT) | ((unsigned long long)(~su) << IDX_BITS) | (unsigned long long)idx;
             }
         }
     }
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(NT) void postprocess_kernel(const PPArgs p) {
         const float x1 = v[0] - hw, y1 = v[1] - hh, x2 = v[0] + hw, y2 = v[1] + hh;
         s_x1[tid] = x1; s_y1[tid] = y1; s_x2[tid] = x2; s_y2[tid] = y2;
         s_area[tid] = (x2 - x1) * (y2 - y1);
-        s_cls[tid] = (int)(k >> 49);
+        s_cls[tid] = (int)(k >> CLS_SHIFT);
     }
     __syncthreads();
     // rows are zero except inside the row's own class segment (classes are contiguous after the sort).  
@@ -404,39 +408,60 @@ __global__ __launch_bounds__(NT) void postprocess_kernel(const PPArgs p) {
                 const int pos = before + __popcll(kept & ((1ull << (tid & 63)) - 1ull));
                 const unsigned long long k = s_key[tid];
                 const unsigned idx = (unsigned)(k & ((1ull << IDX_BITS) - 1));
-                const int64_t o = (int64_t)b * p.topk + pos;
-                *reinterpret_cast<f32x4 *>(p.obox + o * 4) = *reinterpret_cast<const f32x4 *>(bb + (int64_t)idx * 4);
-                p.ocls[o] = ci[idx];
-                p.oscore[o] = sc[idx];
-                p.oidx[o] = (int32_t)idx;
+                *reinterpret_cast<f32x4 *>(p.obox + b * p.obox_st + pos * 4) = *reinterpret_cast<const f32x4 *>(bb + (int64_t)idx * 4);
+                p.ocls[b * p.ocls_st + pos] = ci[idx];
+                p.oscore[b * p.oscore_st + pos] = sc[idx];
+                p.oidx[b * p.oidx_st + pos] = (int32_t)idx;
             }
         }
     }
     for (int r = total + tid; r < p.topk; r += NT) {
-        const int64_t o = (int64_t)b * p.topk + r;
-        *reinterpret_cast<f32x4 *>(p.obox + o * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-        p.ocls[o] = 0;
-        p.oscore[o] = 0.f;
-        p.oidx[o] = 0;
+        *reinterpret_cast<f32x4 *>(p.obox + b * p.obox_st + r * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        p.ocls[b * p.ocls_st + r] = 0;
+        p.oscore[b * p.oscore_st + r] = 0.f;
+        p.oidx[b * p.oidx_st + r] = 0;
     }
-    if (tid == 0) p.count[b] = total;
+    if (tid <= p.count_pad) p.count[b * p.count_st + tid] = tid == 0 ? total : 0;
 }
 
 }  // namespace
+
+static int launch_postprocess(PPArgs &p, const float *bbox, const int64_t *class_idx, const float *score, int B, int64_t N,
+                              float conf_thres, double nms_thres, int topk, void *scratch, void *stream) {
+    if (B <= 0 || N < 0 || topk <= 0 || topk > KMAX) return MYDET_E_BADARG;
+    if (N >= (1ll << IDX_BITS)) return MYDET_E_UNSUPP;
+    if (!p.count || !p.obox || !p.ocls || !p.oscore || !p.oidx) return MYDET_E_BADARG;
+    if (N > 0 && (!bbox || !class_idx || !score || !scratch)) return MYDET_E_BADARG;
+    if (((uintptr_t)bbox & 15) || ((uintptr_t)p.obox & 15) || ((uintptr_t)scratch & 7) || ((uintptr_t)p.ocls & 7)) return MYDET_E_BADARG;
+    p.bbox = bbox; p.cidx = class_idx; p.score = score; p.N = N; p.conf = conf_thres; p.nms = nms_thres;
+    p.topk = topk; p.scratch = (unsigned long long *)scratch;
+    hipLaunchKernelGGL(postprocess_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, p);
+    return mydet_launch_status();
+}
 
 extern "C" int mydet_postprocess_f32(const float *bbox, const int64_t *class_idx, const float *score, int B,
                                      int64_t N, float conf_thres, double nms_thres, int topk, int32_t *count,
                                      float *out_bbox, int64_t *out_class, float *out_score, int32_t *out_index,
                                      void *scratch, void *stream) {
-    if (B <= 0 || N < 0 || topk <= 0 || topk > KMAX) return MYDET_E_BADARG;
-    if (N >= (1ll << IDX_BITS)) return MYDET_E_UNSUPP;
-    if (!count || !out_bbox || !out_class || !out_score || !out_index) return MYDET_E_BADARG;
-    if (N > 0 && (!bbox || !class_idx || !score || !scratch)) return MYDET_E_BADARG;
-    if (((uintptr_t)bbox & 15) || ((uintptr_t)out_bbox & 15) || ((uintptr_t)scratch & 7)) return MYDET_E_BADARG;
     PPArgs p;
-    p.bbox = bbox; p.cidx = class_idx; p.score = score; p.N = N; p.conf = conf_thres; p.nms = nms_thres;
-    p.topk = topk; p.count = count; p.obox = out_bbox; p.ocls = out_class; p.oscore = out_score;
-    p.oidx = out_index; p.scratch = (unsigned long long *)scratch;
-    hipLaunchKernelGGL(postprocess_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, p);
-    return mydet_launch_status();
+    p.count = count; p.obox = out_bbox; p.ocls = out_class; p.oscore = out_score; p.oidx = out_index;
+    p.count_pad = 0; p.count_st = 1; p.obox_st = (int64_t)topk * 4; p.ocls_st = topk; p.oscore_st = topk; p.oidx_st = topk;
+    return launch_postprocess(p, bbox, class_idx, score, B, N, conf_thres, nms_thres, topk, scratch, stream);
+}
+
+extern "C" int mydet_postprocess_records_f32(const float *bbox, const int64_t *class_idx, const float *score, int B,
+                                             int64_t N, float conf_thres, double nms_thres, int32_t *records,
+                                             void *scratch, void *stream) {
+    if ((uintptr_t)records & 15) return MYDET_E_BADARG;
+    PPArgs p;
+    if (!records) { p.count = nullptr; p.obox = nullptr; p.ocls = nullptr; p.oscore = nullptr; p.oidx = nullptr;
+                    return launch_postprocess(p, bbox, class_idx, score, B, N, conf_thres, nms_thres, MYDET_REC_TOPK, scratch, stream); }
+    p.count = records + MYDET_REC_COUNT;
+    p.obox = reinterpret_cast<float *>(records + MYDET_REC_BBOX);
+    p.oscore = reinterpret_cast<float *>(records + MYDET_REC_SCORE);
+    p.ocls = reinterpret_cast<int64_t *>(records + MYDET_REC_CLASS);
+    p.oidx = records + MYDET_REC_INDEX;
+    p.count_pad = MYDET_REC_BBOX - 1; p.count_st = MYDET_REC_WORDS; p.obox_st = MYDET_REC_WORDS; p.oscore_st = MYDET_REC_WORDS;
+    p.ocls_st = MYDET_REC_WORDS / 2; p.oidx_st = MYDET_REC_WORDS;
+    return launch_postprocess(p, bbox, class_idx, score, B, N, conf_thres, nms_thres, MYDET_REC_TOPK, scratch, stream);
 }

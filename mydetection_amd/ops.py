@@ -191,7 +191,7 @@ def conv2d_stem(x, w_ohwi, scale, shift, stride, pad, act):
                                             _ptr(out), ldy, B, H, W, Cout, stride, pad[0], pad[1], Ho, Wo, act,
                                             _stream())
     if t0:
-        TIMER.stop('conv_stem', t0, 4.0 * B * (3 * H * W + Cout * Ho * Wo))        # bytes moved
+        TIMER.stop('conv_stem', t0, *[4.0 * B * (3 * H * W + Cout * Ho * Wo)] * 2)        # bytes moved
     _lib.check(code, 'mydet_conv2d_stem_f32')
     return out
 
@@ -218,7 +218,7 @@ def dwconv(x, w_kkc, scale, shift, k, stride, pad, act, squeeze=False):
     code = _lib.lib().mydet_dwconv_f32(_ptr(x), ldx, _ptr(w_kkc), _ptr(scale), _ptr(shift), _ptr(out), ldy, B, H, W, C,
                                        k, stride, pad[0], pad[1], Ho, Wo, act, _ptr(partial), S, _stream())
     if t0:
-        TIMER.stop(f'dwconv {C} k{k}s{stride} {H}x{W}' if TIMER_DETAIL else 'dwconv', t0, 4.0 * B * C * (H * W + Ho * Wo))
+        TIMER.stop(f'dwconv {C} k{k}s{stride} {H}x{W}' if TIMER_DETAIL else 'dwconv', t0, *[4.0 * B * C * (H * W + Ho * Wo)] * 2)
     _lib.check(code, 'mydet_dwconv_f32')
     return (out, partial) if squeeze else out
 
@@ -246,7 +246,7 @@ def se_gate(partial, n_pixels, w1, b1, w2t, b2):
     code = _lib.lib().mydet_se_gate_f32(_ptr(partial), S, B, n_pixels, C, _ptr(w1), _ptr(b1), Cse, _ptr(w2t), _ptr(b2),
                                         _ptr(gate), _stream())
     if t0:
-        TIMER.stop('se_gate', t0, 4.0 * B * S * C)
+        TIMER.stop('se_gate', t0, *[4.0 * B * S * C] * 2)
     _lib.check(code, 'mydet_se_gate_f32')
     return gate
 
@@ -261,7 +261,7 @@ def maxpool3s2(x):
     t0 = TIMER.start() if TIMER else None
     code = _lib.lib().mydet_maxpool3s2_f32(_ptr(x), ldx, _ptr(out), ldy, B, H, W, C, Ho, Wo, _stream())
     if t0:
-        TIMER.stop('maxpool', t0, 4.0 * B * C * (H * W + Ho * Wo))
+        TIMER.stop('maxpool', t0, *[4.0 * B * C * (H * W + Ho * Wo)] * 2)
     _lib.check(code, 'mydet_maxpool3s2_f32')
     return out
 
@@ -291,7 +291,7 @@ def bifpn_fuse(inputs, modes, weights):
     t0 = TIMER.start() if TIMER else None
     code = _lib.lib().mydet_bifpn_fuse_f32(n, *args, _ptr(weights), _ptr(out), ldy, B, H, W, C, _stream())
     if t0:
-        TIMER.stop('bifpn_fuse', t0, 4.0 * B * C * H * W * (n + 1))
+        TIMER.stop('bifpn_fuse', t0, *[4.0 * B * C * H * W * (n + 1)] * 2)
     _lib.check(code, 'mydet_bifpn_fuse_f32')
     return out
 
@@ -312,7 +312,7 @@ def upsample_concat(a, size, b=None):
     code = _lib.lib().mydet_upsample_concat_f32(_ptr(a), lda, Ha, Wa, C1, _ptr(b), ldb, C2, _ptr(out), ldy, B, Ho,
                                                 Wo, _stream())
     if t0:
-        TIMER.stop('upsample_concat', t0, 4.0 * B * (C1 * Ha * Wa + C2 * Ho * Wo + (C1 + C2) * Ho * Wo))
+        TIMER.stop('upsample_concat', t0, *[4.0 * B * (C1 * Ha * Wa + C2 * Ho * Wo + (C1 + C2) * Ho * Wo)] * 2)
     _lib.check(code, 'mydet_upsample_concat_f32')
     return out
 
@@ -334,7 +334,7 @@ def decode(mode, box, ldbox, box_astride, box_c0, cls, ldcls, cls_astride, cls_c
         _stream())
     if t0:      # algorithmic bytes: every head logit once + 28 B per candidate
         per_pix = A * (C + 4 + (0 if mode == DECODE_RETINA else 1))
-        TIMER.stop('decode', t0, 4.0 * B * H * W * per_pix + 28.0 * B * A * H * W)
+        TIMER.stop('decode', t0, *[4.0 * B * H * W * per_pix + 28.0 * B * A * H * W] * 2)
     _lib.check(code, 'mydet_decode_f32')
 
 
@@ -363,38 +363,46 @@ def decode_levels(mode, levels, box_astride, box_c0, cls_astride, cls_c0, conf_c
                                               cls_astride, cls_c0, conf_c0, A, C, B, int(img_hw[0]), int(img_hw[1]),
                                               _ptr(bbox), _ptr(class_idx), _ptr(score), bbox.shape[1], _stream())
     if t0:
-        TIMER.stop('decode', t0, work)
+        TIMER.stop('decode', t0, work, work)
     _lib.check(code, 'mydet_decode_levels_f32')
+
+
+def record_views(records):
+    """Field views of a detection-record buffer (int32 [B, REC_WORDS], include/mydet.h MYDET_REC_*): nothing is
+    copied -- the dict the rest of the package works with IS the wire buffer of the multi-GPU exchange."""
+    B = records.shape[0]
+    assert records.dtype == torch.int32 and records.shape[1] == _lib.REC_WORDS and records.is_contiguous()
+    k = _lib.REC_TOPK
+    return {'count': records[:, _lib.REC_COUNT],
+            'bbox': records[:, _lib.REC_BBOX:_lib.REC_SCORE].view(torch.float32).view(B, k, 4),
+            'score': records[:, _lib.REC_SCORE:_lib.REC_CLASS].view(torch.float32),
+            'class_idx': records[:, _lib.REC_CLASS:_lib.REC_INDEX].view(torch.int64),
+            'index': records[:, _lib.REC_INDEX:_lib.REC_WORDS],
+            'records': records}
 
 
 def postprocess(bbox, class_idx, score, conf_thres, nms_thres, topk=TOPK):
     """Batched filter/top-k/class-aware NMS.  bbox [B,N,4], class_idx [B,N] i64, score [B,N].
 
-    Returns dict of device tensors: count [B] i32, bbox [B,topk,4], class_idx [B,topk] i64,
-    score [B,topk], index [B,topk] i32.
+    Returns dict of device tensors: count [B] i32, bbox [B,512,4], class_idx [B,512] i64, score [B,512],
+    index [B,512] i32 -- all views of 'records' (int32 [B, REC_WORDS]), which the kernel writes directly in the
+    wire layout of the all-gather (parallel.gather_detections).
     """
     require_gpu(bbox, 'postprocess')
     assert bbox.dtype == torch.float32 and score.dtype == torch.float32 and class_idx.dtype == torch.int64
+    assert topk == TOPK
     bbox, class_idx, score = bbox.contiguous(), class_idx.contiguous(), score.contiguous()
     B, N = score.shape
     dev = bbox.device
-    out = {
-        'count': torch.empty((B,), dtype=torch.int32, device=dev),
-        'bbox': torch.empty((B, topk, 4), dtype=torch.float32, device=dev),
-        'class_idx': torch.empty((B, topk), dtype=torch.int64, device=dev),
-        'score': torch.empty((B, topk), dtype=torch.float32, device=dev),
-        'index': torch.empty((B, topk), dtype=torch.int32, device=dev),
-    }
+    records = torch.empty((B, _lib.REC_WORDS), dtype=torch.int32, device=dev)
     scratch = torch.empty((B, max(N, 1)), dtype=torch.int64, device=dev)
     t0 = TIMER.start() if TIMER else None
-    code = _lib.lib().mydet_postprocess_f32(_ptr(bbox), _ptr(class_idx), _ptr(score), B, N, float(conf_thres),
-                                            float(nms_thres), topk, _ptr(out['count']), _ptr(out['bbox']),
-                                            _ptr(out['class_idx']), _ptr(out['score']), _ptr(out['index']),
-                                            _ptr(scratch), _stream())
+    code = _lib.lib().mydet_postprocess_records_f32(_ptr(bbox), _ptr(class_idx), _ptr(score), B, N, float(conf_thres),
+                                                    float(nms_thres), _ptr(records), _ptr(scratch), _stream())
     if t0:
         TIMER.stop('postprocess', t0, float(B))
-    _lib.check(code, 'mydet_postprocess_f32')
-    return out
+    _lib.check(code, 'mydet_postprocess_records_f32')
+    return record_views(records)
 
 
 def bboxes_iou(a, b, xyxy=False):

@@ -3,15 +3,19 @@ single-process, single-device).
 
 Images are independent (`post_process` is per image, utils/structures.py:92), so a batch is split
 into contiguous shards, one process per GPU runs backbone -> NMS locally, and the only exchange is
-ONE all-gather (RCCL over xGMI; `nccl` backend) of fixed-size detection records:
-    per image  count:i32 | 512 x (cx,cy,w,h:f32) | 512 x score:f32 | 512 x class:i32 | 512 x index:i32
-  = 3585 words = 14 340 B.  32 images/GPU -> 459 KB per rank: latency-bound, one collective, no reduce.
+ONE all-gather (RCCL over xGMI; `nccl` backend) of fixed-size detection records.  The post-process
+kernel writes those records itself (include/mydet.h, MYDET_REC_*):
+    per image  count:i32 +3 pad | 512 x (cx,cy,w,h:f32) | 512 x score:f32 | 512 x class:i64 | 512 x index:i32
+  = 4100 words = 16 400 B.  32 images/GPU -> 525 KB per rank: latency-bound, one collective, no reduce, and
+no pack/unpack pass on either side -- the dict the package works with is a set of views of that buffer.
 """
 import torch
 import torch.distributed as dist
 
-TOPK = 512
-WORDS = 1 + TOPK * 4 + TOPK * 3
+from . import _lib
+
+TOPK = _lib.REC_TOPK
+WORDS = _lib.REC_WORDS
 
 
 def shard_range(total, rank, world):
@@ -21,41 +25,53 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def pack_records(rec):
-    """dict of tensors (ops.postprocess output) -> int32 [B, WORDS] wire buffer."""
+def record_views(records):
+    """Field views of an int32 [B, WORDS] record buffer (any device)."""
+    from .ops import record_views as views
+    return views(records)
+
+
+def make_records(rec):
+    """dict of separate tensors (count, bbox, score, class_idx, index) -> record dict backed by one buffer.
+    Only for records that did not come from `ops.postprocess` (tests, host-side tools)."""
+    if 'records' in rec:
+        return rec
     B = rec['count'].shape[0]
-    buf = torch.empty((B, WORDS), dtype=torch.int32, device=rec['count'].device)
-    buf[:, 0] = rec['count']
-    o = 1
-    buf[:, o:o + TOPK * 4] = rec['bbox'].reshape(B, TOPK * 4).view(torch.int32); o += TOPK * 4
-    buf[:, o:o + TOPK] = rec['score'].view(torch.int32); o += TOPK
-    buf[:, o:o + TOPK] = rec['class_idx'].to(torch.int32); o += TOPK
-    buf[:, o:o + TOPK] = rec['index']
-    return buf
+    buf = torch.zeros((B, WORDS), dtype=torch.int32, device=rec['count'].device)
+    out = record_views(buf)
+    for k in ('count', 'bbox', 'score', 'class_idx', 'index'):
+        out[k].copy_(rec[k])
+    return out
 
 
-def unpack_records(buf):
-    B = buf.shape[0]
-    o = 1
-    bbox = buf[:, o:o + TOPK * 4].contiguous().view(torch.float32).reshape(B, TOPK, 4); o += TOPK * 4
-    score = buf[:, o:o + TOPK].contiguous().view(torch.float32); o += TOPK
-    cls = buf[:, o:o + TOPK].to(torch.int64); o += TOPK
-    index = buf[:, o:o + TOPK].contiguous()
-    return {'count': buf[:, 0].contiguous(), 'bbox': bbox, 'class_idx': cls, 'score': score, 'index': index}
-
-
-def gather_detections(rec, group=None, always=False):
-    """All ranks end up with the records of the whole batch in rank order (equal shard sizes).
-    `always` runs the collective even for a one-rank group (used to rehearse the RCCL path on one GPU)."""
+def gather_detections(rec, group=None, always=False, total=None):
+    """All ranks end up with the records of the whole batch in image order.  `rec`: this rank's shard (contiguous,
+    `shard_range`).  Shards of unequal size are padded to the largest one for the collective and the padding rows
+    dropped afterwards; `total` (the global image count) is required then and checked otherwise.
+    `always` runs the collective even for a one-rank group (rehearses the RCCL path on one GPU)."""
     if not (dist.is_available() and dist.is_initialized()):
         return rec
-    if dist.get_world_size(group) == 1 and not always:
-        return rec
-    buf = pack_records(rec)
     world = dist.get_world_size(group)
-    out = torch.empty((world * buf.shape[0], WORDS), dtype=torch.int32, device=buf.device)
+    if world == 1 and not always:
+        return rec
+    rank = dist.get_rank(group)
+    buf = make_records(rec)['records']
+    B = buf.shape[0]
+    if total is None:
+        total = B * world                   # equal shards; a mismatch across ranks fails in the collective's size check
+    lo, hi = shard_range(total, rank, world)
+    if hi - lo != B:
+        raise ValueError(f'rank {rank} holds {B} images but shard_range({total}, {rank}, {world}) is [{lo}, {hi})')
+    cap = -(-total // world)                # largest shard
+    if B < cap:
+        buf = torch.cat([buf, buf.new_zeros((cap - B, WORDS))])
+    out = torch.empty((world * cap, WORDS), dtype=torch.int32, device=buf.device)
     dist.all_gather_into_tensor(out, buf, group=group)
-    return unpack_records(out)
+    if total != world * cap:                # drop the padding row of the short shards
+        keep = torch.cat([torch.arange(r * cap, r * cap + (lambda a: a[1] - a[0])(shard_range(total, r, world)))
+                          for r in range(world)]).to(out.device)
+        out = out.index_select(0, keep)
+    return record_views(out)
 
 
 def records_to_objects(rec, img_hw=None, bb_format='cxcywh'):

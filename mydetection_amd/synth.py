@@ -280,3 +280,11 @@ def make_normalized_images(batch: int, size, seed: int = 0, kind: str = 'rects')
     mean = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1)
     std = torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
     return (x - mean) / std
+
+
+def make_image_set(lo: int, hi: int, size, input_format: str = 'RGB_1', base_seed: int = 1000) -> torch.Tensor:
+    """Images [lo, hi) of ONE global synthetic batch: image i is a pure function of i (its own seed), so any
+    contiguous sharding of the batch over ranks reproduces the same images (bench.py, multi-GPU verification).
+    input_format: 'RGB_1' or 'RGB_1_norm' (general.input_format of the configuration)."""
+    make = make_images if input_format == 'RGB_1' else make_normalized_images
+    return torch.cat([make(1, size, seed=base_seed + i) for i in range(lo, hi)], dim=0)

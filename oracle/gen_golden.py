@@ -89,18 +89,12 @@ MEAN = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)       # utils/image_
 STD = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
 
 
-def _check_decision_margins(scores, det_cats, det_scores, conf, what, eps=2e-5):
+def _check_decision_margins(scores, cats, conf, what):
     """A fixture must not hinge on float32 round-off ('bit-exact NMS indices is only well-posed on
-    margin-safe inputs'): no candidate within eps of the confidence threshold, a gap at the top-512 boundary, and no
-    two kept detections of one class within eps of each other's score."""
-    top = np.sort(scores)[::-1][:513]        # the threshold only decides among candidates the top-512 cut would keep
-    assert np.abs(top - conf).min() > eps, f'{what}: a score sits on the confidence threshold'
-    passed = np.sort(scores[scores >= conf])[::-1]
-    if len(passed) > 512:
-        assert passed[511] - passed[512] > eps, f'{what}: tie at the top-512 boundary'
-    for c in np.unique(det_cats):
-        s = np.sort(det_scores[det_cats == c])
-        assert len(s) < 2 or np.diff(s).min() > eps, f'{what}: two detections of class {c} with (nearly) equal scores'
+    margin-safe inputs'); oracle.postprocess.decision_margins names what would."""
+    from oracle.postprocess import decision_margins
+    why = decision_margins(scores, cats, conf)
+    assert why is None, f'{what}: {why}'
 
 
 def gen_efficientdet(config, size=256, batch=1):
@@ -169,7 +163,7 @@ def _gen_efficientdet(model, cfg, config, size, batch, seed):
             out[f'pp_{tag}_conf'], out[f'pp_{tag}_nms'] = np.float64(conf), np.float64(nms)
             out[f'pp_{tag}_bboxes_{b}'], out[f'pp_{tag}_cats_{b}'], out[f'pp_{tag}_scores_{b}'] = \
                 _np(d.bboxes), _np(d.cats), _np(d.scores)
-            _check_decision_margins(out[f'scores_{b}'], out[f'pp_{tag}_cats_{b}'], out[f'pp_{tag}_scores_{b}'], conf, f'{config} {tag}')
+            _check_decision_margins(out[f'scores_{b}'], out[f'cats_{b}'], conf, f'{config} {tag}')
     name = config.replace('-', '_') + f'_b{batch}_{size}'
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
     print(name, 'N', out['bboxes_0'].shape[0], 'dets', {t: out[f'pp_{t}_cats_0'].shape[0] for t in ('ap', 'mid', 'demo')})

@@ -150,3 +150,24 @@ def bboxes_to_original(bboxes, pad_info):
     b[:, 2] = b[:, 2] / f(imw) * f(ori_w)
     b[:, 3] = b[:, 3] / f(imh) * f(ori_h)
     return b
+
+
+def decision_margins(scores, cats, conf, eps=2e-5, topk=512):
+    """None when post-processing these candidates cannot hinge on float32 round-off of size eps, else the reason:
+    a top-k candidate on the confidence threshold, a tie at the top-k boundary, or two same-class candidates that
+    enter NMS with (nearly) equal scores (round-off would decide which suppresses the other).  Used by the fixture
+    generator and by the tests that compare detection sets computed from two float32 forwards."""
+    order = np.argsort(-scores, kind='stable')
+    top = scores[order[:topk + 1]]
+    if len(top) and np.abs(top - conf).min() <= eps:
+        return 'a score sits on the confidence threshold'
+    sel = order[scores[order] >= conf]
+    if len(sel) > topk:
+        if scores[sel[topk - 1]] - scores[sel[topk]] <= eps:
+            return f'tie at the top-{topk} boundary'
+        sel = sel[:topk]
+    for c in np.unique(cats[sel]):
+        s = np.sort(scores[sel][cats[sel] == c])
+        if len(s) >= 2 and np.diff(s).min() <= eps:
+            return f'two class-{c} candidates with (nearly) equal scores enter NMS'
+    return None

@@ -210,19 +210,22 @@ def test_effdet_family_vs_oracle_640(effdet):
     np.testing.assert_allclose(bb.cpu().numpy(), ob.numpy(), rtol=RTOL, atol=ATOL)
     flips = (ci.cpu() != oc)
     assert flips.sum().item() <= 4, f'{flips.sum().item()} class-id differences'     # exact up to numerically tied classes
+    compared = 0
     for conf in (0.005, 0.5):
         rec = batched_post_process(bb, ci, sc, conf, cfg['test.nms_thres'])
         for i in range(2):
             rb, rc, rs, src = opp.post_process(ob[i].numpy(), oc[i].numpy(), os_[i].numpy(), conf, cfg['test.nms_thres'])
             k = int(rec['count'][i])
             assert len(src) >= 50
-            if flips[i][torch.from_numpy(src)].any():
-                continue                                    # a tied class id among the kept candidates: undefined order
+            if flips[i].any() or opp.decision_margins(os_[i].numpy(), oc[i].numpy(), conf) is not None:
+                continue            # a decision of this image hinges on float32 round-off: the detection set is not defined
+            compared += 1
             assert k == len(src), f'{name} conf {conf} image {i}: {k} vs {len(src)} detections'
             np.testing.assert_array_equal(rec['index'][i, :k].cpu().numpy().astype(np.int64), src)
             np.testing.assert_array_equal(rec['class_idx'][i, :k].cpu().numpy(), rc)
             np.testing.assert_allclose(rec['score'][i, :k].cpu().numpy(), rs, rtol=RTOL, atol=ATOL)
             np.testing.assert_allclose(rec['bbox'][i, :k].cpu().numpy(), rb, rtol=RTOL, atol=ATOL)
+    assert compared >= 1, 'no margin-safe (image, threshold) pair: pick another image seed'
 
 
 @pytest.mark.parametrize('name,batch', [('efficientdet-d1', 16), ('d1_fcs2_atss', 32)])

@@ -27,8 +27,13 @@ def test_argument_errors_are_reported_before_launch():
     null = ctypes.c_void_p(0)
     assert lib.mydet_conv2d_igemm_f32(null, 0, null, null, null, null, 0, null, null, 0, null, 0, 1, 1, 1, 4, 4, 1, 1, 1, 0, 0,
                                       1, 1, 0, null) == -1
-    assert lib.mydet_postprocess_f32(null, null, null, 1, 1 << 17, 0.5, 0.5, 512, null, null, null, null, null, null,
+    assert lib.mydet_postprocess_f32(null, null, null, 1, 1 << 20, 0.5, 0.5, 512, null, null, null, null, null, null,
                                      null) == -2
+    assert lib.mydet_postprocess_records_f32(null, null, null, 1, 1 << 20, 0.5, 0.5, null, null, null) == -2
+    assert lib.mydet_postprocess_records_f32(null, null, null, 1, 100, 0.5, 0.5, null, null, null) == -1
+    header = open(os.path.join(ROOT, 'include', 'mydet.h')).read()
+    words = {m.group(1): m.group(2) for m in re.finditer(r'#define MYDET_REC_(\w+)\s+(.+)', header)}
+    assert int(words['TOPK']) == _lib.REC_TOPK and int(words['BBOX']) == _lib.REC_BBOX and _lib.REC_WORDS == 4100
     assert lib.mydet_conv2d_wino_f32(null, 0, null, null, null, null, 0, null, 0, null, 0, 1, 8, 8, 8, 8, 0, null) == -1
     assert lib.mydet_wino_weights_floats(64, 12) == 0 and lib.mydet_wino_weights_floats(70, 16) == 16 * 16 * 128
     with pytest.raises(_lib.MydetError):

@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: the multi-GPU exchange (shard -> pack records -> ONE all-gather -> unpack)."""
+"""CPU, world_size 2 over gloo: the multi-GPU exchange (shard -> ONE all-gather of the fixed-size records -> views)."""
 import os
 import socket
 
@@ -22,45 +22,62 @@ def _fake_records(rank, B):
             'score': torch.rand(B, 512, generator=g), 'index': torch.randint(0, 25200, (B, 512), generator=g, dtype=torch.int32)}
 
 
-def _worker(rank, world, port, B, q):
+def _worker(rank, world, port, total, q):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from mydetection_amd import parallel
-    rec = _fake_records(rank, B)
-    allrec = parallel.gather_detections(rec)
-    ok = allrec['count'].shape[0] == world * B
-    for r in range(world):
-        ref = _fake_records(r, B)
-        for k in ref:
-            ok = ok and torch.equal(allrec[k][r * B:(r + 1) * B], ref[k])
+    lo, hi = parallel.shard_range(total, rank, world)
+    glob = _fake_records(0, total)                       # the 1-process result for the whole batch
+    rec = {k: v[lo:hi].clone() for k, v in glob.items()}  # this rank's shard
+    allrec = parallel.gather_detections(rec, total=total)
+    ok = allrec['count'].shape[0] == total
+    for k in glob:
+        ok = ok and torch.equal(allrec[k], glob[k])
     objs = parallel.records_to_objects(allrec, img_hw=(640, 640))
-    ok = ok and len(objs) == world * B and all(len(o) == int(c) for o, c in zip(objs, allrec['count']))
+    ok = ok and len(objs) == total and all(len(o) == int(c) for o, c in zip(objs, allrec['count']))
+    try:                                                  # a shard that is not this rank's range is rejected loudly
+        parallel.gather_detections({k: v[:1] for k, v in rec.items()}, total=total + 2 * world)
+        ok = False
+    except ValueError:
+        pass
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
 
-def test_gather_detections_world2():
-    world, B = 2, 3
+def _run_world(world, total):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, B, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in range(world))
     for p in procs:
         p.join(60)
-    assert res == [(0, True), (1, True)]
+    assert res == [(r, True) for r in range(world)]
+
+
+def test_gather_detections_world2():
+    """gathered records == the single-process records of the same batch, even split."""
+    _run_world(2, 6)
+
+
+def test_gather_detections_world2_uneven():
+    """7 images over 2 ranks (4 + 3): the short shard is padded for the collective and the padding dropped."""
+    _run_world(2, 7)
 
 
 def test_pack_unpack_roundtrip_and_sharding():
     from mydetection_amd import parallel
     rec = _fake_records(0, 4)
-    out = parallel.unpack_records(parallel.pack_records(rec))
+    out = parallel.make_records(rec)
     for k in rec:
         assert torch.equal(out[k], rec[k]), k
-    assert parallel.WORDS * 4 == 14340
+    again = parallel.record_views(out['records'].clone())
+    for k in rec:
+        assert torch.equal(again[k], rec[k]), k
+    assert parallel.WORDS * 4 == 16400 and parallel.make_records(out) is out
     cover = []
     for r in range(8):
         lo, hi = parallel.shard_range(256, r, 8)
