@@ -217,7 +217,7 @@ def test_effdet_family_vs_oracle_640(effdet):
             rb, rc, rs, src = opp.post_process(ob[i].numpy(), oc[i].numpy(), os_[i].numpy(), conf, cfg['test.nms_thres'])
             k = int(rec['count'][i])
             assert len(src) >= 50
-            if flips[i].any() or opp.decision_margins(os_[i].numpy(), oc[i].numpy(), conf) is not None:
+            if flips[i].any() or opp.decision_margins(os_[i].numpy(), oc[i].numpy(), conf, eps=1e-5) is not None:
                 continue            # a decision of this image hinges on float32 round-off: the detection set is not defined
             compared += 1
             assert k == len(src), f'{name} conf {conf} image {i}: {k} vs {len(src)} detections'
@@ -225,7 +225,7 @@ def test_effdet_family_vs_oracle_640(effdet):
             np.testing.assert_array_equal(rec['class_idx'][i, :k].cpu().numpy(), rc)
             np.testing.assert_allclose(rec['score'][i, :k].cpu().numpy(), rs, rtol=RTOL, atol=ATOL)
             np.testing.assert_allclose(rec['bbox'][i, :k].cpu().numpy(), rb, rtol=RTOL, atol=ATOL)
-    assert compared >= 1, 'no margin-safe (image, threshold) pair: pick another image seed'
+    assert compared >= 2, 'fewer than two margin-safe (image, threshold) pairs: pick another image seed'
 
 
 @pytest.mark.parametrize('name,batch', [('efficientdet-d1', 16), ('d1_fcs2_atss', 32)])
