@@ -228,6 +228,36 @@ int mydet_postprocess_records_f32(const float *bbox, const int64_t *class_idx, c
                                   int B, int64_t N, float conf_thres, double nms_thres,
                                   int32_t *records, void *scratch, void *stream);
 
+/* Fused separable-conv node of the 88-channel BiFPN / EfDetHead pyramid, several nodes per launch:
+ *     y = act( pointwise1x1( depthwise3x3_pad1( pre(in...) ) ) * scale + shift )
+ *   n_in == 1: pre = identity                 spconv3x3_bn_swish / last sepconv of a head tower, models/rpns.py:121-205
+ *   n_in >= 2: pre = swish(sum_i w_i * in_i), w = relu(fuse_weights) / (sum + 1e-4)     LinearFusion, models/fpns.py:421-439;
+ *              mode[i]: 0 same size, 1 half-size map read through nearest 2x, 2 double-size map read through
+ *              max_pool2d(3,2,1) (the top-down / bottom-up paths of BiFPN5.forward, models/fpns.py:398-418)
+ * Replaces mydet_bifpn_fuse_f32 + mydet_dwconv_f32 + mydet_conv2d_igemm_f32 for these nodes (SeparableConv2d,
+ * models/modules.py:5-21, with the following BatchNorm folded into scale/shift).
+ * in[i]: logical [B,C,h,w] channels-last, pixel stride ld[i].  w_dw [3][3][C].  w_pw_packed: the pointwise weight
+ * W[Cout][C] in MFMA fragment order, ceil(Cout/16) x (C/4) x 64 floats:
+ *     packed[nb][ks][lane] = W[16*nb + (lane & 15)][4*ks + (lane >> 4)]   (rows >= Cout are zero).
+ * scale may be NULL (no BatchNorm: y = conv + shift).  Cout % 4 == 0.  act: MYDET_ACT_NONE | MYDET_ACT_SWISH.
+ * `nodes` is a HOST array of n (<= MYDET_SEPCONV_MAX_NODES) descriptors; all nodes share B and C (C == 88). */
+#define MYDET_SEPCONV_MAX_NODES 10
+typedef struct {
+    const float *in[3];
+    int64_t ld[3];
+    int mode[3];
+    int n_in;
+    const float *fuse_weights;
+    const float *w_dw;
+    const float *w_pw_packed;
+    const float *scale;
+    const float *shift;
+    float *y;
+    int64_t ldy;
+    int H, W, Cout, act;
+} mydet_sepconv_node;
+int mydet_sepconv_nodes_f32(int n, const mydet_sepconv_node *nodes, int B, int C, void *stream);
+
 /* Pairwise IoU [Na,Nb]; utils/bbox_ops.py:6-49 (xyxy != 0: corner format, else cxcywh). */
 int mydet_bboxes_iou_f32(const float *a, int Na, const float *b, int Nb, int xyxy,
                          float *iou, void *stream);

@@ -36,6 +36,7 @@ SIGNATURES = {
     'mydet_postprocess_f32': [c_ptr, c_ptr, c_ptr, c_int, c_i64, c_f32, c_f64, c_int, c_ptr, c_ptr, c_ptr, c_ptr,
                               c_ptr, c_ptr, c_ptr],
     'mydet_postprocess_records_f32': [c_ptr, c_ptr, c_ptr, c_int, c_i64, c_f32, c_f64, c_ptr, c_ptr, c_ptr],
+    'mydet_sepconv_nodes_f32': [c_int, c_ptr, c_int, c_int, c_ptr],
     'mydet_bboxes_iou_f32': [c_ptr, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr],
     'mydet_preprocess_u8_f32': [c_ptr, c_int, c_int, c_int, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr],
     'mydet_bboxes_to_original_f32': [c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_ptr],
@@ -59,6 +60,15 @@ class DecodeLevel(ctypes.Structure):
     _fields_ = [('box', c_ptr), ('ldbox', c_i64), ('cls', c_ptr), ('ldcls', c_i64), ('anchors_wh', c_ptr),
                 ('H', c_int), ('W', c_int), ('stride', c_f32), ('n_off', c_i64)]
 
+
+class SepconvNode(ctypes.Structure):
+    """mydet_sepconv_node (include/mydet.h)."""
+    _fields_ = [('inp', c_ptr * 3), ('ld', c_i64 * 3), ('mode', c_int * 3), ('n_in', c_int), ('fuse_weights', c_ptr),
+                ('w_dw', c_ptr), ('w_pw_packed', c_ptr), ('scale', c_ptr), ('shift', c_ptr), ('y', c_ptr), ('ldy', c_i64),
+                ('H', c_int), ('W', c_int), ('Cout', c_int), ('act', c_int)]
+
+
+SEPCONV_MAX_NODES = 10
 
 _lib = None
 

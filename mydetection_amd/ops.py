@@ -296,6 +296,75 @@ def bifpn_fuse(inputs, modes, weights):
     return out
 
 
+def pack_pointwise(w):
+    """Pointwise weight [Cout, C] (or OHWI [Cout,1,1,C]) in the MFMA fragment order `sepconv_nodes` reads:
+    packed[nb][ks][lane] = W[16*nb + (lane & 15)][4*ks + (lane >> 4)], rows >= Cout zero (include/mydet.h)."""
+    w = w.reshape(w.shape[0], -1).float()
+    Cout, C = w.shape
+    assert C % 4 == 0
+    nb = (Cout + 15) // 16
+    wp = w.new_zeros((nb * 16, C))
+    wp[:Cout] = w
+    return wp.view(nb, 16, C // 4, 4).permute(0, 2, 3, 1).contiguous()
+
+
+SEPCONV_CHANNELS = (88,)        # instantiated channel counts of the fused node kernel
+
+
+def sepconv_nodes(nodes):
+    """Fused [fusion + swish ->] depthwise 3x3 -> pointwise 1x1 (+ folded BN, act) nodes, up to 10 per launch.
+    nodes: list of dicts with keys inputs (1-3 tensors [B,C,h,w]), modes (FUSE_*), fuse_weights (raw, for >= 2 inputs),
+    w_dw [3,3,C], w_pw (pack_pointwise), scale (or None), shift, cout, act, and optionally out (a tensor to write).
+    Returns the output tensors."""
+    assert 1 <= len(nodes) <= _lib.SEPCONV_MAX_NODES
+    arr = (_lib.SepconvNode * len(nodes))()
+    outs, keep = [], []
+    B = C = None
+    work = 0.0
+    for i, nd in enumerate(nodes):
+        prepared = [to_nhwc(t) for t in nd['inputs']]
+        require_gpu(prepared[0][0], 'sepconv_nodes')
+        modes = list(nd.get('modes') or [FUSE_SAME] * len(prepared))
+        ref = next(t for (t, _), m in zip(prepared, modes) if m == FUSE_SAME)
+        b, c, H, W = ref.shape
+        B, C = (b, c) if B is None else (B, C)
+        assert (b, c) == (B, C), 'all nodes of a launch share batch and channels'
+        for (t, _), m in zip(prepared, modes):
+            exp = {FUSE_SAME: (H, W), FUSE_UP2X: (H // 2, W // 2), FUSE_POOL: (H * 2, W * 2)}[m]
+            assert tuple(t.shape) == (B, C) + exp, (tuple(t.shape), m, (B, C, H, W))
+        cout = nd['cout']
+        out = nd.get('out')
+        if out is None:
+            out, ldy = empty_nhwc(B, cout, H, W, ref.device)
+        else:
+            ldy = nhwc_ld(out)
+            assert ldy is not None and tuple(out.shape) == (B, cout, H, W)
+        n_in = len(prepared)
+        node = arr[i]
+        for k in range(3):
+            node.inp[k] = prepared[k][0].data_ptr() if k < n_in else None
+            node.ld[k] = prepared[k][1] if k < n_in else 0
+            node.mode[k] = int(modes[k]) if k < n_in else 0
+        node.n_in = n_in
+        fw = nd.get('fuse_weights')
+        node.fuse_weights = fw.data_ptr() if n_in > 1 else None
+        node.w_dw, node.w_pw_packed = nd['w_dw'].data_ptr(), nd['w_pw'].data_ptr()
+        node.scale = nd['scale'].data_ptr() if nd.get('scale') is not None else None
+        node.shift = nd['shift'].data_ptr()
+        node.y, node.ldy, node.H, node.W, node.Cout, node.act = out.data_ptr(), ldy, H, W, cout, int(nd.get('act', ACT_NONE))
+        keep.append((prepared, fw, out))
+        outs.append(out)
+        # algorithmic bytes of the reference layers this node replaces: fusion (n+1 maps), depthwise (2), pointwise (C + Cout)
+        px = 4.0 * B * H * W
+        work += px * ((C * (n_in + 1) if n_in > 1 else 0) + 2 * C + C + cout)
+    t0 = TIMER.start() if TIMER else None
+    code = _lib.lib().mydet_sepconv_nodes_f32(len(nodes), ctypes.cast(arr, ctypes.c_void_p), B, C, _stream())
+    if t0:
+        TIMER.stop('sepconv_nodes', t0, work, work)
+    _lib.check(code, 'mydet_sepconv_nodes_f32')
+    return outs
+
+
 def upsample_concat(a, size, b=None):
     """cat((nearest_resize(a, size), b), dim=1) in one pass."""
     require_gpu(a, 'upsample_concat')

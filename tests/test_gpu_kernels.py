@@ -425,3 +425,72 @@ def test_post_process_randomised_sweep_vs_oracle(dev):
             assert k == len(src), (trial, i, N, n_cls, conf, thr, k, len(src))
             np.testing.assert_array_equal(rec['index'][i, :k].cpu().numpy().astype(np.int64), src)
             np.testing.assert_array_equal(rec['score'][i, :k].cpu().numpy(), os_)
+
+
+def _sepconv_ref(inputs, modes, fuse_w, w_dw, w_pw, scale, shift, act):
+    """float64 restatement of one pyramid node: [fusion + swish ->] depthwise 3x3 -> pointwise (+BN fold, act)."""
+    ins = []
+    for t, m in zip(inputs, modes):
+        t = t.double()
+        if m == 1:
+            t = F.interpolate(t, scale_factor=(2, 2), mode='nearest')
+        elif m == 2:
+            t = F.max_pool2d(t, 3, 2, 1)
+        ins.append(t)
+    if len(ins) > 1:
+        w = F.relu(fuse_w.double())
+        w = w / (w.sum() + 0.0001)
+        x = sum([wi * f for wi, f in zip(w, ins)])
+        x = x * torch.sigmoid(x)
+    else:
+        x = ins[0]
+    C = x.shape[1]
+    y = F.conv2d(x, w_dw.double().permute(2, 0, 1).reshape(C, 1, 3, 3), None, 1, 1, 1, C)
+    y = F.conv2d(y, w_pw.double().reshape(w_pw.shape[0], C, 1, 1))
+    y = y * (scale.double().view(1, -1, 1, 1) if scale is not None else 1.0) + shift.double().view(1, -1, 1, 1)
+    return y * torch.sigmoid(y) if act == 2 else y
+
+
+def test_sepconv_nodes_vs_fp64(dev):
+    """The fused pyramid node (fusion + swish -> depthwise 3x3 -> pointwise on FP32 MFMA -> BN/act) against float64:
+    every pre-stage (identity, 2-input with nearest-2x, 3-input with the 3x3/2 max pool), odd / partial tiles (5x5,
+    10x10, 13x7), all Cout of the D1 family (88, 720, 36, 4), with and without BatchNorm, several nodes per launch --
+    and against the three-launch path it replaces."""
+    from mydetection_amd import ops
+    g = torch.Generator().manual_seed(17)
+    C, B = 88, 3
+
+    def node(hw, n_in, cout, act, bn, modes=None):
+        H, W = hw
+        modes = modes or [0] * n_in
+        shapes = {0: (H, W), 1: (H // 2, W // 2), 2: (H * 2, W * 2)}
+        inputs = [torch.randn(B, C, *shapes[m], generator=g) for m in modes]
+        return dict(inputs=inputs, modes=modes, fuse_w=torch.tensor([0.8, 1.3, -0.4][:n_in]) if n_in > 1 else None,
+                    w_dw=torch.randn(3, 3, C, generator=g) / 3.0, w_pw=torch.randn(cout, C, generator=g) / C ** 0.5,
+                    scale=torch.rand(cout, generator=g) + 0.5 if bn else None, shift=torch.randn(cout, generator=g) * 0.2,
+                    cout=cout, act=act)
+
+    groups = [
+        [node((16, 16), 1, 88, 2, True), node((5, 5), 1, 88, 2, True), node((10, 10), 1, 88, 2, True), node((13, 7), 1, 88, 2, True)],
+        [node((8, 8), 2, 88, 0, True, [0, 1]), node((10, 10), 3, 88, 0, True, [0, 0, 2]), node((20, 20), 2, 88, 0, True, [0, 2])],
+        [node((9, 9), 1, 720, 0, False), node((9, 9), 1, 36, 0, False), node((6, 5), 1, 4, 0, False)],
+    ]
+    for grp in groups:
+        dev_nodes = [dict(inputs=[t.to(dev).contiguous(memory_format=torch.channels_last) for t in nd['inputs']], modes=nd['modes'],
+                          fuse_weights=nd['fuse_w'].to(dev) if nd['fuse_w'] is not None else None,
+                          w_dw=nd['w_dw'].to(dev), w_pw=ops.pack_pointwise(nd['w_pw'].to(dev)),
+                          scale=nd['scale'].to(dev) if nd['scale'] is not None else None, shift=nd['shift'].to(dev),
+                          cout=nd['cout'], act=nd['act']) for nd in grp]
+        outs = ops.sepconv_nodes(dev_nodes)
+        again = ops.sepconv_nodes(dev_nodes)
+        for nd, dn, y, y2 in zip(grp, dev_nodes, outs, again):
+            ref = _sepconv_ref(nd['inputs'], nd['modes'], nd['fuse_w'], nd['w_dw'], nd['w_pw'], nd['scale'], nd['shift'], nd['act'])
+            assert y.shape == ref.shape
+            err = (y.cpu().double() - ref).abs().max().item()
+            assert err <= 2e-5 * max(1.0, ref.abs().max().item()), (nd['cout'], nd['modes'], err)
+            assert torch.equal(y, y2)
+            # the three launches it replaces
+            x = dn['inputs'][0] if len(dn['inputs']) == 1 else ops.bifpn_fuse(dn['inputs'], dn['modes'], dn['fuse_weights'])
+            t = ops.dwconv(x, dn['w_dw'], None, None, 3, 1, (1, 1, 1, 1), ops.ACT_NONE)
+            old = ops.conv2d(t, nd['w_pw'].reshape(nd['cout'], 1, 1, C).to(dev), dn['scale'], dn['shift'], 1, 1, (0, 0, 0, 0), nd['act'])
+            assert (y - old).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
