@@ -144,5 +144,7 @@ class LinearFusion(nn.Module):
         assert isinstance(features, (list, tuple)) and len(features) == self.num
         tensors = [f[0] if isinstance(f, tuple) else f for f in features]
         modes = [f[1] if isinstance(f, tuple) else ops.FUSE_SAME for f in features]
+        if self.spconv_bn.fusable():          # fusion + swish + depthwise + pointwise + BN: one launch
+            return ops.sepconv_nodes([self.spconv_bn.node(tensors, modes, self.weights.detach())])[0]
         fused = ops.bifpn_fuse(tensors, modes, self.weights.detach())
         return self.spconv_bn(fused)

@@ -123,9 +123,31 @@ class SeparableConv2d(nn.Module):
         self.depthwise = nn.Conv2d(in_ch, in_ch, kernel_size, stride, padding=padding, groups=in_ch, bias=False)
         self.pointwise = nn.Conv2d(in_ch, out_ch, 1, 1, padding=0)
 
+    def fusable(self):
+        """True when the fused node kernel (ops.sepconv_nodes) covers this layer: 3x3, stride 1, pad 1, an
+        instantiated channel count."""
+        return (ops.FUSED_NODES and self.k == 3 and self.s == 1 and self.p == 1
+                and self.depthwise.in_channels in ops.SEPCONV_CHANNELS and self.pointwise.out_channels % 4 == 0)
+
+    def node(self, inputs, modes=None, fuse_weights=None, bn=None, act=ops.ACT_NONE, out=None):
+        """Descriptor of this layer for `ops.sepconv_nodes` (several layers share one launch)."""
+        if self.training:
+            raise NotImplementedError('mydetection_amd implements the inference path only; call model.eval()')
+        wd, _, _ = prepare_conv(self, 'dw', self.depthwise, None, depthwise=True)
+        wp, scale, shift = prepare_conv(self, ('pw', id(bn)), self.pointwise, bn)
+        cache = self.__dict__.setdefault('_prep_cache', {})
+        hit = cache.get(('pwk', id(bn)))
+        if hit is None or hit[0] is not wp:
+            hit = (wp, ops.pack_pointwise(wp))
+            cache[('pwk', id(bn))] = hit
+        return dict(inputs=list(inputs), modes=modes, fuse_weights=fuse_weights, w_dw=wd, w_pw=hit[1], scale=scale,
+                    shift=shift, cout=self.pointwise.out_channels, act=act, out=out)
+
     def forward(self, x, bn=None, act=ops.ACT_NONE):
         if self.training:
             raise NotImplementedError('mydetection_amd implements the inference path only; call model.eval()')
+        if self.fusable():
+            return ops.sepconv_nodes([self.node([x], bn=bn, act=act)])[0]
         wd, _, _ = prepare_conv(self, 'dw', self.depthwise, None, depthwise=True)
         x = ops.dwconv(x, wd, None, None, self.k, self.s, (self.p,) * 4, ops.ACT_NONE)
         wp, scale, shift = prepare_conv(self, ('pw', id(bn)), self.pointwise, bn)
@@ -154,6 +176,12 @@ class SpconvBn(nn.Sequential):
             mods.append(Swish())
         super().__init__(*mods)
         self.act = ops.ACT_SWISH if swish else ops.ACT_NONE
+
+    def fusable(self):
+        return self[0].fusable()
+
+    def node(self, inputs, modes=None, fuse_weights=None, out=None):
+        return self[0].node(inputs, modes, fuse_weights, bn=self[1], act=self.act, out=out)
 
     def forward(self, x):
         return self[0](x, bn=self[1], act=self.act)

@@ -118,11 +118,33 @@ class EfDetHead(nn.Module):
         self.bb_param = bb_param
         self.enable_conf = enable_conf
 
+    def _towers(self, features):
+        """Class and box predictions of every level.  When the fused node kernel covers the tower layers, the layers of
+        equal depth of all levels and both towers share ONE launch (10 nodes), so the 5x5 ... 80x80 maps of a depth
+        are one grid instead of twenty launches."""
+        n = len(features)
+        if not all(m.fusable() for net in list(self.class_nets) + list(self.bbox_nets) for m in list(net)[:-1]):
+            return [(self.class_nets[i](x), self.bbox_nets[i](x)) for i, x in enumerate(features)]
+        cls_t, box_t = list(features), list(features)
+        depth = len(self.class_nets[0]) - 1
+        for r in range(depth):
+            outs = ops.sepconv_nodes([self.class_nets[i][r].node([cls_t[i]]) for i in range(n)]
+                                     + [self.bbox_nets[i][r].node([box_t[i]]) for i in range(n)])
+            cls_t, box_t = outs[:n], outs[n:]
+        last = [self.bbox_nets[i][depth] for i in range(n)]
+        cls_last = [self.class_nets[i][depth] for i in range(n)]
+        if all(isinstance(m, SeparableConv2d) and m.fusable() for m in last + cls_last):
+            outs = ops.sepconv_nodes([m.node([t]) for m, t in zip(cls_last, cls_t)] + [m.node([t]) for m, t in zip(last, box_t)])
+            return list(zip(outs[:n], outs[n:]))
+        if all(isinstance(m, SeparableConv2d) and m.fusable() for m in last):
+            box = ops.sepconv_nodes([m.node([t]) for m, t in zip(last, box_t)])
+        else:
+            box = [m(t) for m, t in zip(last, box_t)]
+        return [(m(t), b) for m, t, b in zip(cls_last, cls_t, box)]
+
     def forward(self, features: list):
         all_level_preds = []
-        for i, x in enumerate(features):
-            cls_pred = self.class_nets[i](x)
-            bbox_pred = self.bbox_nets[i](x)
+        for i, (cls_pred, bbox_pred) in enumerate(self._towers(features)):
             nB, _, nH, nW = bbox_pred.shape
             nA = self.n_anch
             per_cls = self.n_cls + 1 if self.enable_conf else self.n_cls

@@ -309,6 +309,8 @@ def pack_pointwise(w):
 
 
 SEPCONV_CHANNELS = (88,)        # instantiated channel counts of the fused node kernel
+# MYDET_FUSED_NODES=0 keeps the pyramid on the three-launch path (fusion, depthwise, pointwise GEMM): A/B measurements
+FUSED_NODES = os.environ.get('MYDET_FUSED_NODES', '1') != '0'
 
 
 def sepconv_nodes(nodes):
