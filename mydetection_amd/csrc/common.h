@@ -12,6 +12,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline int mydet_launch_status() { return (int)hipGetLastError(); }
 
+// Compute units of the current device (256 on MI355X), read once.
+static inline int mydet_cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n = v;
+        else
+            n = 256;
+    }
+    return n;
+}
+
 __device__ __forceinline__ float mydet_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
 
 // Logistic for the swish epilogues of the conv / depthwise / fusion kernels: v_exp_f32 on -v*log2(e) (product formed
@@ -29,6 +42,15 @@ __device__ __forceinline__ float mydet_act(float v, int act) {
     if (act == MYDET_ACT_LEAKY) return v > 0.0f ? v : v * 0.1f;
     if (act == MYDET_ACT_SWISH) return v * mydet_sigmoid_fast(v);
     return v;
+}
+
+// Workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight across it (a plain
+// __syncthreads() drains them with s_waitcnt vmcnt(0)), which is what lets a kernel prefetch its next tile into
+// registers while the current one is computed.
+__device__ __forceinline__ void mydet_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 // Bijective XCD-aware remap (8 XCDs, blocks dealt round-robin): blocks that land on one

@@ -20,6 +20,8 @@
 //      owns 16 pixels; the weights come pre-packed in fragment order (one coalesced 256-B load per k-step).
 // LDS 35 KB -> 4 workgroups per CU: the halo loads of one overlap the MFMAs of another.
 // Built with -ffp-contract=off: the fusion arithmetic rounds like the reference's separate mul / add ops.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -35,11 +37,11 @@ struct SpNode {
     const float *fuse_w, *wd, *wpk, *scale, *shift;
     float *y;
     int64_t ldy;
-    int H, W, Cout, act, nb;
+    int H, W, Cout, act, nb, nsplit, nb_per;
     int tiles_x, tiles_per_img, tile_begin;
 };
 struct SpArgs {
-    int n, B;
+    int n, B, total;
     SpNode p[SP_MAX];
 };
 
@@ -51,23 +53,82 @@ __device__ __forceinline__ f32x4 sp_read(const SpNode &P, int i, int64_t b, int 
         const int Hs = P.H >> 1, Ws = P.W >> 1;
         return *reinterpret_cast<const f32x4 *>(x + ((b * Hs + (oh >> 1)) * Ws + (ow >> 1)) * ld + q * 4);
     }
+    // 3x3/2 max pool with -inf padding: all nine taps are loaded unconditionally at clamped coordinates (nine loads
+    // in flight instead of nine branch-and-wait rounds); taps outside the map do not enter the max
     const int Hb = P.H * 2, Wb = P.W * 2;
     const float ninf = -__builtin_inff();
-    f32x4 m = {ninf, ninf, ninf, ninf};
+    f32x4 tap[9];
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-        const int ih = oh * 2 - 1 + kh;
-        if ((unsigned)ih >= (unsigned)Hb) continue;
+    for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
-            const int iw = ow * 2 - 1 + kw;
-            if ((unsigned)iw >= (unsigned)Wb) continue;
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(x + ((b * Hb + ih) * Wb + iw) * ld + q * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], v[j]);
+            const int ih = min(max(oh * 2 - 1 + kh, 0), Hb - 1), iw = min(max(ow * 2 - 1 + kw, 0), Wb - 1);
+            tap[kh * 3 + kw] = *reinterpret_cast<const f32x4 *>(x + ((b * Hb + ih) * Wb + iw) * ld + q * 4);
         }
-    }
+    f32x4 m = {ninf, ninf, ninf, ninf};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const bool in = (unsigned)(oh * 2 - 1 + kh) < (unsigned)Hb && (unsigned)(ow * 2 - 1 + kw) < (unsigned)Wb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[j] = in ? fmaxf(m[j], tap[kh * 3 + kw][j]) : m[j];
+        }
     return m;
+}
+
+template <int KS>
+__device__ __forceinline__ void sp_load_pair(const SpNode &P, int nb, int lane, float (&f0)[KS], float (&f1)[KS]) {
+    const float *wp0 = P.wpk + (int64_t)min(nb, P.nb - 1) * KS * 64 + lane;
+    const float *wp1 = P.wpk + (int64_t)min(nb + 1, P.nb - 1) * KS * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        f0[ks] = wp0[ks * 64];
+        f1[ks] = wp1[ks * 64];
+    }
+}
+
+__device__ __forceinline__ void sp_finish(const SpNode &P, f32x4 acc, int n, bool valid, float *yp) {
+    if (valid && n < P.Cout) {
+        const f32x4 sh = *reinterpret_cast<const f32x4 *>(P.shift + n);
+        if (P.scale) {
+            const f32x4 sc = *reinterpret_cast<const f32x4 *>(P.scale + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = acc[e] * sc[e] + sh[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = acc[e] + sh[e];
+        }
+        if (P.act == MYDET_ACT_SWISH) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = acc[e] * mydet_sigmoid_fast(acc[e]);
+        }
+        *reinterpret_cast<f32x4 *>(yp + n) = acc;
+    }
+}
+
+struct SpItem {
+    int pi, b, oy0, ox0, nb_begin, nb_end;
+};
+
+// work item = (tile, slice of the output-channel blocks)
+__device__ __forceinline__ SpItem sp_decode(const SpArgs &a, int item) {
+    int pi = 0;
+    for (int i = 1; i < a.n; ++i)
+        if (item >= a.p[i].tile_begin) pi = i;                 // uniform
+    const SpNode &P = a.p[pi];
+    const int t0 = item - P.tile_begin;
+    const int t = t0 / P.nsplit, ns = t0 - t * P.nsplit;
+    SpItem it;
+    it.pi = pi;
+    it.nb_begin = ns * P.nb_per;
+    it.nb_end = min(P.nb, it.nb_begin + P.nb_per);
+    it.b = t / P.tiles_per_img;
+    const int r = t - it.b * P.tiles_per_img;
+    const int ty = r / P.tiles_x;
+    it.oy0 = ty * TS;
+    it.ox0 = (r - ty * P.tiles_x) * TS;
+    return it;
 }
 
 template <int KS>
@@ -80,7 +141,11 @@ __global__ __launch_bounds__(256, 4) void sepconv_kernel(const SpArgs a) {
     for (int i = 1; i < a.n; ++i)
         if (bid >= a.p[i].tile_begin) pi = i;                 // uniform
     const SpNode &P = a.p[pi];
-    const int t = bid - P.tile_begin;
+    // work item = (tile, slice of the output-channel blocks): small maps are cut along the channels as well, so a
+    // 5x5 level does not leave 240 CUs idle while 16 workgroups walk all of Cout
+    const int t0 = bid - P.tile_begin;
+    const int t = t0 / P.nsplit, ns = t0 - t * P.nsplit;
+    const int nb_begin = ns * P.nb_per, nb_end = min(P.nb, nb_begin + P.nb_per);
     const int b = t / P.tiles_per_img, r = t - b * P.tiles_per_img;
     const int ty = r / P.tiles_x, tx = r - ty * P.tiles_x;
     const int oy0 = ty * TS, ox0 = tx * TS;
@@ -97,15 +162,26 @@ __global__ __launch_bounds__(256, 4) void sepconv_kernel(const SpArgs a) {
         sum += 0.0001f;
         w0 = w0 / sum; w1 = w1 / sum; w2 = w2 / sum;
     }
-    for (int it = tid; it < HS * HS * Q; it += 256) {
-        const int hp = it / Q, q = it - hp * Q;
-        const int hy = hp / HS, hx = hp - hy * HS;
-        const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+    // three halo items per thread in flight (otherwise a thread waits out one HBM latency per item); the single-input
+    // loads are unconditional at clamped coordinates (a branch per load would serialise them)
+    constexpr int NH = (HS * HS * Q + 255) / 256, HB = 3;
+#pragma unroll
+    for (int j0 = 0; j0 < NH; j0 += HB) {
+        f32x4 hv[HB];
+#pragma unroll
+        for (int u = 0; u < HB; ++u) {
+            const int it = tid + (j0 + u) * 256;
+            const int itc = min(it, HS * HS * Q - 1);
+            const int hp = itc / Q, q = itc - hp * Q;
+            const int hy = hp / HS, hx = hp - hy * HS;
+            const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+            const bool in = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (P.n_in == 1) {
-                v = *reinterpret_cast<const f32x4 *>(P.in[0] + (((int64_t)b * H + iy) * W + ix) * P.ld[0] + q * 4);
-            } else {                                          // python sum(): 0 + w0*x0 + w1*x1 (+ w2*x2), then swish
+                const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+                const f32x4 ld = *reinterpret_cast<const f32x4 *>(P.in[0] + (((int64_t)b * H + cy) * W + cx) * P.ld[0] + q * 4);
+                v = in ? ld : v;
+            } else if (in) {                                  // python sum(): 0 + w0*x0 + w1*x1 (+ w2*x2), then swish
                 const f32x4 v0 = sp_read(P, 0, b, iy, ix, q), v1 = sp_read(P, 1, b, iy, ix, q);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = w0 * v0[j] + w1 * v1[j];
@@ -117,8 +193,13 @@ __global__ __launch_bounds__(256, 4) void sepconv_kernel(const SpArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = v[j] * mydet_sigmoid_fast(v[j]);
             }
+            hv[u] = v;
         }
-        *reinterpret_cast<f32x4 *>(&lds[hp * C + q * 4]) = v;
+#pragma unroll
+        for (int u = 0; u < HB; ++u) {
+            const int it = tid + (j0 + u) * 256;
+            if (it < HS * HS * Q) *reinterpret_cast<f32x4 *>(&lds[it * 4]) = hv[u];      // it * 4 == hp * C + q * 4
+        }
     }
     __syncthreads();
 
@@ -191,25 +272,30 @@ __global__ __launch_bounds__(256, 4) void sepconv_kernel(const SpArgs a) {
             *reinterpret_cast<f32x4 *>(yp + n) = acc;
         }
     };
-    // two output-channel blocks per iteration: two independent accumulator chains keep the matrix pipe issuing
-    int nb = 0;
-    for (; nb + 1 < P.nb; nb += 2) {
-        const float *wp0 = P.wpk + (int64_t)nb * KS * 64 + lane, *wp1 = wp0 + KS * 64;
+    // one 16-channel block at a time; the NEXT block's weight fragments are in flight under the current block's MFMAs
+    // (same register budget as loading a pair and then computing it, without the exposed L2 latency per pair).  Two
+    // accumulator chains over the even / odd k-steps keep the matrix pipe issuing (40-cycle dependent latency).
+    auto load_block = [&](int nb, float (&f)[KS]) {
+        const float *wp = P.wpk + (int64_t)min(nb, P.nb - 1) * KS * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) f[ks] = wp[ks * 64];
+    };
+    float af[KS];
+    load_block(nb_begin, af);
+    for (int nb = nb_begin; nb < nb_end; ++nb) {
+        float an[KS];
+        load_block(nb + 1, an);
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wp0[ks * 64], bf[ks], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wp1[ks * 64], bf[ks], acc1, 0, 0, 0);
+        for (int ks = 0; ks < KS; ks += 2) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks], bf[ks], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks + 1], bf[ks + 1], acc1, 0, 0, 0);
         }
-        finish(acc0, nb * 16 + nsub);
-        finish(acc1, nb * 16 + 16 + nsub);
-    }
-    if (nb < P.nb) {
-        const float *wp0 = P.wpk + (int64_t)nb * KS * 64 + lane;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wp0[ks * 64], bf[ks], acc0, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) acc0[e] = acc0[e] + acc1[e];
         finish(acc0, nb * 16 + nsub);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) af[ks] = an[ks];
     }
 }
 
@@ -250,6 +336,22 @@ extern "C" int mydet_sepconv_nodes_f32(int n, const mydet_sepconv_node *nodes, i
         tiles += (int64_t)p.tiles_per_img * B;
         if (tiles > 0x7fffffff) return MYDET_E_UNSUPP;
     }
+    // launches that do not fill the chip cut their nodes along the output channels too (pairs of 16-channel blocks)
+    const int64_t base_tiles = tiles;
+    tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        SpNode &p = a.p[i];
+        const int pairs = (p.nb + 1) / 2;
+        int split = 1;
+        if (base_tiles < 2 * mydet_cu_count()) split = (int)((3 * mydet_cu_count() + base_tiles - 1) / base_tiles);
+        if (const char *e = getenv("MYDET_SEPCONV_SPLIT")) split = atoi(e) > split ? atoi(e) : split;     // tuning knob
+        if (split > pairs) split = pairs;
+        p.nb_per = 2 * ((pairs + split - 1) / split);
+        p.nsplit = (p.nb + p.nb_per - 1) / p.nb_per;
+        p.tile_begin = (int)tiles;
+        tiles += (int64_t)p.tiles_per_img * B * p.nsplit;
+    }
+    a.total = (int)tiles;
     hipLaunchKernelGGL((sepconv_kernel<22>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
     return mydet_launch_status();
 }
