@@ -223,6 +223,36 @@ def dwconv(x, w_kkc, scale, shift, k, stride, pad, act, squeeze=False):
     return (out, partial) if squeeze else out
 
 
+MBCONV_FUSED_SHAPES = {(3, 2, 16), (3, 1, 24), (5, 2, 24), (5, 1, 40), (3, 2, 40)}     # (k, stride, Cin) instantiated
+# MYDET_FUSED_MBCONV=0 keeps expand conv and depthwise conv as two launches (A/B measurements)
+FUSED_MBCONV = os.environ.get('MYDET_FUSED_MBCONV', '1') != '0'
+
+
+def mbconv_expand_dw(x, w_expand, scale0, shift0, w_dw, scale1, shift1, k, stride, pad):
+    """swish(BN1(depthwise_k(swish(BN0(expand1x1(x)))))) and the per-tile channel sums of the result (SE squeeze) in
+    one launch; w_expand OHWI [Cexp,1,1,Cin], w_dw [k,k,Cexp], pad=(top,left,bottom,right) of the expanded map.
+    Returns (y [B,Cexp,Ho,Wo], partial [B,S+1,Cexp])."""
+    require_gpu(x, 'mbconv_expand_dw')
+    x, ldx = to_nhwc(x)
+    B, Cin, H, W = x.shape
+    Cexp = w_expand.shape[0]
+    Ho = conv_out_size(H, k, stride, pad[0], pad[2])
+    Wo = conv_out_size(W, k, stride, pad[1], pad[3])
+    out, ldy = empty_nhwc(B, Cexp, Ho, Wo, x.device)
+    S = _lib.lib().mydet_mbconv_tiles(Ho, Wo, stride)
+    partial = torch.empty((B, S + 1, Cexp), dtype=torch.float32, device=x.device)
+    t0 = TIMER.start() if TIMER else None
+    code = _lib.lib().mydet_mbconv_expand_dw_f32(_ptr(x), ldx, _ptr(w_expand), _ptr(scale0), _ptr(shift0), _ptr(w_dw),
+                                                 _ptr(scale1), _ptr(shift1), _ptr(out), ldy, B, H, W, Cin, Cexp, k, stride,
+                                                 pad[0], pad[1], Ho, Wo, _ptr(partial), S, _stream())
+    if t0:      # algorithmic bytes of the two reference layers it replaces: expand (in + out) and depthwise (in + out)
+        nb = 4.0 * B * (H * W * (Cin + Cexp) + Cexp * (H * W + Ho * Wo))
+        TIMER.stop(f'mbconv_expand_dw {Cin}->{Cexp} k{k}s{stride} {H}x{W}' if TIMER_DETAIL else 'mbconv_expand_dw', t0,
+                   2.0 * B * H * W * Cin * Cexp, nb)
+    _lib.check(code, 'mydet_mbconv_expand_dw_f32')
+    return out, partial
+
+
 def channel_sums(x):
     """Per-slice channel sums [B,S,C] of x [B,C,H,W] (standalone squeeze)."""
     require_gpu(x, 'channel_sums')

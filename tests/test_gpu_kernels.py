@@ -494,3 +494,40 @@ def test_sepconv_nodes_vs_fp64(dev):
             t = ops.dwconv(x, dn['w_dw'], None, None, 3, 1, (1, 1, 1, 1), ops.ACT_NONE)
             old = ops.conv2d(t, nd['w_pw'].reshape(nd['cout'], 1, 1, C).to(dev), dn['scale'], dn['shift'], 1, 1, (0, 0, 0, 0), nd['act'])
             assert (y - old).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize('k,s,cin,hw', [(3, 2, 16, (40, 48)), (3, 1, 24, (24, 32)), (5, 2, 24, (22, 26)), (5, 1, 40, (17, 23)),
+                                        (3, 2, 40, (16, 16)), (3, 1, 24, (8, 16))])
+def test_mbconv_expand_dw_vs_fp64(dev, k, s, cin, hw):
+    """Fused expand 1x1 + BN + swish -> depthwise k x k (static-SAME pads of the expanded map) + BN + swish + SE squeeze sums
+    against float64, and against the two launches it replaces (expand conv, depthwise with fused squeeze)."""
+    from mydetection_amd import ops
+    from mydetection_amd.external.efficientnet.model import static_same_pad
+    g = torch.Generator().manual_seed(100 * k + 10 * s + cin)
+    B, (H, W), cexp = 3, hw, cin * 6
+    x = torch.randn(B, cin, H, W, generator=g)
+    we = torch.randn(cexp, cin, generator=g) / cin ** 0.5
+    wd = torch.randn(k, k, cexp, generator=g) / k
+    sc0, sh0 = torch.rand(cexp, generator=g) + 0.5, torch.randn(cexp, generator=g) * 0.3
+    sc1, sh1 = torch.rand(cexp, generator=g) + 0.5, torch.randn(cexp, generator=g) * 0.3
+    pad = static_same_pad(k, s, 240)                                  # (top, left, bottom, right)
+    e = F.conv2d(x.double(), we.double().view(cexp, cin, 1, 1)) * sc0.double().view(1, -1, 1, 1) + sh0.double().view(1, -1, 1, 1)
+    e = e * torch.sigmoid(e)
+    e = F.pad(e, (pad[1], pad[3], pad[0], pad[2]))
+    y = F.conv2d(e, wd.double().permute(2, 0, 1).reshape(cexp, 1, k, k), None, s, 0, 1, cexp)
+    y = y * sc1.double().view(1, -1, 1, 1) + sh1.double().view(1, -1, 1, 1)
+    ref = y * torch.sigmoid(y)
+    args = [t.to(dev) for t in (we.view(cexp, 1, 1, cin).contiguous(), sc0, sh0, wd, sc1, sh1)]
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last)
+    out, partial = ops.mbconv_expand_dw(xd, *args, k, s, pad)
+    assert out.shape == ref.shape
+    tol = 2e-5 * max(1.0, ref.abs().max().item())
+    assert (out.cpu().double() - ref).abs().max().item() <= tol
+    sums = partial[:, :-1].sum(dim=1).cpu().double()                 # per-tile sums -> per-image channel sums
+    np.testing.assert_allclose(sums.numpy(), ref.sum(dim=(2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+    out2, partial2 = ops.mbconv_expand_dw(xd, *args, k, s, pad)
+    assert torch.equal(out, out2) and torch.equal(partial[:, :-1], partial2[:, :-1])
+    # the two launches it replaces
+    ex = ops.conv2d(xd, args[0], args[1], args[2], 1, 1, (0, 0, 0, 0), ops.ACT_SWISH)
+    old, _ = ops.dwconv(ex, args[3], args[4], args[5], k, s, pad, ops.ACT_SWISH, squeeze=True)
+    assert (out - old).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
