@@ -231,13 +231,14 @@ int mydet_postprocess_records_f32(const float *bbox, const int64_t *class_idx, c
 /* Fused front half of an MBConv block (external/efficientnet/model.py:71-79): expand 1x1 + BN0 + swish -> depthwise
  * k x k stride s ("static SAME" pad of the EXPANDED map, utils.py:122-145) + BN1 + swish, plus the SE squeeze sums.
  * Replaces mydet_conv2d_igemm_f32 (expand) + mydet_dwconv_f32 for the shallow blocks; the 6x-wide expanded tensor
- * never reaches HBM.  x logical [B,Cin,H,W] (pixel stride ldx); w_expand [Cexp][Cin]; w_dw [K][K][Cexp];
- * scale/shift = folded BatchNorms; y logical [B,Cexp,Ho,Wo].  se_partial (optional): [B][S+1][Cexp] per-tile channel
+ * never reaches HBM.  x logical [B,Cin,H,W] (pixel stride ldx); w_expand [Cexp][Cin] and w_dw [K][K][Cexp] with the
+ * per-channel BatchNorm scale already multiplied in; shift0 / shift1 = the folded BatchNorm shifts (they initialise
+ * the accumulators); y logical [B,Cexp,Ho,Wo].  se_partial (optional): [B][S+1][Cexp] per-tile channel
  * sums of y with S == mydet_mbconv_tiles(Ho, Wo, stride) (slice S is scratch for mydet_se_gate_f32).
  * Instantiated for (K, stride, Cin) in {(3,2,16), (3,1,24), (5,2,24), (5,1,40), (3,2,40)}: MYDET_E_UNSUPP otherwise. */
 int mydet_mbconv_tiles(int Ho, int Wo, int stride);
-int mydet_mbconv_expand_dw_f32(const float *x, int64_t ldx, const float *w_expand, const float *scale0,
-                               const float *shift0, const float *w_dw, const float *scale1, const float *shift1,
+int mydet_mbconv_expand_dw_f32(const float *x, int64_t ldx, const float *w_expand, const float *shift0,
+                               const float *w_dw, const float *shift1,
                                float *y, int64_t ldy, int B, int H, int W, int Cin, int Cexp, int K, int stride,
                                int pad_t, int pad_l, int Ho, int Wo, float *se_partial, int S, void *stream);
 

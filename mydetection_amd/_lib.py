@@ -37,7 +37,7 @@ SIGNATURES = {
                               c_ptr, c_ptr, c_ptr],
     'mydet_postprocess_records_f32': [c_ptr, c_ptr, c_ptr, c_int, c_i64, c_f32, c_f64, c_ptr, c_ptr, c_ptr],
     'mydet_mbconv_tiles': [c_int, c_int, c_int],
-    'mydet_mbconv_expand_dw_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64] + [c_int] * 11 + [c_ptr, c_int, c_ptr],
+    'mydet_mbconv_expand_dw_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64] + [c_int] * 11 + [c_ptr, c_int, c_ptr],
     'mydet_sepconv_nodes_f32': [c_int, c_ptr, c_int, c_int, c_ptr],
     'mydet_bboxes_iou_f32': [c_ptr, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr],
     'mydet_preprocess_u8_f32': [c_ptr, c_int, c_int, c_int, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr],

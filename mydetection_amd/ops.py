@@ -223,14 +223,24 @@ def dwconv(x, w_kkc, scale, shift, k, stride, pad, act, squeeze=False):
     return (out, partial) if squeeze else out
 
 
-MBCONV_FUSED_SHAPES = {(3, 2, 16), (3, 1, 24), (5, 2, 24), (5, 1, 40), (3, 2, 40)}     # (k, stride, Cin) instantiated
+# (k, stride, Cin) the blocks use the fused launch for: the instantiated shapes where it beats expand + depthwise
+# (tools/bench_mbconv.py, batch 16: 235 vs 386, 168 vs 243, 177 vs 192 us; (5,1,40) and (3,2,40) exist but lose: 145 vs 127, 95 vs 73)
+MBCONV_FUSED_SHAPES = {(3, 2, 16), (3, 1, 24), (5, 2, 24)}
 # MYDET_FUSED_MBCONV=0 keeps expand conv and depthwise conv as two launches (A/B measurements)
 FUSED_MBCONV = os.environ.get('MYDET_FUSED_MBCONV', '1') != '0'
 
 
-def mbconv_expand_dw(x, w_expand, scale0, shift0, w_dw, scale1, shift1, k, stride, pad):
+def fold_scale(w, scale):
+    """Conv weight with the per-output-channel BatchNorm scale multiplied in (w OHWI [Cout,...] or depthwise [k,k,C])."""
+    if w.dim() == 3:
+        return (w * scale.view(1, 1, -1)).contiguous()
+    return (w * scale.view(-1, *([1] * (w.dim() - 1)))).contiguous()
+
+
+def mbconv_expand_dw(x, w_expand, shift0, w_dw, shift1, k, stride, pad):
     """swish(BN1(depthwise_k(swish(BN0(expand1x1(x)))))) and the per-tile channel sums of the result (SE squeeze) in
-    one launch; w_expand OHWI [Cexp,1,1,Cin], w_dw [k,k,Cexp], pad=(top,left,bottom,right) of the expanded map.
+    one launch; w_expand OHWI [Cexp,1,1,Cin] and w_dw [k,k,Cexp] carry the BatchNorm scales (`fold_scale`), shift0 /
+    shift1 are the folded shifts; pad=(top,left,bottom,right) of the expanded map.
     Returns (y [B,Cexp,Ho,Wo], partial [B,S+1,Cexp])."""
     require_gpu(x, 'mbconv_expand_dw')
     x, ldx = to_nhwc(x)
@@ -242,8 +252,8 @@ def mbconv_expand_dw(x, w_expand, scale0, shift0, w_dw, scale1, shift1, k, strid
     S = _lib.lib().mydet_mbconv_tiles(Ho, Wo, stride)
     partial = torch.empty((B, S + 1, Cexp), dtype=torch.float32, device=x.device)
     t0 = TIMER.start() if TIMER else None
-    code = _lib.lib().mydet_mbconv_expand_dw_f32(_ptr(x), ldx, _ptr(w_expand), _ptr(scale0), _ptr(shift0), _ptr(w_dw),
-                                                 _ptr(scale1), _ptr(shift1), _ptr(out), ldy, B, H, W, Cin, Cexp, k, stride,
+    code = _lib.lib().mydet_mbconv_expand_dw_f32(_ptr(x), ldx, _ptr(w_expand), _ptr(shift0), _ptr(w_dw),
+                                                 _ptr(shift1), _ptr(out), ldy, B, H, W, Cin, Cexp, k, stride,
                                                  pad[0], pad[1], Ho, Wo, _ptr(partial), S, _stream())
     if t0:      # algorithmic bytes of the two reference layers it replaces: expand (in + out) and depthwise (in + out)
         nb = 4.0 * B * (H * W * (Cin + Cexp) + Cexp * (H * W + Ho * Wo))

@@ -519,13 +519,14 @@ def test_mbconv_expand_dw_vs_fp64(dev, k, s, cin, hw):
     ref = y * torch.sigmoid(y)
     args = [t.to(dev) for t in (we.view(cexp, 1, 1, cin).contiguous(), sc0, sh0, wd, sc1, sh1)]
     xd = x.to(dev).contiguous(memory_format=torch.channels_last)
-    out, partial = ops.mbconv_expand_dw(xd, *args, k, s, pad)
+    fused_args = (ops.fold_scale(args[0], args[1]), args[2], ops.fold_scale(args[3], args[4]), args[5])
+    out, partial = ops.mbconv_expand_dw(xd, *fused_args, k, s, pad)
     assert out.shape == ref.shape
     tol = 2e-5 * max(1.0, ref.abs().max().item())
     assert (out.cpu().double() - ref).abs().max().item() <= tol
     sums = partial[:, :-1].sum(dim=1).cpu().double()                 # per-tile sums -> per-image channel sums
     np.testing.assert_allclose(sums.numpy(), ref.sum(dim=(2, 3)).numpy(), rtol=1e-4, atol=1e-3)
-    out2, partial2 = ops.mbconv_expand_dw(xd, *args, k, s, pad)
+    out2, partial2 = ops.mbconv_expand_dw(xd, *fused_args, k, s, pad)
     assert torch.equal(out, out2) and torch.equal(partial[:, :-1], partial2[:, :-1])
     # the two launches it replaces
     ex = ops.conv2d(xd, args[0], args[1], args[2], 1, 1, (0, 0, 0, 0), ops.ACT_SWISH)
