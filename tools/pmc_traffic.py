@@ -1,9 +1,14 @@
 """Fabric traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE cannot share a pass).
 
-    python tools/pmc_traffic.py <fetch_dir> <write_dir> > profiles/rNN_pmc_traffic_b32_640.json
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d <fetch_dir> -- python3 bench.py ...
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d <write_dir> -- python3 bench.py ...
+    python tools/pmc_traffic.py <fetch_dir> <write_dir> > profiles/rNN_pmc_traffic_<config>_b<B>_<size>.json
 
-Counters are in KB; FETCH_SIZE is doubled for this code's 16-byte-per-lane loads as MI355X_MICROARCH.md (HBM /
-rocprofv3 section) prescribes for gfx950, WRITE_SIZE is exact.  Kernels are grouped into the families bench.py names.
+Counters are in KB.  MI355X_MICROARCH.md (HBM / rocprofv3): on gfx950 FETCH_SIZE reports half the bytes of a wide
+coalesced streaming read (16 B per lane), so it is doubled for the kernel families whose global loads are 16 B per lane;
+families that load dwords (the Winograd kernel's activation patches, raw_buffer_load_b32) are outside the calibrated
+case and are reported with both factors.  WRITE_SIZE is exact for 16-byte-per-lane stores.
+Kernels are grouped into the families bench.py names.
 """
 import csv
 import glob
@@ -11,34 +16,45 @@ import json
 import sys
 from collections import defaultdict
 
-FAMILIES = [('conv_wino_kernel', 'conv_wino'), ('conv_igemm_kernel', 'conv_igemm'), ('conv_fixup', 'conv_igemm_fixup'),
-            ('conv_stem', 'conv_stem'), ('upsample_concat', 'upsample_concat'), ('decode_kernel', 'decode'),
-            ('postprocess', 'postprocess'), ('wino_weights', None)]
+# (substring of the kernel name, family, FETCH_SIZE correction or None = uncalibrated: report x1 and x2)
+FAMILIES = [('conv_wino_kernel', 'conv_wino', None), ('conv_igemm_kernel', 'conv_igemm', 2.0), ('conv_fixup', 'conv_igemm_fixup', 2.0),
+            ('conv_stem', 'conv_stem', None), ('upsample_concat', 'upsample_concat', 2.0), ('decode_kernel', 'decode', 2.0),
+            ('postprocess', 'postprocess', None), ('dwconv', 'dwconv', 2.0), ('sepconv', 'sepconv_nodes', 2.0),
+            ('mbconv_expand_dw', 'mbconv_expand_dw', 2.0), ('se_gate', 'se_gate', None), ('se_mean', 'se_gate', None),
+            ('bifpn_fuse', 'bifpn_fuse', 2.0), ('maxpool', 'maxpool', 2.0), ('wino_weights', None, None)]
 
 
 def family(kernel):
-    for sub, fam in FAMILIES:
+    for sub, fam, corr in FAMILIES:
         if sub in kernel:
-            return fam
-    return None
+            return fam, corr
+    return None, None
 
 
 def collect(d, counter):
-    tot, ids = defaultdict(float), defaultdict(set)
+    tot, ids, corr = defaultdict(float), defaultdict(set), {}
     for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):
-            fam = family(r['Kernel_Name'])
+            fam, c = family(r['Kernel_Name'])
             if fam and r['Counter_Name'] == counter:
                 tot[fam] += float(r['Counter_Value'])
                 ids[fam].add(r['Dispatch_Id'])
-    return {k: (tot[k], len(ids[k])) for k in tot}
+                corr[fam] = c
+    return {k: (tot[k], len(ids[k]), corr[k]) for k in tot}
 
 
 fetch, write = collect(sys.argv[1], 'FETCH_SIZE'), collect(sys.argv[2], 'WRITE_SIZE')
 out = {}
 for fam in fetch:
-    f, n = fetch[fam]
-    w, nw = write.get(fam, (0.0, n))
-    out[fam] = {'launches': n, 'FETCH_SIZE_KB_per_launch': f / n, 'WRITE_SIZE_KB_per_launch': w / max(nw, 1),
-                'hbm_read_bytes_per_launch_x2corr': 2.0 * 1024.0 * f / n, 'hbm_write_bytes_per_launch': 1024.0 * w / max(nw, 1)}
+    f, n, corr = fetch[fam]
+    w, nw, _ = write.get(fam, (0.0, n, None))
+    rd, wr = 1024.0 * f / n, 1024.0 * w / max(nw, 1)
+    e = {'launches': n, 'FETCH_SIZE_KB_per_launch': f / n, 'WRITE_SIZE_KB_per_launch': w / max(nw, 1), 'hbm_write_bytes_per_launch': wr}
+    if corr is None:
+        e.update({'fetch_correction': 'uncalibrated (loads are not 16 B per lane): x1 .. x2',
+                  'hbm_read_bytes_per_launch_x1': rd, 'hbm_read_bytes_per_launch_x2': 2.0 * rd,
+                  'hbm_bytes_per_launch': rd + wr, 'hbm_bytes_per_launch_upper': 2.0 * rd + wr})
+    else:
+        e.update({'fetch_correction': corr, 'hbm_read_bytes_per_launch': corr * rd, 'hbm_bytes_per_launch': corr * rd + wr})
+    out[fam] = e
 print(json.dumps(out, indent=1))
