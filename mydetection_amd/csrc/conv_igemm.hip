@@ -388,17 +388,23 @@ int launch(const ConvArgs &a0, int slots, hipStream_t stream) {
     const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
     const bool cin = (a.Cin % BK) == 0;
     const int nk = (a.K + BK - 1) / BK;
-    const int rounds = total / slots, rem = total % slots;
+    const int rounds = total / slots;
+    int rem = total % slots;
+    // a grid that fills less than half of one round (batch-1 / small-map layers: M = Ho*Wo is a few tiles) is cut along K
+    // as a whole, so the chip is busy instead of a handful of CUs walking all of K
+    const bool small = rounds == 0 && total * 2 <= slots && nk >= 16;
     int splits = rem > 0 ? slots / rem : 0;
     if (splits > 16) splits = 16;
     if (splits > nk / 4) splits = nk / 4;
     const size_t need = (size_t)rem * (splits > 0 ? splits : 0) * BM * BN * sizeof(float);
     // only long-K layers: on short ones the two extra launches cost more than the spared round
-    const bool split = !a.gate && nk >= 32 && rounds >= 2 && rem > 0 && rem * 2 <= slots && splits >= 2 && a0.ws &&
-                       need <= a0.ws_bytes;
+    const bool split = !a.gate && rem > 0 && splits >= 2 && a0.ws && need <= a0.ws_bytes &&
+                       (small || (nk >= 32 && rounds >= 2 && rem * 2 <= slots));
     a.tile0 = 0; a.splits = 1;
     a.nblk = split ? total - rem : total;
-    int rc = cin ? launch_act<BM, BN, WM, WN, BK, true>(a, lds, stream) : launch_act<BM, BN, WM, WN, BK, false>(a, lds, stream);
+    int rc = 0;
+    if (a.nblk > 0)
+        rc = cin ? launch_act<BM, BN, WM, WN, BK, true>(a, lds, stream) : launch_act<BM, BN, WM, WN, BK, false>(a, lds, stream);
     if (rc || !split) return rc;
     a.tile0 = total - rem; a.splits = splits; a.nblk = rem * splits;
     if (cin) rc = launch_inst<BM, BN, WM, WN, BK, true, MYDET_ACT_NONE, false, false, true>(a, lds, stream);

@@ -424,7 +424,9 @@ int launch_nw(WinoArgs a, hipStream_t stream) {
     const size_t need = (size_t)2 * resident * 8 * NT * sizeof(f32x4);
     // (measured: pays on the 64-tile shape, whose single workgroup per CU exposes the partial last round; not on the
     // 32-tile shape, MYDET_WINO_SK=1 forces it there)
-    if (forced_sk() != 0 && (NW == 8 || forced_sk() == 1) && a.ws && need <= a.ws_bytes && a.nblk >= 2 * resident) {
+    // ... or a grid that fills less than half of the chip (batch-1 / small-map layers): then ALL items are cut along K
+    const bool big = a.nblk >= 2 * resident, small = a.nblk * 2 <= resident && a.nk >= 8;
+    if (forced_sk() != 0 && (NW == 8 || forced_sk() == 1) && a.ws && need <= a.ws_bytes && (big || small)) {
         a.nwg = resident;
         hipLaunchKernelGGL((conv_wino_kernel<ACT, RES, NW, true>), dim3(resident), dim3(NT), LDS, stream, a);
         int rc = mydet_launch_status();
