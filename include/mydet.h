@@ -228,6 +228,31 @@ int mydet_postprocess_records_f32(const float *bbox, const int64_t *class_idx, c
                                   int B, int64_t N, float conf_thres, double nms_thres,
                                   int32_t *records, void *scratch, void *stream);
 
+/* Bilinear resize of one 8-bit RGB image [H][W][3] -> [oh][ow][3] (rows src_row_bytes / dst_row_bytes apart, so the
+ * result can land inside a padded batch buffer), bit-exact with PIL.Image.resize(size, BILINEAR), i.e. with the
+ * reference's tvf.resize of a PIL image (utils/image_ops.py:22-35, :55-137; api/detection.py:177-205): Pillow's
+ * two-pass 8-bit fixed-point filter.  bounds_* int32 [o][2] = (first tap, tap count), k* int32 [o][ks] = 22-bit
+ * integer weights, both DEVICE arrays built by Pillow's rule (mydetection_amd/utils/image_ops.py:resample_tables);
+ * NULL tables skip that pass (the size must then be unchanged). */
+int mydet_resize_bilinear_u8(const unsigned char *src, int H, int W, int64_t src_row_bytes, unsigned char *dst, int oh,
+                             int ow, int64_t dst_row_bytes, const int32_t *bounds_x, const int32_t *kx, int ksx,
+                             const int32_t *bounds_y, const int32_t *ky, int ksy, void *stream);
+
+/* Batched forms over per-image groups of K detection slots (e.g. the records of mydet_postprocess_records_f32):
+ * bbox of image b at bbox + b*bbox_stride (floats), `count[b*count_stride]` slots valid.
+ *   to_original: utils/structures.py:175-189 with one pad_info row (ori w, ori h, tl x, tl y, imw, imh) per image,
+ *                pad_info DEVICE float [B][6] -- the per-image call of api/detection.py:173-174 for a whole batch.
+ *   to_json:     the arithmetic of ImageObjects.to_json (utils/structures.py:243-256), which runs in Python floats:
+ *                out[b][k] = { (double)cx - (double)w/2, (double)cy - (double)h/2, (double)w, (double)h, (double)score },
+ *                out_cat[b][k] = cat_table[class] (class itself when cat_table is NULL; -1 outside the table);
+ *                rows >= count are zero; count may be NULL (all K rows valid, e.g. B = 1 for one ImageObjects). */
+int mydet_bboxes_to_original_batched_f32(float *bbox, int64_t bbox_stride, const int32_t *count, int64_t count_stride,
+                                         int B, int K, const float *pad_info, void *stream);
+int mydet_detections_to_json_f64(const float *bbox, int64_t bbox_stride, const float *score, int64_t score_stride,
+                                 const int64_t *cls, int64_t cls_stride, const int32_t *count, int64_t count_stride,
+                                 int B, int K, const int64_t *cat_table, int n_cat, double *out, int64_t *out_cat,
+                                 void *stream);
+
 /* Fused front half of an MBConv block (external/efficientnet/model.py:71-79): expand 1x1 + BN0 + swish -> depthwise
  * k x k stride s ("static SAME" pad of the EXPANDED map, utils.py:122-145) + BN1 + swish, plus the SE squeeze sums.
  * Replaces mydet_conv2d_igemm_f32 (expand) + mydet_dwconv_f32 for the shallow blocks; the 6x-wide expanded tensor

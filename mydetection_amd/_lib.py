@@ -40,6 +40,9 @@ SIGNATURES = {
     'mydet_mbconv_expand_dw_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64] + [c_int] * 11 + [c_ptr, c_int, c_ptr],
     'mydet_sepconv_nodes_f32': [c_int, c_ptr, c_int, c_int, c_ptr],
     'mydet_bboxes_iou_f32': [c_ptr, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr],
+    'mydet_bboxes_to_original_batched_f32': [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr],
+    'mydet_detections_to_json_f64': [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr],
+    'mydet_resize_bilinear_u8': [c_ptr, c_int, c_int, c_i64, c_ptr, c_int, c_int, c_i64, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr],
     'mydet_preprocess_u8_f32': [c_ptr, c_int, c_int, c_int, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr],
     'mydet_bboxes_to_original_f32': [c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_ptr],
 }

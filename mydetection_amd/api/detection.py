@@ -56,23 +56,51 @@ class Detector():
         self.nms_thres = cfg['test.nms_thres']
 
     def evaluation_predict(self, eval_info: dict, **kwargs):
+        '''
+        COCO-style detections of a whole evaluation set (reference: api/detection.py:58-76, a per-image loop).
+        Images are decoded on the host and then handled `batch_size` (default 16) at a time: device resize + pad +
+        normalise, ONE forward and ONE batched post-process per group of equal input size, boxes mapped back and
+        converted to json rows on the device.  The list has the reference's order (image by image).
+        '''
         img_dir = eval_info['image_dir']
+        infos = list(eval_info['image_info']['images'])
+        kwargs = dict(kwargs)
+        batch_size = int(kwargs.pop('batch_size', 16))
+        cat_map = kwargs.pop('catIdx2id', None)
         detection_json = []
-        for imgInfo in eval_info['image_info']['images']:
-            impath = os.path.join(img_dir, imgInfo['file_name'])
-            detections = self.detect_one(img_path=impath, **kwargs)
-            detection_json += detections.to_json(img_id=imgInfo['id'], eval_type=eval_info['eval_type'],
-                                                 catIdx2id=kwargs.get('catIdx2id', None))
+        for i in range(0, len(infos), batch_size):
+            chunk = infos[i:i + batch_size]
+            imgs = [imgUtils.imread_pil(os.path.join(img_dir, info['file_name'])) for info in chunk]
+            detection_json += self._json_batch(imgs, [info['id'] for info in chunk], eval_info['eval_type'], cat_map, **kwargs)
         return detection_json
 
     def predict_imgDir(self, img_dir, **kwargs):
+        """reference: api/detection.py:93-110 (per-image loop); batched like evaluation_predict."""
+        kwargs = dict(kwargs)
+        batch_size = int(kwargs.pop('batch_size', 16))
+        names = os.listdir(img_dir)
         detection_json = []
-        for imname in os.listdir(img_dir):
-            detections = self.detect_one(img_path=os.path.join(img_dir, imname), **kwargs)
-            assert imname[-4] == '.'
-            img_id = int(imname[:-4]) if imname[:-4].isdigit() else imname[:-4]
-            detection_json += detections.to_json(img_id=img_id, eval_type='x1y1wh')
+        for i in range(0, len(names), batch_size):
+            chunk = names[i:i + batch_size]
+            ids = []
+            for imname in chunk:
+                assert imname[-4] == '.'
+                ids.append(int(imname[:-4]) if imname[:-4].isdigit() else imname[:-4])
+            imgs = [imgUtils.imread_pil(os.path.join(img_dir, n)) for n in chunk]
+            detection_json += self._json_batch(imgs, ids, 'x1y1wh', None, **kwargs)
         return detection_json
+
+    def _json_batch(self, pil_imgs, img_ids, eval_type, cat_map, **kwargs):
+        from ..utils.structures import batched_to_json
+        out = [None] * len(pil_imgs)
+        for idxs, rec in self._records_by_size(pil_imgs, **kwargs):
+            rows = batched_to_json(rec, [img_ids[j] for j in idxs], eval_type, cat_map)
+            counts = rec['count'].cpu().tolist()
+            o = 0
+            for j, k in zip(idxs, counts):
+                out[j] = rows[o:o + k]
+                o += k
+        return [d for per_img in out for d in per_img]
 
     def detect_one(self, **kwargs):
         '''
@@ -92,81 +120,78 @@ class Detector():
             pil_img, preprocessing (str), input_size (int), conf_thres (float), nms_thres (float)
         '''
         assert isinstance(pil_img, PIL.Image.Image), 'input must be a PIL.Image'
-        pre_proc = kwargs.get('preprocessing', self.preprocess)
-        input_size = kwargs.get('input_size', self.input_size)
-        conf_thres = kwargs.get('conf_thres', self.conf_thres)
-        nms_thres = kwargs.get('nms_thres', self.nms_thres)
+        return self.predict_batch([pil_img], **kwargs)[0]
 
-        # host: PIL resize only; pad + to_tensor + normalise run in one HIP kernel on the uint8 image
-        pil_img, pad_info, out_hw = self._preprocess_pil(pil_img, pre_proc, input_size, pad_on_device=True)
-        u8 = torch.from_numpy(np.array(pil_img.convert('RGB'), dtype=np.uint8)).cuda()
-        input_ = ops.preprocess_u8(u8, out_hw, self.model.input_format)
-        assert input_.dim() == 4
-        with torch.no_grad():
-            dts = self.model(input_)
-        assert isinstance(dts, list)
-        dts: ImageObjects = dts[0]
-        dts = dts.post_process(conf_thres, nms_thres)
-        if pad_info is not None:
-            dts.bboxes_to_original_(pad_info)
-        return dts
-
-    def _preprocess_pil(self, pil_img, pre_proc_name, input_size=None, pad_on_device=False):
-        """reference: api/detection.py:177-205.  With pad_on_device the right/bottom zero padding of the
-        '*_divisible' modes is left to the device kernel and the padded (H, W) is returned as third value."""
-        assert isinstance(pil_img, PIL.Image.Image), 'input must be a PIL.Image'
+    def _geometry(self, ori_h, ori_w, pre_proc_name, input_size=None):
+        """What api/detection.py:177-205 does to an image of (ori_h, ori_w), as numbers: the resize target (h, w) or
+        None, the (top, left) offset of the resized image inside the network input, the input size (H, W), and
+        pad_info for bboxes_to_original_ (None when the boxes are already in image coordinates)."""
         assert isinstance(self.divisibe, int)
-        ori_h, ori_w = pil_img.height, pil_img.width
         div = self.divisibe
 
-        def padded(img):
-            return (int(np.ceil(img.height / div) * div), int(np.ceil(img.width / div) * div))
+        def up(v):
+            return int(np.ceil(v / div) * div)
         if pre_proc_name == 'pad_divisible':
-            out_hw = padded(pil_img)
-            if not pad_on_device:
-                pil_img = imgUtils.pad_to_divisible(pil_img, div)
-            pad_info = None
-        elif pre_proc_name == 'resize_pad_divisible':
+            return None, (0, 0), (up(ori_h), up(ori_w)), None
+        if pre_proc_name == 'resize_pad_divisible':
             assert input_size is not None
-            pil_img = imgUtils.resize_pil(pil_img, input_size, shorter=False)
-            new_h, new_w = pil_img.height, pil_img.width
-            out_hw = padded(pil_img)
-            if not pad_on_device:
-                pil_img = imgUtils.pad_to_divisible(pil_img, div)
-            pad_info = (ori_w, ori_h, 0, 0, new_w, new_h)
-        elif pre_proc_name == 'resize_pad_square':
+            factor = input_size / max(ori_h, ori_w)                  # utils/image_ops.py:30-33 (resize_pil, shorter=False)
+            th, tw = round(ori_h * factor), round(ori_w * factor)
+            return (th, tw), (0, 0), (up(th), up(tw)), (ori_w, ori_h, 0, 0, tw, th)
+        if pre_proc_name == 'resize_pad_square':
             assert input_size is not None
-            pil_img, _, pad_info = imgUtils.rect_to_square(pil_img, None, input_size, aug=False)
-            out_hw = (pil_img.height, pil_img.width)
-        else:
-            raise Exception('Unknown preprocessing name')
-        return (pil_img, pad_info, out_hw) if pad_on_device else (pil_img, pad_info)
+            scale = input_size / max(ori_w, ori_h)                   # utils/image_ops.py:55-137 (rect_to_square, aug=False)
+            rw, rh = int(ori_w * scale), int(ori_h * scale)
+            left, top = (input_size - rw) // 2, (input_size - rh) // 2
+            return (rh, rw), (top, left), (input_size, input_size), (ori_w, ori_h, left, top, rw, rh)
+        raise Exception('Unknown preprocessing name')
 
-    def predict_batch(self, pil_imgs, **kwargs):
-        """Batched form of detect_one for images that preprocess to the same size (e.g. 'resize_pad_square'):
-        one forward + one batched post-process for the whole list (the reference loops image by image,
-        api/detection.py:67-74).  Returns a list of ImageObjects in the original image coordinates."""
-        from ..parallel import records_to_objects
-        from ..utils.structures import batched_post_process
+    def preprocess_batch(self, pil_imgs, **kwargs):
+        """Network inputs of a list of PIL images, grouped by input size: yields (indices, x [n,3,H,W] float32 on the
+        device, pad_infos, image sizes).  Per image the host only decodes the file; resize (PIL-exact: the reference's
+        tvf.resize of a PIL image), zero padding, /255 and normalisation (api/detection.py:158-163) are HIP kernels on
+        the uint8 pixels."""
         pre_proc = kwargs.get('preprocessing', self.preprocess)
         input_size = kwargs.get('input_size', self.input_size)
+        groups = {}
+        for j, img in enumerate(pil_imgs):
+            assert isinstance(img, PIL.Image.Image), 'input must be a PIL.Image'
+            geo = self._geometry(img.height, img.width, pre_proc, input_size)
+            groups.setdefault(geo[2], []).append((j, img, geo))
+        dev = next(self.model.parameters()).device
+        for (Hp, Wp), items in groups.items():
+            buf = torch.zeros((len(items), Hp, Wp, 3), dtype=torch.uint8, device=dev)     # zero padding lives here
+            for n, (j, img, (target, (top, left), _, _)) in enumerate(items):
+                u8 = torch.from_numpy(np.array(img.convert('RGB'), dtype=np.uint8)).to(dev, non_blocking=True)
+                ops.resize_bilinear_u8(u8, target or (img.height, img.width), buf[n], top, left)
+            x = ops.preprocess_u8(buf, (Hp, Wp), self.model.input_format)
+            yield ([j for j, _, _ in items], x, [g[3] for _, _, g in items],
+                   [(img.height, img.width) if g[3] is not None else (Hp, Wp) for _, img, g in items])
+
+    def _records_by_size(self, pil_imgs, **kwargs):
+        """Detection records of a list of PIL images, grouped by network input size: yields (indices, records) with the
+        boxes already in the coordinates of the original images."""
+        from ..utils.structures import batched_post_process
         conf_thres = kwargs.get('conf_thres', self.conf_thres)
         nms_thres = kwargs.get('nms_thres', self.nms_thres)
-        u8s, pads, hw = [], [], None
-        for img in pil_imgs:
-            p_img, pad_info, out_hw = self._preprocess_pil(img, pre_proc, input_size, pad_on_device=True)
-            arr = np.array(p_img.convert('RGB'), dtype=np.uint8)
-            assert hw is None or (hw == out_hw and arr.shape == u8s[0].shape), 'images must preprocess to one size'
-            hw = out_hw
-            u8s.append(arr)
-            pads.append(pad_info)
-        u8 = torch.from_numpy(np.stack(u8s)).cuda()
-        x = ops.preprocess_u8(u8, hw, self.model.input_format)
-        with torch.no_grad():
-            bb, ci, sc = self.model.forward_candidates(x)
-            rec = batched_post_process(bb, ci, sc, conf_thres, nms_thres)
-        objs = records_to_objects(rec, img_hw=tuple(hw), bb_format=self.model.bb_format)
-        for o, pad_info in zip(objs, pads):
-            if pad_info is not None:
-                o.bboxes_to_original_(pad_info)
-        return objs
+        for idxs, x, pads, hws in self.preprocess_batch(pil_imgs, **kwargs):
+            with torch.no_grad():
+                bb, ci, sc = self.model.forward_candidates(x)
+                rec = batched_post_process(bb, ci, sc, conf_thres, nms_thres)
+            if any(p is not None for p in pads):
+                ops.records_to_original_(rec, pads)
+            rec['img_hw'] = hws
+            yield idxs, rec
+
+    def predict_batch(self, pil_imgs, **kwargs):
+        """Batched form of detect_one (the reference loops image by image, api/detection.py:67-74): images that share a
+        network input size go through ONE forward + ONE batched post-process.  Returns a list of ImageObjects in the
+        original image coordinates, in input order."""
+        from ..parallel import records_to_objects
+        out = [None] * len(pil_imgs)
+        for idxs, rec in self._records_by_size(pil_imgs, **kwargs):
+            objs = records_to_objects(rec, bb_format=self.model.bb_format)
+            for j, o, hw in zip(idxs, objs, rec['img_hw']):
+                o.img_hw = hw
+                out[j] = o
+        return out

@@ -38,10 +38,11 @@ def _yolo_anchors(wh, per_level=3):
             'model.yolo.anchor.negative_threshold': 0.7}
 
 
-def _efficientnet_bifpn(divisibility, dropout, c6c7=None):
-    """EfficientNet-B1 with five levels (C6/C7 appended, 88 channels) under four BiFPN5 layers."""
+def _efficientnet_bifpn(divisibility, dropout, c6c7=None, levels=5):
+    """EfficientNet-B1 with five levels (C6/C7 appended, 88 channels) under four BiFPN5 layers, or its three backbone
+    levels under four BiFPN3 layers."""
     cfg = _general('RGB_1_norm', divisibility)
-    cfg.update(_pyramid('efficientnet-b1', 5, 'bifpn'))
+    cfg.update(_pyramid('efficientnet-b1', levels, 'bifpn'))
     cfg.update({'model.backbone.C6C7_out_channels': 88, 'model.efficientnet.enable_dropout': dropout,
                 'model.bifpn.out_ch': 88, 'model.bifpn.repeat_num': 4, 'model.bifpn.fusion_method': 'linear'})
     if c6c7:
@@ -90,6 +91,14 @@ def _build():
     c.update({'model.pred_layer': 'FCOS', 'model.fcos.anchors': _FCOS_RANGES})
     c.update(_test(640, 0.5))
     out['d1_fcs'] = c
+
+    # registry composition on three pyramid levels (get_bifpn -> BiFPN3, models/fpns.py:302-303; the reference ships it
+    # for its rotated-box model d1_rapid): d1_fcs2 with model.backbone.num_levels = 3
+    c = _efficientnet_bifpn(32, False, None, levels=3)
+    c.update(_effrpn('effrpn', 1, True, **{'model.effrpn.cls_last': 'conv'}))
+    c.update({'model.pred_layer': 'FCOS2', 'model.fcos2.ignored_threshold': 0.7, 'model.fcos.anchors': _FCOS_RANGES[:3] + [100000000]})
+    c.update(_test(640, 0.5))
+    out['d1_fcs2_p3'] = c
 
     c = _efficientnet_bifpn(32, True)
     c.update(_effrpn('effrpn', 3, True))

@@ -68,11 +68,15 @@ def get_bifpn(cfg: dict):
     repeat_num = cfg['model.bifpn.repeat_num']
     fusion_method = cfg['model.bifpn.fusion_method']
     assert repeat_num >= 1
-    if len(in_channels) != 5:
+    if len(in_channels) == 3:
+        fpn_func = BiFPN3
+    elif len(in_channels) == 5:
+        fpn_func = BiFPN5
+    else:
         raise NotImplementedError()
-    fpn = [BiFPN5(out_ch, fusion_method=fusion_method, in_chs=in_channels)]
+    fpn = [fpn_func(out_ch, fusion_method=fusion_method, in_chs=in_channels)]
     for _ in range(repeat_num - 1):
-        fpn.append(BiFPN5(out_ch, fusion_method=fusion_method))
+        fpn.append(fpn_func(out_ch, fusion_method=fusion_method))
     return nn.Sequential(*fpn)
 
 
@@ -82,6 +86,42 @@ def conv1x1_bn(in_ch, out_ch):
 
 def _identity(x):
     return x
+
+
+class BiFPN3(nn.Module):
+    '''
+    One bidirectional pyramid layer over P3..P5 for three-level backbones (reference: models/fpns.py:315-354):
+        P4m = fuse(p4in_m(P4in), up(p5in_4m(P5in)));  P3out = fuse(p3in_out(P3in), up(P4m));
+        P4out = fuse(p4in_out(P4in), P4m, pool(P3out));  P5out = fuse(p5in_out(P5in), pool(P4out)).
+    Every node is one launch of the fused node kernel; the 2x upsampling / max pooling are read through.
+    '''
+    def __init__(self, fpn_ch, fusion_method='linear', in_chs=None):
+        super().__init__()
+        if in_chs:
+            assert len(in_chs) == 3
+            self.p3in_out = conv1x1_bn(in_chs[0], fpn_ch)
+            self.p4in_m = conv1x1_bn(in_chs[1], fpn_ch)
+            self.p4in_out = conv1x1_bn(in_chs[1], fpn_ch)
+            self.p5in_4m = conv1x1_bn(in_chs[2], fpn_ch)
+            self.p5in_out = conv1x1_bn(in_chs[2], fpn_ch)
+        else:
+            self.p3in_out = self.p4in_m = self.p4in_out = self.p5in_4m = self.p5in_out = _identity
+        if fusion_method != 'linear':
+            raise NotImplementedError()
+        self.fuse_4m = LinearFusion(num=2, channels=fpn_ch)
+        self.fuse_3out = LinearFusion(num=2, channels=fpn_ch)
+        self.fuse_4out = LinearFusion(num=3, channels=fpn_ch)
+        self.fuse_5out = LinearFusion(num=2, channels=fpn_ch)
+
+    def forward(self, features):
+        P3in, P4in, P5in = features
+        assert P3in.shape[2] == P4in.shape[2] * 2 == P5in.shape[2] * 4
+        up, down = ops.FUSE_UP2X, ops.FUSE_POOL
+        P4m = self.fuse_4m(self.p4in_m(P4in), (self.p5in_4m(P5in), up))
+        P3out = self.fuse_3out(self.p3in_out(P3in), (P4m, up))
+        P4out = self.fuse_4out(self.p4in_out(P4in), P4m, (P3out, down))
+        P5out = self.fuse_5out(self.p5in_out(P5in), (P4out, down))
+        return [P3out, P4out, P5out]
 
 
 class BiFPN5(nn.Module):

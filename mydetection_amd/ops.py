@@ -536,6 +536,77 @@ def bboxes_to_original_(bbox, pad_info):
     return bbox
 
 
+def resize_bilinear_u8(src_u8, out_hw, dst=None, top=0, left=0):
+    """PIL-exact bilinear resize of one uint8 image [H,W,3] on the device (include/mydet.h: mydet_resize_bilinear_u8).
+    dst: optional uint8 [Hd,Wd,3] to write into at (top, left) -- e.g. one image of a zero-padded batch buffer."""
+    from .utils.image_ops import resample_tables
+    require_gpu(src_u8, 'resize_bilinear_u8')
+    assert src_u8.dtype == torch.uint8 and src_u8.dim() == 3 and src_u8.shape[2] == 3 and src_u8.is_contiguous()
+    H, W, _ = src_u8.shape
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    if dst is None:
+        dst = torch.empty((oh, ow, 3), dtype=torch.uint8, device=src_u8.device)
+    assert dst.dtype == torch.uint8 and dst.dim() == 3 and dst.shape[2] == 3 and dst.stride(2) == 1 and dst.stride(1) == 3
+    assert top + oh <= dst.shape[0] and left + ow <= dst.shape[1]
+    tabs = []
+    for n_in, n_out in ((W, ow), (H, oh)):
+        if n_in == n_out:
+            tabs.append((None, None, 0))
+        else:
+            key = (n_in, n_out, str(src_u8.device))
+            hit = _RESAMPLE_CACHE.get(key)
+            if hit is None:
+                b, k = resample_tables(n_in, n_out)
+                hit = (torch.from_numpy(b).to(src_u8.device), torch.from_numpy(k).to(src_u8.device), k.shape[1])
+                if len(_RESAMPLE_CACHE) > 256:
+                    _RESAMPLE_CACHE.clear()
+                _RESAMPLE_CACHE[key] = hit
+            tabs.append(hit)
+    (bx, kx, ksx), (by, ky, ksy) = tabs
+    dptr = ctypes.c_void_p(dst.data_ptr() + top * dst.stride(0) + left * 3)
+    code = _lib.lib().mydet_resize_bilinear_u8(_ptr(src_u8), H, W, W * 3, dptr, oh, ow, dst.stride(0), _ptr(bx), _ptr(kx), ksx,
+                                               _ptr(by), _ptr(ky), ksy, _stream())
+    _lib.check(code, 'mydet_resize_bilinear_u8')
+    return dst
+
+
+_RESAMPLE_CACHE = {}
+
+
+def records_to_original_(rec, pad_infos):
+    """bboxes_to_original_ for a whole batch of records in place: pad_infos = one (ori w, ori h, tl x, tl y, imw, imh)
+    per image (a row of ones-and-zeros (1, 1, 0, 0, 1, 1) leaves an image's boxes unchanged bit for bit)."""
+    bbox = rec['bbox']
+    require_gpu(bbox, 'records_to_original_')
+    B, K = bbox.shape[0], bbox.shape[1]
+    pad = torch.tensor([[float(v) for v in p] if p is not None else [1.0, 1.0, 0.0, 0.0, 1.0, 1.0] for p in pad_infos],
+                       dtype=torch.float32).to(bbox.device, non_blocking=True)
+    assert pad.shape == (B, 6) and bbox.stride(1) == 4 and bbox.stride(2) == 1
+    code = _lib.lib().mydet_bboxes_to_original_batched_f32(_ptr(bbox), bbox.stride(0), _ptr(rec['count']), rec['count'].stride(0),
+                                                           B, K, _ptr(pad), _stream())
+    _lib.check(code, 'mydet_bboxes_to_original_batched_f32')
+    return rec
+
+
+def detections_to_json(bbox, score, cls, count=None, cat_table=None):
+    """The numbers of ImageObjects.to_json for B x K detection slots in one launch: returns (rows float64 [B,K,5] =
+    x1, y1, w, h, score in the reference's double arithmetic, category int64 [B,K]).  bbox [B,K,4] (any image
+    stride), score [B,K], cls [B,K] int64, count [B] int32 or None, cat_table int64 [n] or None."""
+    require_gpu(bbox, 'detections_to_json')
+    B, K = bbox.shape[0], bbox.shape[1]
+    out = torch.empty((B, K, 5), dtype=torch.float64, device=bbox.device)
+    cat = torch.empty((B, K), dtype=torch.int64, device=bbox.device)
+    if K == 0:
+        return out, cat
+    assert bbox.stride(1) == 4 and bbox.stride(2) == 1 and score.stride(1) == 1 and cls.stride(1) == 1
+    code = _lib.lib().mydet_detections_to_json_f64(_ptr(bbox), bbox.stride(0), _ptr(score), score.stride(0), _ptr(cls),
+                                                   cls.stride(0), _ptr(count), count.stride(0) if count is not None else 0,
+                                                   B, K, _ptr(cat_table), cat_table.numel() if cat_table is not None else 0,
+                                                   _ptr(out), _ptr(cat), _stream())
+    _lib.check(code, 'mydet_detections_to_json_f64')
+    return out, cat
+
+
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 

@@ -1,8 +1,8 @@
-"""Host-side image preparation used by api.detection (reference: utils/image_ops.py:11-188).
+"""Image preparation used by api.detection (reference: utils/image_ops.py:11-188).
 
-Out of scope for kernels this round (SURVEY.md section 8f ranks a fused device-side version
-next); implemented with PIL + numpy only because torchvision is not a dependency here.
-Resampling follows torchvision's default for PIL inputs (bilinear).
+The PIL forms below are the host path (and the geometry: target sizes, paddings, pad_info); `resample_tables` builds
+the coefficient tables with which the device kernel (ops.resize_bilinear_u8) reproduces PIL's bilinear resize -- what
+torchvision's tvf.resize does to a PIL image -- bit for bit.  PIL + numpy only: torchvision is not a dependency here.
 """
 import numpy as np
 import PIL.Image
@@ -81,3 +81,31 @@ def format_tensor_img(t_img, code):
         std = torch.tensor([0.229, 0.224, 0.225], dtype=t_img.dtype).view(3, 1, 1)
         return (t_img - mean) / std
     raise NotImplementedError()
+
+
+_PRECISION_BITS = 32 - 8 - 2
+
+
+def resample_tables(in_size, out_size):
+    """Pillow's bilinear coefficient tables for one axis, 8-bit fixed-point form (src/libImaging/Resample.c:
+    precompute_coeffs + normalize_coeffs_8bpc): bounds int32 [out,2] = (first tap, tap count), kk int32 [out,ksize].
+    All arithmetic in float64 in Pillow's order, so the integers are Pillow's integers."""
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(np.ceil(support)) * 2 + 1
+    ss = 1.0 / filterscale
+    center = (np.arange(out_size, dtype=np.float64) + 0.5) * scale
+    xmin = np.maximum((center - support + 0.5).astype(np.int64), 0)          # C (int) cast: truncation
+    xmax = np.minimum((center + support + 0.5).astype(np.int64), in_size) - xmin
+    x = np.arange(ksize, dtype=np.float64)[None, :]
+    a = np.abs((x + xmin[:, None] - center[:, None] + 0.5) * ss)
+    w = np.where(a < 1.0, 1.0 - a, 0.0)
+    w[x >= xmax[:, None]] = 0.0
+    ww = np.zeros(out_size, np.float64)
+    for j in range(ksize):                                                   # Pillow sums the taps in order
+        ww = ww + w[:, j]
+    w = np.where(ww[:, None] != 0.0, w / np.where(ww == 0.0, 1.0, ww)[:, None], w)
+    kk = (0.5 + w * (1 << _PRECISION_BITS)).astype(np.int64).astype(np.int32)     # weights are >= 0 for this filter
+    bounds = np.stack([xmin, xmax], axis=1).astype(np.int32)
+    return bounds, kk

@@ -164,22 +164,74 @@ class ImageObjects():
 
     def to_json(self, img_id, eval_type='x1y1wh', catIdx2id=None) -> list:
         '''
-        COCO-like json (reference: utils/structures.py:221-259).  One device->host copy of the
-        survivors, then the same per-row arithmetic in Python floats.
+        COCO-like json (reference: utils/structures.py:221-259).  The numbers (x1 = cx - w/2 ... in the reference's
+        Python-float, i.e. double, arithmetic; category ids) come from one HIP launch and one device->host copy.
         '''
         assert self.bboxes.dim() == 2
         assert self.bboxes.shape[0] == self.cats.shape[0] == self.scores.shape[0]
         if eval_type != 'x1y1wh':
             raise NotImplementedError()
         assert self._bb_format == 'cxcywh'
-        from .constants import COCO_CATEGORY_IDS
-        list_json = []
-        for bb, c, s in zip(self.bboxes.cpu().tolist(), self.cats.cpu().tolist(), self.scores.cpu().tolist()):
-            cx, cy, w, h = bb
-            bbox = [cx - w / 2, cy - h / 2, w, h]
-            cat_id = catIdx2id[int(c)] if catIdx2id is not None else COCO_CATEGORY_IDS[int(c)]
-            list_json.append({'image_id': img_id, 'category_id': cat_id, 'bbox': bbox, 'score': float(s)})
-        return list_json
+        if len(self) == 0:
+            return []
+        bb, cats, sc = self._device_fields()
+        table, host_map = _category_table(catIdx2id, bb.device)
+        rows, cat = ops.detections_to_json(bb.contiguous()[None], sc.contiguous()[None], cats.contiguous()[None], None, table)
+        return _json_rows(rows[0].cpu().tolist(), cat[0].cpu().tolist(), img_id, host_map)
+
+
+def _category_table(catIdx2id, device):
+    """(device int64 table or None, host mapping or None) for to_json's category lookup: the COCO ids by default
+    (utils/constants.py:2, COCO_CATEGORY_LIST[c]['id']); an integer list / dict becomes a device table, anything else
+    (e.g. string ids) is mapped on the host from the class indices."""
+    from .constants import COCO_CATEGORY_IDS
+    src = COCO_CATEGORY_IDS if catIdx2id is None else catIdx2id
+    try:
+        if isinstance(src, dict):
+            n = max(src) + 1
+            vals = [int(src.get(i, -1)) for i in range(n)]
+            if any(not isinstance(v, int) for v in src.values()):
+                raise TypeError
+        else:
+            vals = [v for v in src]
+            if any(not isinstance(v, int) for v in vals):
+                raise TypeError
+        key = (tuple(vals), str(device))
+        hit = _category_table.cache.get(key)
+        if hit is None:
+            hit = torch.tensor(vals, dtype=torch.int64, device=device)
+            _category_table.cache[key] = hit
+        return hit, None
+    except (TypeError, ValueError):
+        return None, src
+
+
+_category_table.cache = {}
+
+
+def _json_rows(rows, cats, img_id, host_map):
+    out = []
+    for r, c in zip(rows, cats):
+        out.append({'image_id': img_id, 'category_id': host_map[int(c)] if host_map is not None else c,
+                    'bbox': r[:4], 'score': r[4]})
+    return out
+
+
+def batched_to_json(rec, img_ids, eval_type='x1y1wh', catIdx2id=None) -> list:
+    '''
+    `to_json` of every image of a batch of detection records (the concatenation the reference builds image by image,
+    api/detection.py:67-74): one launch, one device->host copy.  img_ids: one id per image.
+    '''
+    if eval_type != 'x1y1wh':
+        raise NotImplementedError()
+    table, host_map = _category_table(catIdx2id, rec['bbox'].device)
+    rows, cat = ops.detections_to_json(rec['bbox'], rec['score'], rec['class_idx'], rec['count'], table)
+    counts = rec['count'].cpu().tolist()
+    rows, cat = rows.cpu(), cat.cpu()
+    out = []
+    for b, (k, img_id) in enumerate(zip(counts, img_ids)):
+        out += _json_rows(rows[b, :k].tolist(), cat[b, :k].tolist(), img_id, host_map)
+    return out
 
 
 def batched_post_process(bboxes, cats, scores, conf_thres, nms_thres):

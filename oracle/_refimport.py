@@ -49,6 +49,39 @@ def install():
                                    float(iou_threshold))
         return torch.from_numpy(keep)
     tv.ops.nms = nms
+    # torchvision.transforms.functional for PIL inputs is a thin layer over PIL itself (resize -> Image.resize with
+    # BILINEAR, pad -> a new image with the old one pasted in, to_tensor -> uint8 HWC / 255 as float32 CHW, normalize ->
+    # sub_(mean).div_(std)); torchvision is not installed, so those four are supplied with exactly that behaviour and the reference's own
+    # utils/image_ops.py (resize_pil, pad_to_divisible, rect_to_square, format_tensor_img) runs on top of them
+    import PIL.Image
+
+    def tv_resize(img, size, interpolation=None):
+        if isinstance(size, int):
+            w, h = img.size
+            if w <= h:
+                size = (int(size * h / w), size)
+            else:
+                size = (size, int(size * w / h))
+        return img.resize((int(size[1]), int(size[0])), PIL.Image.BILINEAR)
+
+    def tv_pad(img, padding, fill=0, padding_mode='constant'):
+        left, top, right, bottom = padding
+        fill = 0 if fill is None else fill              # torchvision's _parse_fill
+        out = PIL.Image.new(img.mode, (img.width + left + right, img.height + top + bottom), fill)
+        out.paste(img, (left, top))
+        return out
+
+    def tv_to_tensor(img):
+        arr = np.array(img.convert('RGB'), dtype=np.uint8)
+        return torch.from_numpy(arr).permute(2, 0, 1).contiguous().float().div(255)
+    def tv_normalize(tensor, mean, std, inplace=False):
+        mean = torch.as_tensor(mean, dtype=tensor.dtype).view(-1, 1, 1)
+        std = torch.as_tensor(std, dtype=tensor.dtype).view(-1, 1, 1)
+        return tensor.clone().sub_(mean).div_(std)
+    tv.transforms.functional.normalize = tv_normalize
+    tv.transforms.functional.resize = tv_resize
+    tv.transforms.functional.pad = tv_pad
+    tv.transforms.functional.to_tensor = tv_to_tensor
     _stub('cv2')
     pc = _stub('pycocotools')
     pc.mask = _stub('pycocotools.mask')
@@ -84,13 +117,24 @@ def no_pretrained():
             patched[0].load_pretrained_weights = patched[1]
 
 
-def build_reference_model(config_name):
-    """Reference OneStageBBox for configs/<name>.json filled with the synthetic weights."""
+# configurations composed through the reference's registry that it has no JSON file for: (base file, overrides)
+DERIVED = {'d1_fcs2_p3': ('d1_fcs2', {'model.backbone.num_levels': 3, 'model.fcos.anchors': [0, 64, 128, 100000000]})}
+
+
+def reference_config(config_name):
     import json
+    base, over = DERIVED.get(config_name, (config_name, {}))
+    cfg = json.load(open(f'{REFERENCE_ROOT}/configs/{base}.json'))
+    cfg.update(over)
+    return cfg
+
+
+def build_reference_model(config_name):
+    """Reference OneStageBBox for configs/<name>.json (or a DERIVED composition) filled with the synthetic weights."""
     import io
     install()
     from mydetection_amd import synth
-    cfg = json.load(open(f'{REFERENCE_ROOT}/configs/{config_name}.json'))
+    cfg = reference_config(config_name)
     with no_pretrained(), contextlib.redirect_stdout(io.StringIO()):
         from models.general import OneStageBBox
         model = OneStageBBox(cfg)

@@ -99,6 +99,8 @@ def backbone(x, sd, name='efficientnet-b1', c6c7='maxpool', p='backbone'):
         x = y
     feats.append(x)
     c3, c4, c5 = feats[2], feats[3], feats[4]
+    if c6c7 is None:                                  # three-level backbone (models/backbones.py:174-177)
+        return [c3, c4, c5]
     pad6 = 0 if c6c7 == 'maxpool' else 1
     c6 = F.conv2d(c5, sd[p + '.c5_to_c6.0.weight'], sd[p + '.c5_to_c6.0.bias'], 1, pad6)
     c6 = F.max_pool2d(_bn(c6, sd, p + '.c5_to_c6.1'), 3, 2, 1)
@@ -141,9 +143,22 @@ def bifpn5(feats, sd, p):
     return [p3o, p4o, p5o, p6o, p7o]
 
 
+def bifpn3(feats, sd, p):
+    """BiFPN3.forward, models/fpns.py:336-354."""
+    p3, p4, p5 = feats
+    up = lambda t: F.interpolate(t, scale_factor=(2, 2), mode='nearest')    # noqa: E731
+    down = lambda t: F.max_pool2d(t, kernel_size=3, stride=2, padding=1)      # noqa: E731
+    p4m = fusion([_proj(p4, sd, p + '.p4in_m'), up(_proj(p5, sd, p + '.p5in_4m'))], sd, p + '.fuse_4m')
+    p3o = fusion([_proj(p3, sd, p + '.p3in_out'), up(p4m)], sd, p + '.fuse_3out')
+    p4o = fusion([_proj(p4, sd, p + '.p4in_out'), p4m, down(p3o)], sd, p + '.fuse_4out')
+    p5o = fusion([_proj(p5, sd, p + '.p5in_out'), down(p4o)], sd, p + '.fuse_5out')
+    return [p3o, p4o, p5o]
+
+
 def bifpn(feats, sd, repeat=4, p='fpn'):
+    layer = bifpn3 if len(feats) == 3 else bifpn5
     for i in range(repeat):
-        feats = bifpn5(feats, sd, f'{p}.{i}')
+        feats = layer(feats, sd, f'{p}.{i}')
     return feats
 
 
@@ -207,7 +222,7 @@ D1_YV3_ANCHORS = [[12.6, 13.2], [23.5, 38.1], [57.3, 32.3], [42.9, 75.5], [106.6
 
 
 def forward(x, sd, config):
-    """config in {'efficientdet-d1', 'd1_fcs2_atss', 'd1_fcs2', 'd1_fcs'} -> (bbox [B,N,4], class_idx [B,N],
+    """config in {'efficientdet-d1', 'd1_fcs2_atss', 'd1_fcs2', 'd1_fcs2_p3', 'd1_fcs', 'd1_yv3'} -> (bbox [B,N,4], class_idx [B,N],
     score [B,N]).  d1_fcs2 is d1_fcs2_atss at inference (models/detlayers/fcos2.py:24-69 == :222-251)."""
     img = tuple(x.shape[2:4])
     if config == 'd1_fcs':          # EfDetHead_wCenter + FCOSLayer (models/detlayers/fcos.py:21-68)
@@ -224,8 +239,9 @@ def forward(x, sd, config):
             anch = torch.tensor(D1_YV3_ANCHORS[3 * lvl:3 * lvl + 3], dtype=torch.float32)
             outs.append(decoders.yolo_decode_raw(raw, STRIDES[lvl], anch))
         return tuple(torch.cat([o[j] for o in outs], dim=1) for j in range(3))
-    atss = config in ('d1_fcs2_atss', 'd1_fcs2')
-    feats = bifpn(backbone(x, sd, c6c7='conv' if atss else 'maxpool'), sd)
+    atss = config in ('d1_fcs2_atss', 'd1_fcs2', 'd1_fcs2_p3')
+    c6c7 = None if config == 'd1_fcs2_p3' else ('conv' if atss else 'maxpool')
+    feats = bifpn(backbone(x, sd, c6c7=c6c7), sd)
     raws = raw_dicts(head(feats, sd), 1 if atss else 9, 80, atss)
     outs = []
     for lvl, raw in enumerate(raws):

@@ -293,6 +293,52 @@ def gen_postprocess():
     print('postprocess', {n: out[f'{n}_bboxes'].shape[0] for n in cases})
 
 
+def gen_preprocess_and_json():
+    """Rows 8f ranks 1-2: the reference's own preprocessing chain (api/detection.py:158-163,177-205 ->
+    utils/image_ops.py resize_pil / pad_to_divisible / rect_to_square / format_tensor_img, on PIL through the
+    torchvision-functional stand-ins of _refimport) and ImageObjects.to_json (utils/structures.py:221-259)."""
+    import types
+    import PIL.Image
+    _refimport.install()
+    from api.detection import Detector
+    import utils.image_ops as rio
+    from utils.structures import ImageObjects
+    import torchvision.transforms.functional as tvf
+    rng = np.random.Generator(np.random.PCG64(2024))
+    out = {}
+    cases = [('pad_divisible', None, 32, (37, 53), 'RGB_1'), ('resize_pad_divisible', 96, 32, (75, 131), 'RGB_1_norm'),
+             ('resize_pad_divisible', 160, 128, (301, 97), 'RGB_1_norm'), ('resize_pad_square', 128, 32, (200, 150), 'RGB_1'),
+             ('resize_pad_square', 96, 32, (61, 240), 'RGB_1_norm'), ('resize_pad_square', 64, 32, (40, 33), 'RGB_1')]   # last: upscale
+    out['n_cases'] = len(cases)
+    for i, (mode, size, div, hw, fmt) in enumerate(cases):
+        base = rng.integers(0, 256, size=(hw[0] // 4 + 1, hw[1] // 4 + 1, 3), dtype=np.uint8)      # smooth + noise: realistic taps
+        img = np.array(PIL.Image.fromarray(base).resize((hw[1], hw[0]), PIL.Image.BICUBIC))
+        img = np.clip(img.astype(np.int32) + rng.integers(-20, 21, size=img.shape), 0, 255).astype(np.uint8)
+        fake = types.SimpleNamespace(divisibe=div)
+        pil, pad_info = Detector._preprocess_pil(fake, PIL.Image.fromarray(img), mode, size)
+        t = rio.format_tensor_img(tvf.to_tensor(pil), code=fmt)
+        out[f'c{i}_mode'], out[f'c{i}_fmt'] = np.array(mode), np.array(fmt)
+        out[f'c{i}_size'], out[f'c{i}_div'] = np.int64(size or 0), np.int64(div)
+        out[f'c{i}_image'] = img
+        out[f'c{i}_tensor'] = _np(t)
+        out[f'c{i}_pad_info'] = np.array(pad_info if pad_info is not None else [], dtype=np.float64)
+    # to_json: random detections, default COCO ids and an explicit table
+    n = 37
+    bb = (rng.random((n, 4), dtype=np.float32) * np.float32(300) + np.float32(3)).astype(np.float32)
+    cats = rng.integers(0, 80, size=n).astype(np.int64)
+    sc = rng.random(n, dtype=np.float32)
+    d = ImageObjects(torch.from_numpy(bb.copy()), torch.from_numpy(cats.copy()), None, torch.from_numpy(sc.copy()), 'cxcywh', (512, 512))
+    table = [int(v) for v in rng.permutation(200)[:80]]
+    out['json_bboxes'], out['json_cats'], out['json_scores'], out['json_table'] = bb, cats, sc, np.array(table)
+    for tag, kw in (('coco', {}), ('table', {'catIdx2id': table})):
+        js = d.to_json(img_id=5, **kw)
+        out[f'json_{tag}_bbox'] = np.array([r['bbox'] for r in js], dtype=np.float64)
+        out[f'json_{tag}_score'] = np.array([r['score'] for r in js], dtype=np.float64)
+        out[f'json_{tag}_cat'] = np.array([r['category_id'] for r in js], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, 'preprocess_json.npz'), **out)
+    print('preprocess_json', {f'c{i}': out[f'c{i}_tensor'].shape for i in range(len(cases))})
+
+
 def gen_bbox_ops():
     _refimport.install()
     from utils.bbox_ops import bboxes_iou, cxcywh_to_x1y1x2y2
@@ -315,6 +361,8 @@ if __name__ == '__main__':
     which = sys.argv[1:] or ['bbox_ops', 'postprocess', 'detlayers', 'yolov3', 'efficientdet']
     if 'bbox_ops' in which:
         gen_bbox_ops()
+    if 'preprocess' in which:
+        gen_preprocess_and_json()
     if 'postprocess' in which:
         gen_postprocess()
     if 'detlayers' in which:
@@ -329,3 +377,5 @@ if __name__ == '__main__':
         gen_efficientdet('d1_fcs')
     if 'd1_yv3' in which:               # EfDetHead decoded by the YOLO layer (registry composition)
         gen_efficientdet('d1_yv3')
+    if 'bifpn3' in which:               # three-level composition: EfficientNet-B1 C3..C5 + 4 x BiFPN3 + EfDetHead + FCOS2
+        gen_efficientdet('d1_fcs2_p3')

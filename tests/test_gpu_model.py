@@ -136,7 +136,7 @@ def test_detector_api(model, tmp_path):
 
 
 # ------------------- EfficientDet-D1 / D1-FCOS2-ATSS, and the registry plug-ins 'FCOS2' (d1_fcs2), 'effrpn_ct' + 'FCOS' (d1_fcs), EfDetHead + 'YOLO' (d1_yv3)
-@pytest.fixture(scope='module', params=['efficientdet-d1', 'd1_fcs2_atss', 'd1_fcs2', 'd1_fcs', 'd1_yv3'])
+@pytest.fixture(scope='module', params=['efficientdet-d1', 'd1_fcs2_atss', 'd1_fcs2', 'd1_fcs', 'd1_yv3', 'd1_fcs2_p3'])
 def effdet(request):
     assert torch.cuda.is_available()
     from mydetection_amd import synth
@@ -210,7 +210,7 @@ def test_effdet_family_vs_oracle_640(effdet):
     with torch.no_grad():
         ob, oc, os_ = oe.forward(x, sd, name)
         bb, ci, sc = m.forward_candidates(x.cuda())
-    assert bb.shape == ob.shape and bb.shape[1] == {'efficientdet-d1': 76725, 'd1_yv3': 25575}.get(name, 8525)
+    assert bb.shape == ob.shape and bb.shape[1] == {'efficientdet-d1': 76725, 'd1_yv3': 25575, 'd1_fcs2_p3': 8400}.get(name, 8525)
     np.testing.assert_allclose(sc.cpu().numpy(), os_.numpy(), rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(bb.cpu().numpy(), ob.numpy(), rtol=RTOL, atol=ATOL)
     flips = (ci.cpu() != oc)
@@ -412,3 +412,81 @@ def test_hipgraph_replay_equals_eager(model):
         assert int(ref['count'].sum()) > 0
         for k in ('count', 'index', 'class_idx', 'score', 'bbox'):
             assert torch.equal(rec[k], ref[k]), k
+
+
+def test_device_preprocessing_vs_reference_golden(model, golden):
+    """Row 8f rank 1: resize (PIL-exact) + zero pad + /255 + normalise as HIP kernels on the uint8 image, against the
+    tensor the reference's own chain (api/detection.py:158-163,177-205 on utils/image_ops.py) builds: bit for bit."""
+    import PIL.Image
+    from mydetection_amd.api import Detector
+    m, cfg = model
+    g = golden('preprocess_json')
+    det = Detector(model_and_cfg=(m, cfg))
+    for i in range(int(g['n_cases'])):
+        mode, fmt, size, div = str(g[f'c{i}_mode']), str(g[f'c{i}_fmt']), int(g[f'c{i}_size']) or None, int(g[f'c{i}_div'])
+        det.divisibe = div
+        m.input_format = fmt
+        try:
+            (idxs, x, pads, hws), = det.preprocess_batch([PIL.Image.fromarray(g[f'c{i}_image'])], preprocessing=mode, input_size=size)
+        finally:
+            m.input_format = cfg['general.input_format']
+        assert torch.equal(x[0].cpu(), torch.from_numpy(g[f'c{i}_tensor'])), (i, mode)
+        want = g[f'c{i}_pad_info']
+        assert (pads[0] is None and want.size == 0) or list(pads[0]) == list(want)
+
+
+def test_to_json_vs_reference_golden(golden):
+    """Row 8f rank 2: ImageObjects.to_json / batched_to_json numbers come from one HIP launch in the reference's
+    double arithmetic: equal to the reference's json rows exactly (bbox doubles, scores, category ids)."""
+    from mydetection_amd.utils.structures import ImageObjects, batched_to_json
+    from mydetection_amd import parallel
+    g = golden('preprocess_json')
+    bb, cats, sc = torch.from_numpy(g['json_bboxes']), torch.from_numpy(g['json_cats']), torch.from_numpy(g['json_scores'])
+    d = ImageObjects(bb.cuda(), cats.cuda(), None, sc.cuda(), 'cxcywh', (512, 512))
+    for tag, kw in (('coco', {}), ('table', {'catIdx2id': [int(v) for v in g['json_table']]}),
+                    ('table', {'catIdx2id': {i: int(v) for i, v in enumerate(g['json_table'])}})):
+        js = d.to_json(img_id=5, **kw)
+        assert len(js) == len(cats) and set(js[0]) == {'image_id', 'category_id', 'bbox', 'score'} and js[0]['image_id'] == 5
+        assert np.array_equal(np.array([r['bbox'] for r in js]), g[f'json_{tag}_bbox'])
+        assert np.array_equal(np.array([r['score'] for r in js]), g[f'json_{tag}_score'])
+        assert [r['category_id'] for r in js] == list(g[f'json_{tag}_cat'])
+    names = d.to_json(img_id='a', catIdx2id={i: f'c{i}' for i in range(80)})           # non-integer ids: host mapping
+    assert [r['category_id'] for r in names] == [f'c{int(c)}' for c in cats]
+    # batched: two images' records (second one empty)
+    n = len(cats)
+    rec = parallel.make_records({'count': torch.tensor([n, 0], dtype=torch.int32), 'bbox': torch.zeros(2, 512, 4),
+                                 'score': torch.zeros(2, 512), 'class_idx': torch.zeros(2, 512, dtype=torch.int64),
+                                 'index': torch.zeros(2, 512, dtype=torch.int32)})
+    rec['bbox'][0, :n], rec['score'][0, :n], rec['class_idx'][0, :n] = bb, sc, cats
+    rec = parallel.record_views(rec['records'].cuda())
+    js = batched_to_json(rec, [7, 8])
+    assert len(js) == n and all(r['image_id'] == 7 for r in js)
+    assert np.array_equal(np.array([r['bbox'] for r in js]), g['json_coco_bbox'])
+
+
+def test_batched_evaluation_predict_equals_per_image(model, tmp_path):
+    """Row 8f rank 3: evaluation_predict (batched: device preprocessing, one forward per input size, batched post-process,
+    to_original and json on the device) returns exactly the rows of the reference's per-image loop
+    (detect_one + to_json, api/detection.py:67-74), in the same order, for images of different sizes."""
+    import PIL.Image
+    from mydetection_amd import synth
+    from mydetection_amd.api import Detector
+    m, cfg = model
+    det = Detector(model_and_cfg=(m, cfg))
+    sizes = [(240, 320), (200, 200), (240, 320), (180, 300), (200, 200)]
+    infos = []
+    for i, hw in enumerate(sizes):
+        img = (synth.make_images(1, hw, seed=40 + i)[0].permute(1, 2, 0).numpy() * 255).astype(np.uint8)
+        PIL.Image.fromarray(img).save(tmp_path / f'{100 + i}.png')
+        infos.append({'file_name': f'{100 + i}.png', 'id': 100 + i})
+    eval_info = {'image_dir': str(tmp_path), 'image_info': {'images': infos}, 'eval_type': 'x1y1wh'}
+    for kw in (dict(preprocessing='resize_pad_square', input_size=256, conf_thres=0.005),
+               dict(preprocessing='resize_pad_divisible', input_size=224, conf_thres=0.05)):
+        batched = det.evaluation_predict(eval_info, batch_size=4, **kw)
+        loop = []
+        for info in infos:
+            loop += det.detect_one(img_path=str(tmp_path / info['file_name']), **kw).to_json(img_id=info['id'])
+        assert len(batched) == len(loop) > 0
+        assert [r['image_id'] for r in batched] == [r['image_id'] for r in loop]
+        for a, b in zip(batched, loop):
+            assert a == b

@@ -109,8 +109,12 @@ def test_image_objects_host_logic():
     assert d.cats.tolist() == [1, 3, 3]
     d.category_filter_([3])
     assert d.scores.tolist() == [0.5, 0.25]
-    js = d.to_json(img_id='a')
-    assert js[0]['category_id'] == 4 and js[0]['bbox'] == [4.5, 4.5, 1.0, 1.0]
+    if not torch.cuda.is_available():           # the json numbers come from a HIP launch: loud failure without the GPU
+        with pytest.raises(RuntimeError):
+            d.to_json(img_id='a')
+    from mydetection_amd.utils.structures import _category_table, _json_rows
+    assert _category_table({0: 'a'}, 'cpu') == (None, {0: 'a'})
+    assert _json_rows([[4.5, 4.5, 1.0, 1.0, 0.5]], [4], 'a', None) == [{'image_id': 'a', 'category_id': 4, 'bbox': [4.5, 4.5, 1.0, 1.0], 'score': 0.5}]
     with pytest.raises(AssertionError):
         ImageObjects(b, torch.tensor([1, 2, 3], dtype=torch.int32))
     with pytest.raises(NotImplementedError):
@@ -139,3 +143,54 @@ def test_preprocess_shapes():
     assert sq.size == (256, 256) and info == (400, 300, 0, 32, 256, 192)
     t = image_ops.format_tensor_img(image_ops.to_tensor(p), 'RGB_1_norm')
     assert t.shape == (3, 256, 320)
+
+
+def test_pil_resize_restatement_and_tables():
+    """oracle/pil_resize.py (numpy restatement of Pillow's 8-bit bilinear resize) equals PIL itself bit for bit, and the
+    product's vectorised coefficient tables (utils/image_ops.resample_tables, uploaded to the device resize kernel)
+    equal the restatement's."""
+    import numpy as np
+    import PIL.Image
+    from mydetection_amd.utils.image_ops import resample_tables
+    from oracle import pil_resize
+    rng = np.random.default_rng(3)
+    for t in range(12):
+        H, W = int(rng.integers(5, 120)), int(rng.integers(5, 120))
+        oh, ow = int(rng.integers(3, 140)), int(rng.integers(3, 140))
+        if t % 4 == 0:
+            oh = H
+        if t % 5 == 0:
+            ow = W
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        ref = np.array(PIL.Image.fromarray(img).resize((ow, oh), PIL.Image.BILINEAR))
+        assert np.array_equal(pil_resize.resize_bilinear_u8(img, (oh, ow)), ref), ((H, W), (oh, ow))
+    for n_in, n_out in ((640, 480), (480, 640), (37, 301), (1000, 64), (64, 1000), (7, 7), (2, 3)):
+        b0, k0 = pil_resize.coefficients(n_in, n_out)
+        b1, k1 = resample_tables(n_in, n_out)
+        assert np.array_equal(b0, b1) and np.array_equal(k0, k1), (n_in, n_out)
+
+
+def test_detector_geometry_matches_reference_golden(golden):
+    """Detector._geometry (target size, offsets, input size, pad_info) against what the reference's _preprocess_pil
+    produced for the fixture images; the PIL host path of utils/image_ops reproduces the reference tensor too."""
+    import numpy as np
+    import PIL.Image
+    from mydetection_amd.api.detection import Detector
+    from mydetection_amd.utils import image_ops
+    g = golden('preprocess_json')
+    det = Detector.__new__(Detector)
+    for i in range(int(g['n_cases'])):
+        mode, fmt, size, div = str(g[f'c{i}_mode']), str(g[f'c{i}_fmt']), int(g[f'c{i}_size']) or None, int(g[f'c{i}_div'])
+        img, ref = g[f'c{i}_image'], g[f'c{i}_tensor']
+        det.divisibe = div
+        target, (top, left), out_hw, pad_info = det._geometry(img.shape[0], img.shape[1], mode, size)
+        assert tuple(out_hw) == ref.shape[1:]
+        want = g[f'c{i}_pad_info']
+        assert (pad_info is None and want.size == 0) or np.array_equal(np.array(pad_info, dtype=np.float64), want)
+        pil = PIL.Image.fromarray(img)
+        if target is not None:
+            pil = image_ops._resize(pil, target)
+        canvas = np.zeros((out_hw[0], out_hw[1], 3), np.uint8)
+        canvas[top:top + pil.height, left:left + pil.width] = np.array(pil)
+        t = image_ops.format_tensor_img(image_ops.to_tensor(PIL.Image.fromarray(canvas)), fmt)
+        assert np.array_equal(t.numpy(), ref), (i, mode)

@@ -129,7 +129,7 @@ def test_yolov3_post_process_matches_reference(yolov3_oracle_run):
         np.testing.assert_allclose(b, g[f'pp_{tag}_bboxes_0'], rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize('config', ['efficientdet-d1', 'd1_fcs2_atss', 'd1_fcs2', 'd1_fcs', 'd1_yv3'])
+@pytest.mark.parametrize('config', ['efficientdet-d1', 'd1_fcs2_atss', 'd1_fcs2', 'd1_fcs', 'd1_yv3', 'd1_fcs2_p3'])
 def test_efficientdet_family_matches_reference(golden, config):
     """Oracle restatement of EfficientNet-B1 + BiFPN + EfDetHead + decode vs the imported reference."""
     from mydetection_amd.models.general import state_dict_template
@@ -139,9 +139,10 @@ def test_efficientdet_family_matches_reference(golden, config):
     x = synth.make_normalized_images(int(g['batch']), int(g['size']), seed=int(g['image_seed']))
     torch.set_num_threads(8)
     atss = config in ('d1_fcs2_atss', 'd1_fcs2')       # C6/C7 by conv (configs' model.efficientnet.C6C7_downsample)
+    c6c7 = None if config == 'd1_fcs2_p3' else ('conv' if atss else 'maxpool')     # d1_fcs2_p3: three levels, BiFPN3
     with torch.no_grad():
-        c = oe.backbone(x, sd, c6c7='conv' if atss else 'maxpool')
-        p0 = oe.bifpn5(c, sd, 'fpn.0')
+        c = oe.backbone(x, sd, c6c7=c6c7)
+        p0 = oe.bifpn(c, sd, repeat=1)
         p = oe.bifpn(c, sd)
         bb, ci, sc = oe.forward(x, sd, config)
     for key, feats in (('backbone', c), ('bifpn0', p0), ('fpn', p)):
