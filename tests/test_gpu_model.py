@@ -328,7 +328,10 @@ def test_device_preprocess_and_batched_detector(model):
     for img, d in zip(imgs, batch):
         one = det.detect_one(pil_img=img, **kw)
         assert len(one) == len(d) > 0 and d.img_hw == (240, 320)
-        assert torch.equal(one.cats, d.cats) and torch.equal(one.scores, d.scores) and torch.equal(one.bboxes, d.bboxes)
+        # to 1e-5, not bit for bit: a batch of 3 and a batch of 1 cut their small grids along K differently
+        assert torch.equal(one.cats, d.cats)
+        np.testing.assert_allclose(one.scores.cpu().numpy(), d.scores.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(one.bboxes.cpu().numpy(), d.bboxes.cpu().numpy(), rtol=1e-5, atol=1e-4)
 
 
 def test_full_size_properties_batch32_640(model):
@@ -488,5 +491,8 @@ def test_batched_evaluation_predict_equals_per_image(model, tmp_path):
             loop += det.detect_one(img_path=str(tmp_path / info['file_name']), **kw).to_json(img_id=info['id'])
         assert len(batched) == len(loop) > 0
         assert [r['image_id'] for r in batched] == [r['image_id'] for r in loop]
-        for a, b in zip(batched, loop):
-            assert a == b
+        assert [r['category_id'] for r in batched] == [r['category_id'] for r in loop]
+        # numbers to 1e-5, not bit for bit: a batch of 2 and a batch of 1 cut their small grids along K differently
+        np.testing.assert_allclose(np.array([r['bbox'] for r in batched]), np.array([r['bbox'] for r in loop]), rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(np.array([r['score'] for r in batched]), np.array([r['score'] for r in loop]), rtol=1e-5, atol=1e-6)
+        assert all(isinstance(r['bbox'][0], float) and isinstance(r['score'], float) for r in batched)
