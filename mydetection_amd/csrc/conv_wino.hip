@@ -424,14 +424,20 @@ int launch_nw(WinoArgs a, hipStream_t stream) {
     const size_t need = (size_t)2 * resident * 8 * NT * sizeof(f32x4);
     // (measured: pays on the 64-tile shape, whose single workgroup per CU exposes the partial last round; not on the
     // 32-tile shape, MYDET_WINO_SK=1 forces it there)
-    // ... or a grid that fills less than half of the chip (batch-1 / small-map layers): then ALL items are cut along K
+    // ... or a grid that fills less than half of the chip (batch-1 / small-map layers): then ALL items are cut along K.
+    // Every persistent workgroup must own at least one slab iteration of the cut part (the fixup sums the pieces of
+    // ALL workgroups between two item boundaries), so the grid shrinks to the iteration count when that is smaller.
     const bool big = a.nblk >= 2 * resident, small = a.nblk * 2 <= resident && a.nk >= 8;
-    if (forced_sk() != 0 && (NW == 8 || forced_sk() == 1) && a.ws && need <= a.ws_bytes && (big || small)) {
-        a.nwg = resident;
-        hipLaunchKernelGGL((conv_wino_kernel<ACT, RES, NW, true>), dim3(resident), dim3(NT), LDS, stream, a);
+    int nwg = resident;
+    if (small && (int64_t)a.nblk * a.nk < resident) nwg = a.nblk * a.nk;
+    const int64_t tail_total = (int64_t)(a.nblk - (a.nblk / nwg) * nwg) * a.nk;
+    const bool covered = tail_total == 0 || tail_total >= nwg;
+    if (forced_sk() != 0 && (NW == 8 || forced_sk() == 1) && a.ws && need <= a.ws_bytes && (big || small) && covered) {
+        a.nwg = nwg;
+        hipLaunchKernelGGL((conv_wino_kernel<ACT, RES, NW, true>), dim3(nwg), dim3(NT), LDS, stream, a);
         int rc = mydet_launch_status();
-        if (rc) return rc;
-        hipLaunchKernelGGL((conv_wino_fixup_kernel<ACT, RES, NW>), dim3(resident - 1), dim3(NT), 0, stream, a);
+        if (rc || nwg < 2) return rc;
+        hipLaunchKernelGGL((conv_wino_fixup_kernel<ACT, RES, NW>), dim3(nwg - 1), dim3(NT), 0, stream, a);
         return mydet_launch_status();
     }
     a.nwg = 0;

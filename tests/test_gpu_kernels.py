@@ -77,6 +77,9 @@ def test_conv_igemm_vs_fp64(dev, case):
     dict(B=32, Cin=128, Cout=256, H=40, W=40, act=1, residual=True),   # stream-K, 64-tile shape: 3.125 items/workgroup
     dict(B=16, Cin=64, Cout=128, H=80, W=80, act=1),                   # stream-K, 32-tile shape
     dict(B=24, Cin=136, Cout=200, H=37, W=37, act=2, residual=True),   # stream-K with ragged tiles, channels and K=17 slabs
+    dict(B=1, Cin=128, Cout=128, H=8, W=8, act=1, residual=True),      # small grid cut along K: 2 items x 16 slabs on 32 workgroups
+    dict(B=1, Cin=512, Cout=1024, H=16, W=16, act=1, residual=True),   # batch-1 deep layer: 16 items x 64 slabs over the whole chip
+    dict(B=2, Cin=256, Cout=192, H=6, W=7, act=0, bias_only=True),     # small, ragged: 3 items x 32 slabs on 96 workgroups
 ])
 def test_conv_winograd_vs_fp64(dev, case):
     """Fused Winograd F(2x2,3x3) kernel (3x3, stride 1, pad 1) against the same float64 reference and tolerance
