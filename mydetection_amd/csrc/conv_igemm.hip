@@ -415,14 +415,15 @@ int launch(const ConvArgs &a0, int slots, hipStream_t stream) {
 
 // Tile configurations (id -> BM x BN, wave grid, BK).  MYDET_CONV_CFG=<id> forces one (tuning only).
 int launch_cfg(int id, const ConvArgs &a, hipStream_t s) {
+    const int cus = mydet_cu_count();
     switch (id) {
-        // last argument: resident workgroups = 256 CUs x (LDS / register limited workgroups per CU)
-        case 0: return launch<128, 128, 2, 2, 32>(a, 512, s);
-        case 1: return launch<128, 64, 2, 2, 32>(a, 512, s);
-        case 2: return launch<128, 32, 4, 1, 32>(a, 768, s);
-        case 3: return launch<64, 64, 2, 2, 32>(a, 1024, s);
-        case 6: return launch<128, 64, 2, 2, 16>(a, 1280, s);
-        case 8: return launch<128, 128, 2, 4, 32>(a, 512, s);     // 8 waves, wave tile 64x32
+        // last argument: resident workgroups = CUs (256 on MI355X) x (LDS / register limited workgroups per CU)
+        case 0: return launch<128, 128, 2, 2, 32>(a, 2 * cus, s);
+        case 1: return launch<128, 64, 2, 2, 32>(a, 2 * cus, s);
+        case 2: return launch<128, 32, 4, 1, 32>(a, 3 * cus, s);
+        case 3: return launch<64, 64, 2, 2, 32>(a, 4 * cus, s);
+        case 6: return launch<128, 64, 2, 2, 16>(a, 5 * cus, s);
+        case 8: return launch<128, 128, 2, 4, 32>(a, 2 * cus, s);     // 8 waves, wave tile 64x32
         default: return MYDET_E_BADARG;
     }
 }
@@ -447,7 +448,10 @@ extern "C" int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *
         stride <= 0 || Ho <= 0 || Wo <= 0)
         return MYDET_E_BADARG;
     if ((Cin & 3) || (ldx & 3) || ldx < Cin || ldy < Cout || (residual && ldr < Cout)) return MYDET_E_BADARG;
-    if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return MYDET_E_BADARG;
+    if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15) || (residual && ((uintptr_t)residual & 15)) ||
+        (scale && ((uintptr_t)scale & 15)) || (shift && ((uintptr_t)shift & 15)))
+        return MYDET_E_BADARG;                       // the epilogue uses 16-byte buffer operations on all of these
+    if ((ldy & 3) || (residual && (ldr & 3))) return MYDET_E_UNSUPP;
     const int64_t M64 = (int64_t)B * Ho * Wo;
     if (M64 > (int64_t)1 << 30 || (int64_t)KH * KW * Cin > (int64_t)1 << 30) return MYDET_E_BADARG;
     // 32-bit byte offsets inside a block's window (the images its 128 rows touch, +1) and the weights

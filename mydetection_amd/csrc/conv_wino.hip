@@ -420,7 +420,7 @@ int launch_nw(WinoArgs a, hipStream_t stream) {
     a.nk = a.Cin >> 3;
     // stream-K when the grid is at least two resident rounds (below that the plain grid is already one round or
     // its prologue/epilogue overlap is what matters) and the caller gave room for the partial tiles
-    const int resident = 256 * (NW == 8 ? 1 : 2);
+    const int resident = mydet_cu_count() * (NW == 8 ? 1 : 2);
     const size_t need = (size_t)2 * resident * 8 * NT * sizeof(f32x4);
     // (measured: pays on the 64-tile shape, whose single workgroup per CU exposes the partial last round; not on the
     // 32-tile shape, MYDET_WINO_SK=1 forces it there)

@@ -135,6 +135,9 @@ def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None
     gate: optional [B,Cin] per-image channel multipliers (squeeze-excite), 1x1 convs only;
     wino: optional `wino_weights(w_ohwi)`: 3x3 stride-1 pad-1 layers then run the fused Winograd kernel."""
     require_gpu(x, 'conv2d')
+    if x.shape[1] % 4:
+        raise ValueError(f'conv2d: Cin = {x.shape[1]} is not a multiple of 4 (the implicit-GEMM kernel reads channels in '
+                         'float4; the 3-channel image layer goes through conv2d_stem)')
     x, ldx = to_nhwc(x)
     B, Cin, H, W = x.shape
     Cout = w_ohwi.shape[0]
