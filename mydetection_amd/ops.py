@@ -130,7 +130,29 @@ def wino_weights(w_ohwi):
     return u
 
 
-def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None, out_ld=None, gate=None, wino=None):
+# F(4x4,3x3) for the deep 3x3 layers (Cin >= WINO4_MIN_CIN); MYDET_CONV_WINO4=0 keeps them on F(2x2,3x3)
+WINOGRAD4 = os.environ.get('MYDET_CONV_WINO4', '1') != '0'
+WINO4_MIN_CIN = int(os.environ.get('MYDET_WINO4_MIN_CIN', '128'))
+
+
+def wino4_weights(w_ohwi):
+    """Transform-domain copy of a 3x3 OHWI weight for the F(4x4,3x3) kernel (`conv2d(..., wino4=)`), or None when the
+    shape is not covered (Cin % 4, Cout % 4)."""
+    require_gpu(w_ohwi, 'wino4_weights')
+    Cout, kh, kw, Cin = w_ohwi.shape
+    if kh != 3 or kw != 3 or Cout % 4:
+        return None
+    n = _lib.lib().mydet_wino4_weights_floats(Cout, Cin)
+    if n <= 0:
+        return None
+    u = torch.empty(n, dtype=torch.float32, device=w_ohwi.device)
+    w = w_ohwi.contiguous()
+    _lib.check(_lib.lib().mydet_wino4_weights_f32(_ptr(w), Cout, Cin, _ptr(u), _stream()), 'mydet_wino4_weights_f32')
+    return u
+
+
+def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None, out_ld=None, gate=None, wino=None,
+           wino4=None):
     """y = act(conv(x * gate)*scale + shift) + residual.  x logical [B,Cin,H,W]; pad=(top,left,bottom,right);
     gate: optional [B,Cin] per-image channel multipliers (squeeze-excite), 1x1 convs only;
     wino: optional `wino_weights(w_ohwi)`: 3x3 stride-1 pad-1 layers then run the fused Winograd kernel."""
@@ -152,6 +174,17 @@ def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None
     if residual is not None:
         residual, ldr = to_nhwc(residual)
         assert residual.shape == out.shape
+    if (wino4 is not None and WINOGRAD and WINOGRAD4 and gate is None and k == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1)
+            and ldy % 4 == 0 and ldr % 4 == 0):
+        t0 = TIMER.start() if TIMER else None
+        code = _lib.lib().mydet_conv2d_wino4_f32(_ptr(x), ldx, _ptr(wino4), _ptr(scale), _ptr(shift), _ptr(residual), ldr,
+                                                 _ptr(out), ldy, B, H, W, Cin, Cout, act, _stream())
+        if t0:      # priced with the direct form's flops: the algorithmic work of the layer
+            name = f'conv_wino4 {Cin}->{Cout} k3s1 {H}x{W}' if TIMER_DETAIL else 'conv_wino4'
+            TIMER.stop(name, t0, 2.0 * B * Ho * Wo * Cout * 9 * Cin,
+                       4.0 * (B * H * W * Cin + B * Ho * Wo * Cout * (2 if residual is not None else 1) + 9 * Cin * Cout))
+        _lib.check(code, 'mydet_conv2d_wino4_f32')
+        return out
     if (wino is not None and WINOGRAD and gate is None and k == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1)
             and ldy % 4 == 0 and ldr % 4 == 0):
         ws = conv_workspace(x.device)
