@@ -1,0 +1,370 @@
+// 3x3 stride-1 pad-1 convolution by Winograd F(4x4,3x3) on the gfx950 FP32 matrix cores, fully fused (input transform
+// while staging, 36 transform-domain GEMMs on v_mfma_f32_16x16x4_f32, output transform + BN / activation / residual in
+// the epilogue): 4x fewer multiplies than the direct form (F(2x2,3x3) of conv_wino.hip: 2.25x), no transformed tensor
+// in HBM.  Used for the deep layers, where the matrix pipe is the bound.
+//
+//   tile  = 4x4 output pixels (6x6 input patch d, origin (4ty-1, 4tx-1), zero outside the image)
+//   V     = Bt d B      Bt = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   U     = G g Gt      G  = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]  (float64, once)
+//   M_p   = sum_c U_p[n][c] * V_p[c][tile]    for the 36 positions p = 6i+j -- the MFMA part
+//   Y     = At M A      At = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+//   y     = act(Y*scale[n] + shift[n]) + residual
+// float32 throughout; against float64 the error is ~3e-6 rms of O(1) outputs (the direct form: 2e-7; tests/
+// test_winograd_algebra.py), i.e. 30x inside the 1e-4 the detections are held to.
+//
+// A workgroup of 8 waves owns 64 output channels x 32 tiles; wave (wc, wt) owns channels 16wc.. x tiles 16wt.. for
+// all 36 positions (36 x 4 = 144 accumulator registers, two waves per SIMD).  K = Cin is walked 4 channels (one MFMA
+// k-step) per slab through two LDS slabs, ONE barrier per slab.  Slab layout = MFMA fragment order:
+// [position group of 4][k][row] float4 = positions 4g..4g+3, so one ds_read_b128 per operand feeds four MFMAs.
+//   U slab: the transformed weights are stored in exactly this order in memory, and waves 4-7 copy the next slab
+//           global -> LDS with the DMA path (buffer_load ... lds: no registers, no VALU);
+//   V slab: waves 0-3 (one per SIMD) each stage (tile, channel, half): 36 dword buffer loads of the patch (out-of-image
+//           pixels: voffset 0xFFFFFFFF -> 0), the three rows of Bt d B they own (~85 VALU), four ds_write_b128 + one b64;
+//           the transform is woven into the second half of the current slab's MFMAs.
+// Output channels are MFMA rows, so a lane ends up with 4 consecutive channels of a tile: after At M A, sixteen
+// 16-byte stores; the residual loads of a lane are all in flight before its first store.
+// Replaces the same ATen chain as conv_wino.hip (models/modules.py:69-73,94-95).
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+constexpr unsigned OOB = 0xFFFFFFFFu;
+constexpr int CH = 64, TILES = 32, KC = 4, NPG = 9;
+constexpr int U_BYTES = NPG * KC * CH * 16;            // 36 864
+constexpr int V_BYTES = NPG * KC * TILES * 16;         // 18 432
+constexpr int SLAB = U_BYTES + V_BYTES;                // 55 296; two slabs: 110 592
+
+struct W4Args {
+    const float *x, *u, *scale, *shift, *res;
+    float *y;
+    int64_t ldx, ldr, ldy;
+    int B, H, W, Cin, Cout, CoutP;
+    int TH, TW, MT, ntn, nblk;
+};
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const float *base, int64_t bytes) {
+    const uint64_t a = (uint64_t)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const int64_t capped = bytes > 0x7FFFFFF0ll ? 0x7FFFFFF0ll : bytes;
+    const int n = __builtin_amdgcn_readfirstlane((int)capped);
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, n, 0x00020000);
+}
+
+// Bt x (x = six values): all six rows, or only rows 0-2 / 3-5 (the column pass of a thread that owns half the rows)
+#define W4_BT_LO(o, x0, x1, x2, x3, x4, x5)               \
+    {                                                     \
+        o[0] = fmaf(4.0f, x0, fmaf(-5.0f, x2, x4));       \
+        o[1] = (x3 + x4) - 4.0f * (x1 + x2);              \
+        o[2] = (x4 - x3) + 4.0f * (x1 - x2);              \
+    }
+#define W4_BT_HI(o, x0, x1, x2, x3, x4, x5)               \
+    {                                                     \
+        o[0] = (x4 - x2) + 2.0f * (x3 - x1);              \
+        o[1] = (x4 - x2) - 2.0f * (x3 - x1);              \
+        o[2] = fmaf(4.0f, x1, fmaf(-5.0f, x3, x5));       \
+    }
+#define W4_BT(o, x0, x1, x2, x3, x4, x5)                  \
+    {                                                     \
+        W4_BT_LO(o, x0, x1, x2, x3, x4, x5)               \
+        o[3] = (x4 - x2) + 2.0f * (x3 - x1);              \
+        o[4] = (x4 - x2) - 2.0f * (x3 - x1);              \
+        o[5] = fmaf(4.0f, x1, fmaf(-5.0f, x3, x5));       \
+    }
+
+// row I of Bt applied to a column (x0..x5)
+template <int I>
+__device__ __forceinline__ float w4_bt_row(float x0, float x1, float x2, float x3, float x4, float x5) {
+    if constexpr (I == 0) return fmaf(4.0f, x0, fmaf(-5.0f, x2, x4));
+    if constexpr (I == 1) return (x3 + x4) - 4.0f * (x1 + x2);
+    if constexpr (I == 2) return (x4 - x3) + 4.0f * (x1 - x2);
+    if constexpr (I == 3) return (x4 - x2) + 2.0f * (x3 - x1);
+    if constexpr (I == 4) return (x4 - x2) - 2.0f * (x3 - x1);
+    return fmaf(4.0f, x1, fmaf(-5.0f, x3, x5));
+}
+
+template <int ACT, bool RES>
+__global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const W4Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int item = mydet_xcd_remap(blockIdx.x, p.nblk);
+    const int tpi = p.TH * p.TW;
+    const int nk = p.Cin >> 2;
+    const int m0 = (item / p.ntn) * TILES, n0 = (item % p.ntn) * CH;
+    const int b0 = m0 / tpi;
+    const int wc = wave & 3, wt = wave >> 2;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    // ---- staging roles
+    const bool stage_v = tid < 256;                    // waves 0-3: (tile, channel of the slab, half of the rows)
+    const int st = tid & 31, sc = (tid >> 5) & 3;
+    const int shu = (wave >> 1) & 1;                   // wave-uniform: waves 0-1 own rows 0-2 of Bt d B, waves 2-3 rows 3-5
+    const int64_t img = (int64_t)p.H * p.W * p.ldx;
+    // the buffer starts one row + one pixel BEFORE image b0, so that the patch origin (-1, -1) of its first tile is offset 0:
+    // the range check sees the voffset only, and a negative one would read as out of range (those addresses are never
+    // touched: row -1 and column -1 are masked to OOB below)
+    const int64_t lead = (int64_t)(p.W + 1) * p.ldx;
+    const __amdgpu_buffer_rsrc_t xr = rsrc(p.x + b0 * img - lead, ((p.B - b0) * img + lead) * 4);
+    // patch pixel (i, j): voffset = row offset of i (OOB when the row or the tile is outside), column j rides in the scalar
+    // offset; a column outside the image turns the voffset into OOB through a lane mask -- 6 registers instead of 36
+    unsigned rowoff[6];
+    bool colok[6];
+    {
+        const int mt = m0 + st;
+        const int mm = mt < p.MT ? mt : p.MT - 1;
+        const int b = mm / tpi, r = mm - b * tpi, ty = r / p.TW, tx = r - ty * p.TW;
+        const int iy0 = 4 * ty - 1, ix0 = 4 * tx - 1;
+        const int base = (int)((((((int64_t)(b - b0) * p.H + iy0) * p.W + ix0) * p.ldx + sc) + lead) * 4);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const bool ok = stage_v && mt < p.MT && (unsigned)(iy0 + i) < (unsigned)p.H;
+            rowoff[i] = ok ? (unsigned)(base + (int)((int64_t)i * p.W * p.ldx * 4)) : OOB;
+            colok[i] = (unsigned)(ix0 + i) < (unsigned)p.W;
+        }
+    }
+    const unsigned colstep = (unsigned)(p.ldx * 4);
+    // U: run r = (position group, k) of the slab is 64 consecutive float4 in memory (layout of wino4_weights_kernel);
+    // wave 4 + (r & 3) copies runs r, r+4, ...
+    const __amdgpu_buffer_rsrc_t ur = rsrc(p.u, (int64_t)p.Cin * 36 * p.CoutP * 4);
+    const unsigned uoff = (unsigned)((n0 + lane) * 16);
+    const unsigned urun = (unsigned)p.CoutP * 16u;     // bytes between runs
+    const unsigned wr_v = U_BYTES + (unsigned)((sc * TILES + st) * 16);      // + position group * KC*TILES*16
+
+    float gv[36];
+    auto load_slab = [&](int kt, char *next) {
+        if (stage_v) {
+            const unsigned sv = (unsigned)kt * 16u;    // 4 channels further
+#pragma unroll
+            for (int q = 0; q < 36; ++q)
+                gv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                      xr, colok[q % 6] ? rowoff[q / 6] : OOB,
+                                                      __builtin_amdgcn_readfirstlane(sv + (unsigned)(q % 6) * colstep), 0));
+        } else {
+            const unsigned su = (unsigned)kt * 36u * urun;
+            const int w4 = wave - 4;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const int r = w4 + 4 * j;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (__attribute__((address_space(3))) void *)(next + r * 1024), 16, uoff,
+                                                         __builtin_amdgcn_readfirstlane(su + (unsigned)r * urun), 0, 0);
+            }
+        }
+    };
+    // V rows 3sh .. 3sh+2 of Bt d B for this thread's (tile, channel), one row at a time (column pass of that row over
+    // the six patch columns, then the row pass), written as aligned 16- / 8-byte pieces of the position groups
+    auto store_row = [&](char *base, auto row) {       // row = global row index 0..5 (compile time)
+        constexpr int I = decltype(row)::value;
+        float t[6], o[6];
+#pragma unroll
+        for (int m = 0; m < 6; ++m)                    // column m of the patch: d[r][m] = gv[6r + m]
+            t[m] = w4_bt_row<I>(gv[m], gv[6 + m], gv[12 + m], gv[18 + m], gv[24 + m], gv[30 + m]);
+        W4_BT(o, t[0], t[1], t[2], t[3], t[4], t[5])
+        constexpr int GB = KC * TILES * 16;            // bytes between position groups
+        constexpr int p0 = 6 * I;                      // first position of this row
+        if constexpr (p0 % 4 == 0) {                   // [4 | 2]: whole group p0/4, first half of the next
+            *reinterpret_cast<f32x4 *>(base + (p0 / 4) * GB) = f32x4{o[0], o[1], o[2], o[3]};
+            *reinterpret_cast<f32x2 *>(base + (p0 / 4 + 1) * GB) = f32x2{o[4], o[5]};
+        } else {                                       // [2 | 4]: second half of group p0/4, whole next group
+            *reinterpret_cast<f32x2 *>(base + (p0 / 4) * GB + 8) = f32x2{o[0], o[1]};
+            *reinterpret_cast<f32x4 *>(base + (p0 / 4 + 1) * GB) = f32x4{o[2], o[3], o[4], o[5]};
+        }
+    };
+    auto store_slab = [&](char *slab) {
+        if (!stage_v) return;
+        char *base = slab + wr_v;
+        if (shu == 0) {
+            store_row(base, std::integral_constant<int, 0>{});
+            store_row(base, std::integral_constant<int, 1>{});
+            store_row(base, std::integral_constant<int, 2>{});
+        } else {
+            store_row(base, std::integral_constant<int, 3>{});
+            store_row(base, std::integral_constant<int, 4>{});
+            store_row(base, std::integral_constant<int, 5>{});
+        }
+    };
+
+    // ---- compute role
+    const unsigned rd_u = (unsigned)((fq * CH + wc * 16 + fr) * 16);                 // + position group * KC*CH*16
+    const unsigned rd_v = U_BYTES + (unsigned)((fq * TILES + wt * 16 + fr) * 16);    // + position group * KC*TILES*16
+    f32x4 acc[36];
+#pragma unroll
+    for (int q = 0; q < 36; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    load_slab(0, smem);
+    store_slab(smem);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): the DMA'd weights have landed
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const char *cur = smem + (kt & 1) * SLAB;
+        char *nxt = smem + ((kt + 1) & 1) * SLAB;
+        load_slab(kt + 1 < nk ? kt + 1 : kt, nxt);     // past the end: re-load, never consumed
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 fu[2], fv[2];
+        fu[0] = *reinterpret_cast<const f32x4 *>(cur + rd_u);
+        fv[0] = *reinterpret_cast<const f32x4 *>(cur + rd_v);
+#pragma unroll
+        for (int g = 0; g < NPG; ++g) {
+            if (g + 1 < NPG) {
+                fu[(g + 1) & 1] = *reinterpret_cast<const f32x4 *>(cur + rd_u + (g + 1) * (KC * CH * 16));
+                fv[(g + 1) & 1] = *reinterpret_cast<const f32x4 *>(cur + rd_v + (g + 1) * (KC * TILES * 16));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (g == 4) {                              // the other slab was last read before the previous barrier
+#pragma unroll
+                for (int q = 0; q < 36; ++q) asm volatile("" : "+v"(gv[q]));     // pins the transform to this point
+                store_slab(nxt);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc[4 * g + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(fu[g & 1][e], fv[g & 1][e], acc[4 * g + e], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): next slab's DMA'd weights have landed
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane = tile m0 + 16wt + fr, components = channels n0 + 16wc + 4fq + (0..3)
+    const int n = n0 + wc * 16 + fq * 4;
+    const bool nok = n < p.Cout;                       // Cout % 4 == 0
+    const int nc = nok ? n : 0;
+    const f32x4 scl = p.scale ? *reinterpret_cast<const f32x4 *>(p.scale + nc) : f32x4{1.f, 1.f, 1.f, 1.f};
+    const f32x4 sft = p.shift ? *reinterpret_cast<const f32x4 *>(p.shift + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t oimg = (int64_t)p.H * p.W;
+    const __amdgpu_buffer_rsrc_t yr = rsrc(p.y + b0 * oimg * p.ldy, (p.B - b0) * oimg * p.ldy * 4);
+    const __amdgpu_buffer_rsrc_t rr = rsrc(RES ? p.res + b0 * oimg * p.ldr : p.y, (p.B - b0) * oimg * (RES ? p.ldr : p.ldy) * 4);
+    const int mt = m0 + wt * 16 + fr;
+    const bool tok = mt < p.MT && nok;
+    const int mm = mt < p.MT ? mt : p.MT - 1;
+    const int b = mm / tpi, r = mm - b * tpi, ty = r / p.TW, tx = r - ty * p.TW;
+    const int oy = 4 * ty, ox = 4 * tx;
+    const int64_t pix = ((int64_t)(b - b0) * p.H + oy) * p.W + ox;
+    // output transform Y = At M A, one output row a at a time (the whole 4x4 result plus its residuals would not fit
+    // the register file next to the 144 accumulators): s[m] = sum_i At[a][i] M[i][m], out[c] = sum_m s[m] At[c][m]
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        unsigned yo[4];
+        f32x4 rv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool ok = tok && oy + a < p.H && ox + c < p.W;
+            const int64_t px = pix + (int64_t)a * p.W + c;
+            yo[c] = ok ? (unsigned)((px * p.ldy + n) * 4) : OOB;
+            if (RES) rv[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ok ? (unsigned)((px * p.ldr + n) * 4) : OOB, 0, 0));
+        }
+        f32x4 s[6];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+            if (a == 0) s[m] = acc[m] + (acc[6 + m] + acc[12 + m]) + (acc[18 + m] + acc[24 + m]);
+            if (a == 1) s[m] = (acc[6 + m] - acc[12 + m]) + 2.0f * (acc[18 + m] - acc[24 + m]);
+            if (a == 2) s[m] = (acc[6 + m] + acc[12 + m]) + 4.0f * (acc[18 + m] + acc[24 + m]);
+            if (a == 3) s[m] = (acc[6 + m] - acc[12 + m]) + 8.0f * (acc[18 + m] - acc[24 + m]) + acc[30 + m];
+        }
+        const f32x4 pp = s[1] + s[2], qq = s[3] + s[4], dd = s[1] - s[2], ee = s[3] - s[4];
+        f32x4 out[4];
+        out[0] = s[0] + pp + qq;
+        out[1] = dd + 2.0f * ee;
+        out[2] = pp + 4.0f * qq;
+        out[3] = dd + 8.0f * ee + s[5];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f32x4 v = out[c] * scl + sft;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (ACT == MYDET_ACT_LEAKY) v[e] = v[e] > 0.0f ? v[e] : v[e] * 0.1f;
+                if (ACT == MYDET_ACT_SWISH) v[e] = v[e] * mydet_sigmoid_fast(v[e]);
+            }
+            if (RES) v += rv[c];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, yo[c], 0, 0);
+        }
+    }
+}
+
+// U = G g Gt in float64, rounded once; layout [Cin/4][9 position groups][4 k][CoutP][4] with the float4 = positions
+// 4g..4g+3 at channel k (CoutP = Cout rounded up to 64, zero rows): exactly the LDS slab, so a workgroup's share of a
+// slab is 36 contiguous runs of 64 float4.
+__global__ void wino4_weights_kernel(const float *w, int Cout, int Cin, int CoutP, float *u) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)CoutP * Cin) return;
+    const int n = (int)(i / Cin), c = (int)(i - (int64_t)n * Cin);
+    const double G[6][3] = {{0.25, 0.0, 0.0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+    double g[3][3], t[6][3];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) g[a][b] = n < Cout ? (double)w[(((int64_t)n * 3 + a) * 3 + b) * Cin + c] : 0.0;
+    for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 3; ++b) t[a][b] = G[a][0] * g[0][b] + G[a][1] * g[1][b] + G[a][2] * g[2][b];
+    const int ks = c >> 2, kq = c & 3;
+    for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 6; ++b) {
+            const double v = t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2];
+            const int q = a * 6 + b;
+            u[((((int64_t)ks * NPG + (q >> 2)) * KC + kq) * CoutP + n) * 4 + (q & 3)] = (float)v;
+        }
+}
+
+template <int ACT, bool RES>
+int launch_w4(W4Args a, hipStream_t stream) {
+    static bool attr_set = false;                      // > 64 KiB of dynamic LDS needs the opt-in once
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino4_kernel<ACT, RES>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SLAB);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_wino4_kernel<ACT, RES>), dim3(a.nblk), dim3(512), 2 * SLAB, stream, a);
+    return mydet_launch_status();
+}
+
+}  // namespace
+
+extern "C" int64_t mydet_wino4_weights_floats(int Cout, int Cin) {
+    if (Cout <= 0 || Cin <= 0 || (Cin & 3)) return 0;
+    return (int64_t)36 * Cin * ((Cout + 63) / 64 * 64);
+}
+
+extern "C" int mydet_wino4_weights_f32(const float *w, int Cout, int Cin, float *u, void *stream) {
+    if (!w || !u || Cout <= 0 || Cin <= 0) return MYDET_E_BADARG;
+    if (Cin & 3) return MYDET_E_UNSUPP;
+    const int CoutP = (Cout + 63) / 64 * 64;
+    const int64_t n = (int64_t)CoutP * Cin;
+    hipLaunchKernelGGL(wino4_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin,
+                       CoutP, u);
+    return mydet_launch_status();
+}
+
+extern "C" int mydet_conv2d_wino4_f32(const float *x, int64_t ldx, const float *u, const float *scale, const float *shift,
+                                      const float *residual, int64_t ldr, float *y, int64_t ldy, int B, int H, int W,
+                                      int Cin, int Cout, int act, void *stream) {
+    if (!x || !u || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || act < 0 || act > 2) return MYDET_E_BADARG;
+    if ((ldx & 3) || ldx < Cin || ldy < Cout || (residual && ldr < Cout)) return MYDET_E_BADARG;
+    if (((uintptr_t)x & 15) || ((uintptr_t)u & 15) || ((uintptr_t)y & 15) || (residual && ((uintptr_t)residual & 15)) ||
+        (scale && ((uintptr_t)scale & 15)) || (shift && ((uintptr_t)shift & 15)))
+        return MYDET_E_BADARG;
+    if ((Cin & 3) || (Cout & 3) || (ldy & 3) || (residual && (ldr & 3))) return MYDET_E_UNSUPP;
+    W4Args a;
+    a.x = x; a.u = u; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+    a.ldx = ldx; a.ldr = residual ? ldr : ldy; a.ldy = ldy;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.CoutP = (Cout + 63) / 64 * 64;
+    a.TH = (H + 3) / 4; a.TW = (W + 3) / 4;
+    const int64_t MT = (int64_t)B * a.TH * a.TW;
+    if (MT > (int64_t)1 << 30) return MYDET_E_UNSUPP;
+    // 32-bit byte offsets inside a workgroup's window: the images its 32 tiles touch
+    const int64_t span = TILES / ((int64_t)a.TH * a.TW) + 2;
+    const int64_t ldmax = ldx > ldy ? (ldx > a.ldr ? ldx : a.ldr) : (ldy > a.ldr ? ldy : a.ldr);
+    if ((int64_t)H * W * ldmax * 4 * span >= 0x7FFFFFF0ll || (int64_t)36 * Cin * a.CoutP * 4 >= 0x7FFFFFF0ll) return MYDET_E_UNSUPP;
+    a.MT = (int)MT;
+    a.ntn = a.CoutP / CH;
+    a.nblk = (int)((MT + TILES - 1) / TILES) * a.ntn;
+    hipStream_t s = (hipStream_t)stream;
+    const bool res = residual != nullptr;
+    switch (act) {
+        case MYDET_ACT_LEAKY: return res ? launch_w4<MYDET_ACT_LEAKY, true>(a, s) : launch_w4<MYDET_ACT_LEAKY, false>(a, s);
+        case MYDET_ACT_SWISH: return res ? launch_w4<MYDET_ACT_SWISH, true>(a, s) : launch_w4<MYDET_ACT_SWISH, false>(a, s);
+        default: return res ? launch_w4<MYDET_ACT_NONE, true>(a, s) : launch_w4<MYDET_ACT_NONE, false>(a, s);
+    }
+}
