@@ -12,15 +12,20 @@
 // float32 throughout; against float64 the error is ~3e-6 rms of O(1) outputs (the direct form: 2e-7; tests/
 // test_winograd_algebra.py), i.e. 30x inside the 1e-4 the detections are held to.
 //
-// A workgroup of 8 waves owns 64 output channels x 32 tiles; wave (wc, wt) owns channels 16wc.. x tiles 16wt.. for
-// all 36 positions (36 x 4 = 144 accumulator registers, two waves per SIMD).  K = Cin is walked 4 channels (one MFMA
-// k-step) per slab through two LDS slabs, ONE barrier per slab.  Slab layout = MFMA fragment order:
-// [position group of 4][k][row] float4 = positions 4g..4g+3, so one ds_read_b128 per operand feeds four MFMAs.
-//   U slab: the transformed weights are stored in exactly this order in memory, and waves 4-7 copy the next slab
-//           global -> LDS with the DMA path (buffer_load ... lds: no registers, no VALU);
-//   V slab: waves 0-3 (one per SIMD) each stage (tile, channel, half): 36 dword buffer loads of the patch (out-of-image
-//           pixels: voffset 0xFFFFFFFF -> 0), the three rows of Bt d B they own (~85 VALU), four ds_write_b128 + one b64;
-//           the transform is woven into the second half of the current slab's MFMAs.
+// A workgroup of 8 waves (one per CU: 144 KB of LDS) owns 64 output channels x 32 tiles; wave (wc, wt) owns channels
+// 16wc.. x tiles 16wt.. for all 36 positions (36 x 4 = 144 accumulator registers, two waves per SIMD).
+// K = Cin is walked in V slabs of 16 channels, each consumed as four U sub-slabs of 4 channels (one MFMA k-step):
+//   V slab (72 KB, one buffer): every thread stages one (tile, channel): 36 dword buffer loads of the 6x6 patch -- a wave
+//           covers 4 tiles x 16 channels, i.e. one 64-byte run per pixel, a quarter of the cache-line lookups of a
+//           4-channel slab --, issued at the top of the slab and landing under its 144 MFMAs per wave; after the slab's
+//           last MFMA: Bt d B in registers (~150 VALU), nine ds_write_b128.  Out-of-image pixels: voffset 0xFFFFFFFF
+//           (hardware range check returns 0); row, column and K advance ride in the scalar offset.
+//           Layout [position group of 4][tile][k ^ (tile & 15)] float4 = positions 4g..4g+3: the XOR makes both the
+//           staging stores (16 channels of a tile) and the fragment reads (16 tiles at one k) bank-conflict free.
+//   U sub-slab (36 KB, two buffers): the transformed weights are stored in MFMA fragment order in memory
+//           ([k/4][position group][k%4][channel] float4), and the waves copy sub-slab kt+1 global -> LDS with the DMA path
+//           (buffer_load ... lds: no registers, no VALU) under the MFMAs of sub-slab kt.
+// One ds_read_b128 per operand feeds four MFMAs (36 MFMAs : 18 LDS reads per wave and k-step).
 // Output channels are MFMA rows, so a lane ends up with 4 consecutive channels of a tile: after At M A, sixteen
 // 16-byte stores; the residual loads of a lane are all in flight before its first store.
 // Replaces the same ATen chain as conv_wino.hip (models/modules.py:69-73,94-95).
@@ -32,10 +37,11 @@
 namespace {
 
 constexpr unsigned OOB = 0xFFFFFFFFu;
-constexpr int CH = 64, TILES = 32, KC = 4, NPG = 9;
-constexpr int U_BYTES = NPG * KC * CH * 16;            // 36 864
-constexpr int V_BYTES = NPG * KC * TILES * 16;         // 18 432
-constexpr int SLAB = U_BYTES + V_BYTES;                // 55 296; two slabs: 110 592
+constexpr int CH = 64, TILES = 32, KC = 4, KV = 16, NPG = 9;
+constexpr int U_BYTES = NPG * KC * CH * 16;            // 36 864: one 4-channel sub-slab of U
+constexpr int V_PG = TILES * KV * 16;                  // 8 192: bytes between position groups of V
+constexpr int V_BYTES = NPG * V_PG;                    // 73 728: one 16-channel slab of V
+constexpr int LDS_BYTES = V_BYTES + 2 * U_BYTES;       // 147 456
 
 struct W4Args {
     const float *x, *u, *scale, *shift, *res;
@@ -92,141 +98,135 @@ __device__ __forceinline__ float w4_bt_row(float x0, float x1, float x2, float x
 template <int ACT, bool RES>
 __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const W4Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *const vbuf = smem, *const ubuf = smem + V_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int item = mydet_xcd_remap(blockIdx.x, p.nblk);
     const int tpi = p.TH * p.TW;
-    const int nk = p.Cin >> 2;
+    const int nk = p.Cin >> 2, nks = (p.Cin + 15) >> 4;       // Cin % 4 == 0; the last V slab may be partial
     const int m0 = (item / p.ntn) * TILES, n0 = (item % p.ntn) * CH;
     const int b0 = m0 / tpi;
     const int wc = wave & 3, wt = wave >> 2;
     const int fr = lane & 15, fq = lane >> 4;
 
-    // ---- staging roles
-    const bool stage_v = tid < 256;                    // waves 0-3: (tile, channel of the slab, half of the rows)
-    const int st = tid & 31, sc = (tid >> 5) & 3;
-    const int shu = (wave >> 1) & 1;                   // wave-uniform: waves 0-1 own rows 0-2 of Bt d B, waves 2-3 rows 3-5
+    // ---- staging role: (tile st, channel sc of the 16-channel slab)
+    const int sc = tid & 15, st = tid >> 4;
     const int64_t img = (int64_t)p.H * p.W * p.ldx;
     // the buffer starts one row + one pixel BEFORE image b0, so that the patch origin (-1, -1) of its first tile is offset 0:
     // the range check sees the voffset only, and a negative one would read as out of range (those addresses are never
     // touched: row -1 and column -1 are masked to OOB below)
     const int64_t lead = (int64_t)(p.W + 1) * p.ldx;
     const __amdgpu_buffer_rsrc_t xr = rsrc(p.x + b0 * img - lead, ((p.B - b0) * img + lead) * 4);
-    // patch pixel (i, j): voffset = row offset of i (OOB when the row or the tile is outside), column j rides in the scalar
-    // offset; a column outside the image turns the voffset into OOB through a lane mask -- 6 registers instead of 36
-    unsigned rowoff[6];
-    bool colok[6];
+    // patch pixel (i, j): voffset = the patch origin (or OOB when the pixel is outside the image / the tile past the end);
+    // i * row pitch + j * pixel pitch + slab * 64 bytes ride in the scalar offset
+    unsigned vbase;
+    bool rowok[6], colok[6];
     {
         const int mt = m0 + st;
         const int mm = mt < p.MT ? mt : p.MT - 1;
         const int b = mm / tpi, r = mm - b * tpi, ty = r / p.TW, tx = r - ty * p.TW;
         const int iy0 = 4 * ty - 1, ix0 = 4 * tx - 1;
-        const int base = (int)((((((int64_t)(b - b0) * p.H + iy0) * p.W + ix0) * p.ldx + sc) + lead) * 4);
+        vbase = (unsigned)((((((int64_t)(b - b0) * p.H + iy0) * p.W + ix0) * p.ldx + sc) + lead) * 4);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            const bool ok = stage_v && mt < p.MT && (unsigned)(iy0 + i) < (unsigned)p.H;
-            rowoff[i] = ok ? (unsigned)(base + (int)((int64_t)i * p.W * p.ldx * 4)) : OOB;
+            rowok[i] = mt < p.MT && (unsigned)(iy0 + i) < (unsigned)p.H;
             colok[i] = (unsigned)(ix0 + i) < (unsigned)p.W;
         }
     }
-    const unsigned colstep = (unsigned)(p.ldx * 4);
-    // U: run r = (position group, k) of the slab is 64 consecutive float4 in memory (layout of wino4_weights_kernel);
-    // wave 4 + (r & 3) copies runs r, r+4, ...
+    const unsigned colstep = (unsigned)(p.ldx * 4), rowstep = (unsigned)(p.W * p.ldx * 4);
+    // U: run r = (position group, k) of a sub-slab is 64 consecutive float4 in memory (layout of wino4_weights_kernel);
+    // wave w copies runs w, w + 8, ...
     const __amdgpu_buffer_rsrc_t ur = rsrc(p.u, (int64_t)p.Cin * 36 * p.CoutP * 4);
     const unsigned uoff = (unsigned)((n0 + lane) * 16);
     const unsigned urun = (unsigned)p.CoutP * 16u;     // bytes between runs
-    const unsigned wr_v = U_BYTES + (unsigned)((sc * TILES + st) * 16);      // + position group * KC*TILES*16
+    char *const wr_v = vbuf + st * (KV * 16) + ((sc ^ (st & 15)) * 16);      // + position group * V_PG
 
     float gv[36];
-    auto load_slab = [&](int kt, char *next) {
-        if (stage_v) {
-            const unsigned sv = (unsigned)kt * 16u;    // 4 channels further
+    auto load_v = [&](int ks) {                        // raw patch of slab ks -> registers
+        const unsigned sv = (unsigned)ks * 64u;
+        const unsigned vb = 16 * ks + sc < p.Cin ? vbase : OOB;              // channels past Cin (partial last slab): 0
 #pragma unroll
-            for (int q = 0; q < 36; ++q)
-                gv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                      xr, colok[q % 6] ? rowoff[q / 6] : OOB,
-                                                      __builtin_amdgcn_readfirstlane(sv + (unsigned)(q % 6) * colstep), 0));
-        } else {
-            const unsigned su = (unsigned)kt * 36u * urun;
-            const int w4 = wave - 4;
+        for (int q = 0; q < 36; ++q)
+            gv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                  xr, rowok[q / 6] && colok[q % 6] ? vb : OOB,
+                                                  __builtin_amdgcn_readfirstlane(sv + (unsigned)(q / 6) * rowstep + (unsigned)(q % 6) * colstep), 0));
+    };
+    auto load_u = [&](int kt) {                        // sub-slab kt -> ubuf[kt & 1], DMA
+        const unsigned su = (unsigned)kt * 36u * urun;
+        char *dst = ubuf + (kt & 1) * U_BYTES;
 #pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const int r = w4 + 4 * j;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (__attribute__((address_space(3))) void *)(next + r * 1024), 16, uoff,
+        for (int j = 0; j < 5; ++j) {
+            const int r = wave + 8 * j;
+            if (r < 36)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (__attribute__((address_space(3))) void *)(dst + r * 1024), 16, uoff,
                                                          __builtin_amdgcn_readfirstlane(su + (unsigned)r * urun), 0, 0);
-            }
         }
     };
-    // V rows 3sh .. 3sh+2 of Bt d B for this thread's (tile, channel), one row at a time (column pass of that row over
-    // the six patch columns, then the row pass), written as aligned 16- / 8-byte pieces of the position groups
-    auto store_row = [&](char *base, auto row) {       // row = global row index 0..5 (compile time)
-        constexpr int I = decltype(row)::value;
-        float t[6], o[6];
+    // rows 2h, 2h+1 of V = Bt d B (positions 12h .. 12h+11 = position groups 3h .. 3h+2): column pass of the row over the
+    // six patch columns, then the row pass
+    auto store_rows = [&](auto half) {
+        constexpr int I = 2 * decltype(half)::value;
+        float t[6], o[6], o2[6];
 #pragma unroll
         for (int m = 0; m < 6; ++m)                    // column m of the patch: d[r][m] = gv[6r + m]
             t[m] = w4_bt_row<I>(gv[m], gv[6 + m], gv[12 + m], gv[18 + m], gv[24 + m], gv[30 + m]);
         W4_BT(o, t[0], t[1], t[2], t[3], t[4], t[5])
-        constexpr int GB = KC * TILES * 16;            // bytes between position groups
-        constexpr int p0 = 6 * I;                      // first position of this row
-        if constexpr (p0 % 4 == 0) {                   // [4 | 2]: whole group p0/4, first half of the next
-            *reinterpret_cast<f32x4 *>(base + (p0 / 4) * GB) = f32x4{o[0], o[1], o[2], o[3]};
-            *reinterpret_cast<f32x2 *>(base + (p0 / 4 + 1) * GB) = f32x2{o[4], o[5]};
-        } else {                                       // [2 | 4]: second half of group p0/4, whole next group
-            *reinterpret_cast<f32x2 *>(base + (p0 / 4) * GB + 8) = f32x2{o[0], o[1]};
-            *reinterpret_cast<f32x4 *>(base + (p0 / 4 + 1) * GB) = f32x4{o[2], o[3], o[4], o[5]};
-        }
+#pragma unroll
+        for (int m = 0; m < 6; ++m)
+            t[m] = w4_bt_row<I + 1>(gv[m], gv[6 + m], gv[12 + m], gv[18 + m], gv[24 + m], gv[30 + m]);
+        W4_BT(o2, t[0], t[1], t[2], t[3], t[4], t[5])
+        char *base = wr_v + (3 * decltype(half)::value) * V_PG;
+        *reinterpret_cast<f32x4 *>(base) = f32x4{o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<f32x4 *>(base + V_PG) = f32x4{o[4], o[5], o2[0], o2[1]};
+        *reinterpret_cast<f32x4 *>(base + 2 * V_PG) = f32x4{o2[2], o2[3], o2[4], o2[5]};
     };
-    auto store_slab = [&](char *slab) {
-        if (!stage_v) return;
-        char *base = slab + wr_v;
-        if (shu == 0) {
-            store_row(base, std::integral_constant<int, 0>{});
-            store_row(base, std::integral_constant<int, 1>{});
-            store_row(base, std::integral_constant<int, 2>{});
-        } else {
-            store_row(base, std::integral_constant<int, 3>{});
-            store_row(base, std::integral_constant<int, 4>{});
-            store_row(base, std::integral_constant<int, 5>{});
-        }
+    auto store_v = [&]() {
+        store_rows(std::integral_constant<int, 0>{});
+        store_rows(std::integral_constant<int, 1>{});
+        store_rows(std::integral_constant<int, 2>{});
     };
 
     // ---- compute role
-    const unsigned rd_u = (unsigned)((fq * CH + wc * 16 + fr) * 16);                 // + position group * KC*CH*16
-    const unsigned rd_v = U_BYTES + (unsigned)((fq * TILES + wt * 16 + fr) * 16);    // + position group * KC*TILES*16
+    const unsigned rd_u = (unsigned)((fq * CH + wc * 16 + fr) * 16);         // + position group * KC*CH*16
+    const unsigned rd_vt = (unsigned)((wt * 16 + fr) * (KV * 16));           // + ((k ^ fr) * 16) + position group * V_PG
     f32x4 acc[36];
 #pragma unroll
     for (int q = 0; q < 36; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    load_slab(0, smem);
-    store_slab(smem);
+    load_v(0);
+    load_u(0);
+    store_v();
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): the DMA'd weights have landed
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const char *cur = smem + (kt & 1) * SLAB;
-        char *nxt = smem + ((kt + 1) & 1) * SLAB;
-        load_slab(kt + 1 < nk ? kt + 1 : kt, nxt);     // past the end: re-load, never consumed
-        __builtin_amdgcn_sched_barrier(0);
-        f32x4 fu[2], fv[2];
-        fu[0] = *reinterpret_cast<const f32x4 *>(cur + rd_u);
-        fv[0] = *reinterpret_cast<const f32x4 *>(cur + rd_v);
+    for (int ks = 0; ks < nks; ++ks) {
+        if (ks + 1 < nks) load_v(ks + 1);              // lands under this slab's MFMAs
+#pragma unroll 1
+        for (int s = 0; s < 4; ++s) {
+            const int kt = 4 * ks + s;
+            if (kt >= nk) break;
+            if (kt + 1 < nk) load_u(kt + 1);           // its buffer was last read before the previous barrier
+            const char *cu = ubuf + (kt & 1) * U_BYTES + rd_u;
+            const char *cv = vbuf + rd_vt + (unsigned)((((4 * s + fq) ^ fr) & 15) * 16);
+            f32x4 fu[2], fv[2];
+            fu[0] = *reinterpret_cast<const f32x4 *>(cu);
+            fv[0] = *reinterpret_cast<const f32x4 *>(cv);
 #pragma unroll
-        for (int g = 0; g < NPG; ++g) {
-            if (g + 1 < NPG) {
-                fu[(g + 1) & 1] = *reinterpret_cast<const f32x4 *>(cur + rd_u + (g + 1) * (KC * CH * 16));
-                fv[(g + 1) & 1] = *reinterpret_cast<const f32x4 *>(cur + rd_v + (g + 1) * (KC * TILES * 16));
+            for (int g = 0; g < NPG; ++g) {
+                if (g + 1 < NPG) {
+                    fu[(g + 1) & 1] = *reinterpret_cast<const f32x4 *>(cu + (g + 1) * (KC * CH * 16));
+                    fv[(g + 1) & 1] = *reinterpret_cast<const f32x4 *>(cv + (g + 1) * V_PG);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[4 * g + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(fu[g & 1][e], fv[g & 1][e], acc[4 * g + e], 0, 0, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            if (g == 4) {                              // the other slab was last read before the previous barrier
-#pragma unroll
-                for (int q = 0; q < 36; ++q) asm volatile("" : "+v"(gv[q]));     // pins the transform to this point
-                store_slab(nxt);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                acc[4 * g + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(fu[g & 1][e], fv[g & 1][e], acc[4 * g + e], 0, 0, 0);
+            __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): next sub-slab's DMA'd weights (and the patch) have landed
+            __syncthreads();
         }
-        __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): next slab's DMA'd weights have landed
-        __syncthreads();
+        if (ks + 1 < nks) {
+            store_v();                                 // every wave is past its last read of the V slab
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: lane = tile m0 + 16wt + fr, components = channels n0 + 16wc + 4fq + (0..3)
@@ -313,10 +313,10 @@ int launch_w4(W4Args a, hipStream_t stream) {
     static bool attr_set = false;                      // > 64 KiB of dynamic LDS needs the opt-in once
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino4_kernel<ACT, RES>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SLAB);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_wino4_kernel<ACT, RES>), dim3(a.nblk), dim3(512), 2 * SLAB, stream, a);
+    hipLaunchKernelGGL((conv_wino4_kernel<ACT, RES>), dim3(a.nblk), dim3(512), LDS_BYTES, stream, a);
     return mydet_launch_status();
 }
 

@@ -1,5 +1,5 @@
 import sys, torch, torch.nn.functional as F
-sys.path.insert(0,'/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mydetection_amd import ops
 dev=torch.device('cuda')
 def run(B,Cin,Cout,H,W,mode):
