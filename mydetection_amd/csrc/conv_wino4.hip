@@ -12,17 +12,18 @@
 // float32 throughout; against float64 the error is ~3e-6 rms of O(1) outputs (the direct form: 2e-7; tests/
 // test_winograd_algebra.py), i.e. 30x inside the 1e-4 the detections are held to.
 //
-// A workgroup of 8 waves (one per CU: 144 KB of LDS) owns 64 output channels x 32 tiles; wave (wc, wt) owns channels
-// 16wc.. x tiles 16wt.. for all 36 positions (36 x 4 = 144 accumulator registers, two waves per SIMD).
-// K = Cin is walked in V slabs of 16 channels, each consumed as four U sub-slabs of 4 channels (one MFMA k-step):
-//   V slab (72 KB, one buffer): every thread stages one (tile, channel): 36 dword buffer loads of the 6x6 patch -- a wave
-//           covers 4 tiles x 16 channels, i.e. one 64-byte run per pixel, a quarter of the cache-line lookups of a
-//           4-channel slab --, issued at the top of the slab and landing under its 144 MFMAs per wave; after the slab's
-//           last MFMA: Bt d B in registers (~150 VALU), nine ds_write_b128.  Out-of-image pixels: voffset 0xFFFFFFFF
-//           (hardware range check returns 0); row, column and K advance ride in the scalar offset.
-//           Layout [position group of 4][tile][k ^ (tile & 15)] float4 = positions 4g..4g+3: the XOR makes both the
-//           staging stores (16 channels of a tile) and the fragment reads (16 tiles at one k) bank-conflict free.
-//   U sub-slab (36 KB, two buffers): the transformed weights are stored in MFMA fragment order in memory
+// A workgroup of 4 waves owns 32 output channels x 32 tiles; wave (wc, wt) owns channels 16wc.. x tiles 16wt.. for all
+// 36 positions (36 x 4 = 144 accumulator registers).  Two workgroups per CU (72 KB of LDS each, one wave of each per
+// SIMD): they drift apart, so one's barriers, prologue and epilogue run under the other's MFMAs.
+// K = Cin is walked in V slabs of 8 channels, each consumed as two U sub-slabs of 4 channels (one MFMA k-step):
+//   V slab (36 KB, one buffer): every thread stages one (tile, channel): 36 dword buffer loads of the 6x6 patch (a wave
+//           covers 8 tiles x 8 channels: one 32-byte run per pixel), issued at the top of the slab and landing under its
+//           72 MFMAs per wave; after the slab's last MFMA: Bt d B in registers (~150 VALU), nine ds_write_b128.
+//           Out-of-image pixels: voffset 0xFFFFFFFF (hardware range check returns 0); row, column and K advance ride in
+//           the scalar offset.  Layout [position group of 4][tile][k ^ (tile >> 1 & 7)] float4 = positions 4g..4g+3: the
+//           XOR makes both the staging stores (8 channels of 8 tiles) and the fragment reads (16 tiles at one k)
+//           bank-conflict free.
+//   U sub-slab (18 KB, two buffers): the transformed weights are stored in MFMA fragment order in memory
 //           ([k/4][position group][k%4][channel] float4), and the waves copy sub-slab kt+1 global -> LDS with the DMA path
 //           (buffer_load ... lds: no registers, no VALU) under the MFMAs of sub-slab kt.
 // One ds_read_b128 per operand feeds four MFMAs (36 MFMAs : 18 LDS reads per wave and k-step).
@@ -37,11 +38,11 @@
 namespace {
 
 constexpr unsigned OOB = 0xFFFFFFFFu;
-constexpr int CH = 64, TILES = 32, KC = 4, KV = 16, NPG = 9;
-constexpr int U_BYTES = NPG * KC * CH * 16;            // 36 864: one 4-channel sub-slab of U
-constexpr int V_PG = TILES * KV * 16;                  // 8 192: bytes between position groups of V
-constexpr int V_BYTES = NPG * V_PG;                    // 73 728: one 16-channel slab of V
-constexpr int LDS_BYTES = V_BYTES + 2 * U_BYTES;       // 147 456
+constexpr int CH = 32, TILES = 32, KC = 4, KV = 8, NPG = 9;
+constexpr int U_BYTES = NPG * KC * CH * 16;            // 18 432: one 4-channel sub-slab of U
+constexpr int V_PG = TILES * KV * 16;                  // 4 096: bytes between position groups of V
+constexpr int V_BYTES = NPG * V_PG;                    // 36 864: one 8-channel slab of V
+constexpr int LDS_BYTES = V_BYTES + 2 * U_BYTES;       // 73 728: two workgroups per CU
 
 struct W4Args {
     const float *x, *u, *scale, *shift, *res;
@@ -96,21 +97,21 @@ __device__ __forceinline__ float w4_bt_row(float x0, float x1, float x2, float x
 }
 
 template <int ACT, bool RES>
-__global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const W4Args p) {
+__global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const W4Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *const vbuf = smem, *const ubuf = smem + V_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int item = mydet_xcd_remap(blockIdx.x, p.nblk);
     const int tpi = p.TH * p.TW;
-    const int nk = p.Cin >> 2, nks = (p.Cin + 15) >> 4;       // Cin % 4 == 0; the last V slab may be partial
+    const int nk = p.Cin >> 2, nks = (p.Cin + KV - 1) / KV;       // Cin % 4 == 0; the last V slab may be partial
     const int m0 = (item / p.ntn) * TILES, n0 = (item % p.ntn) * CH;
     const int b0 = m0 / tpi;
-    const int wc = wave & 3, wt = wave >> 2;
+    const int wc = wave & 1, wt = wave >> 1;
     const int fr = lane & 15, fq = lane >> 4;
 
-    // ---- staging role: (tile st, channel sc of the 16-channel slab)
-    const int sc = tid & 15, st = tid >> 4;
+    // ---- staging role: (tile st, channel sc of the 8-channel slab)
+    const int sc = tid & 7, st = tid >> 3;
     const int64_t img = (int64_t)p.H * p.W * p.ldx;
     // the buffer starts one row + one pixel BEFORE image b0, so that the patch origin (-1, -1) of its first tile is offset 0:
     // the range check sees the voffset only, and a negative one would read as out of range (those addresses are never
@@ -135,95 +136,111 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const W4Args p) {
     }
     const unsigned colstep = (unsigned)(p.ldx * 4), rowstep = (unsigned)(p.W * p.ldx * 4);
     // U: run r = (position group, k) of a sub-slab is 64 consecutive float4 in memory (layout of wino4_weights_kernel);
-    // wave w copies runs w, w + 8, ...
+    // a DMA instruction copies two runs (32 lanes each); wave w copies run pairs w, w + 4, ...
     const __amdgpu_buffer_rsrc_t ur = rsrc(p.u, (int64_t)p.Cin * 36 * p.CoutP * 4);
-    const unsigned uoff = (unsigned)((n0 + lane) * 16);
     const unsigned urun = (unsigned)p.CoutP * 16u;     // bytes between runs
-    char *const wr_v = vbuf + st * (KV * 16) + ((sc ^ (st & 15)) * 16);      // + position group * V_PG
+    const unsigned uoff = (unsigned)((n0 + (lane & 31)) * 16) + (lane >> 5) * urun;
+    char *const wr_v = vbuf + st * (KV * 16) + ((sc ^ ((st >> 1) & 7)) * 16);      // + position group * V_PG
 
     float gv[36];
-    auto load_v = [&](int ks) {                        // raw patch of slab ks -> registers
-        const unsigned sv = (unsigned)ks * 64u;
-        const unsigned vb = 16 * ks + sc < p.Cin ? vbase : OOB;              // channels past Cin (partial last slab): 0
+    auto load_v = [&](int ks) __attribute__((always_inline)) {                        // raw patch of slab ks -> registers
+        const unsigned sv = (unsigned)ks * (KV * 4);
+        const unsigned vb = KV * ks + sc < p.Cin ? vbase : OOB;              // channels past Cin (partial last slab): 0
 #pragma unroll
         for (int q = 0; q < 36; ++q)
             gv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                   xr, rowok[q / 6] && colok[q % 6] ? vb : OOB,
                                                   __builtin_amdgcn_readfirstlane(sv + (unsigned)(q / 6) * rowstep + (unsigned)(q % 6) * colstep), 0));
     };
-    auto load_u = [&](int kt) {                        // sub-slab kt -> ubuf[kt & 1], DMA
+    auto load_u = [&](int kt) __attribute__((always_inline)) {                        // sub-slab kt -> ubuf[kt & 1], DMA
         const unsigned su = (unsigned)kt * 36u * urun;
         char *dst = ubuf + (kt & 1) * U_BYTES;
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            const int r = wave + 8 * j;
-            if (r < 36)
+            const int r = wave + 4 * j;                // run pair
+            if (r < 18)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (__attribute__((address_space(3))) void *)(dst + r * 1024), 16, uoff,
-                                                         __builtin_amdgcn_readfirstlane(su + (unsigned)r * urun), 0, 0);
+                                                         __builtin_amdgcn_readfirstlane(su + (unsigned)(2 * r) * urun), 0, 0);
         }
     };
-    // rows 2h, 2h+1 of V = Bt d B (positions 12h .. 12h+11 = position groups 3h .. 3h+2): column pass of the row over the
-    // six patch columns, then the row pass
-    auto store_rows = [&](auto half) {
-        constexpr int I = 2 * decltype(half)::value;
-        float t[6], o[6], o2[6];
-#pragma unroll
-        for (int m = 0; m < 6; ++m)                    // column m of the patch: d[r][m] = gv[6r + m]
-            t[m] = w4_bt_row<I>(gv[m], gv[6 + m], gv[12 + m], gv[18 + m], gv[24 + m], gv[30 + m]);
-        W4_BT(o, t[0], t[1], t[2], t[3], t[4], t[5])
-#pragma unroll
-        for (int m = 0; m < 6; ++m)
-            t[m] = w4_bt_row<I + 1>(gv[m], gv[6 + m], gv[12 + m], gv[18 + m], gv[24 + m], gv[30 + m]);
-        W4_BT(o2, t[0], t[1], t[2], t[3], t[4], t[5])
-        char *base = wr_v + (3 * decltype(half)::value) * V_PG;
-        *reinterpret_cast<f32x4 *>(base) = f32x4{o[0], o[1], o[2], o[3]};
-        *reinterpret_cast<f32x4 *>(base + V_PG) = f32x4{o[4], o[5], o2[0], o2[1]};
-        *reinterpret_cast<f32x4 *>(base + 2 * V_PG) = f32x4{o2[2], o2[3], o2[4], o2[5]};
+    // V = Bt d B in place on gv (position p = 6i + j ends up in gv[p]), cut into nine pieces that ride between the MFMA
+    // groups of the slab's last sub-slab: pieces 0-2 = the column pass (Bt d, two patch columns each), pieces 3-8 = the
+    // row pass (one row of (Bt d) B each)
+    auto bt6 = [&](float &x0, float &x1, float &x2, float &x3, float &x4, float &x5) __attribute__((always_inline)) {
+        float o[6];
+        W4_BT(o, x0, x1, x2, x3, x4, x5)
+        x0 = o[0]; x1 = o[1]; x2 = o[2]; x3 = o[3]; x4 = o[4]; x5 = o[5];
     };
-    auto store_v = [&]() {
-        store_rows(std::integral_constant<int, 0>{});
-        store_rows(std::integral_constant<int, 1>{});
-        store_rows(std::integral_constant<int, 2>{});
+    auto transform_piece = [&](auto piece) __attribute__((always_inline)) {
+        constexpr int P = decltype(piece)::value;
+        if constexpr (P < 3) {
+            bt6(gv[2 * P], gv[6 + 2 * P], gv[12 + 2 * P], gv[18 + 2 * P], gv[24 + 2 * P], gv[30 + 2 * P]);
+            bt6(gv[2 * P + 1], gv[7 + 2 * P], gv[13 + 2 * P], gv[19 + 2 * P], gv[25 + 2 * P], gv[31 + 2 * P]);
+        } else {
+            constexpr int I = P - 3;
+            bt6(gv[6 * I], gv[6 * I + 1], gv[6 * I + 2], gv[6 * I + 3], gv[6 * I + 4], gv[6 * I + 5]);
+        }
+    };
+    auto store_v = [&]() __attribute__((always_inline)) {                             // nine ds_write_b128: position group g = gv[4g .. 4g+3]
+#pragma unroll
+        for (int g = 0; g < NPG; ++g)
+            *reinterpret_cast<f32x4 *>(wr_v + g * V_PG) = f32x4{gv[4 * g], gv[4 * g + 1], gv[4 * g + 2], gv[4 * g + 3]};
+    };
+    auto transform_all = [&]() __attribute__((always_inline)) {
+        transform_piece(std::integral_constant<int, 0>{}); transform_piece(std::integral_constant<int, 1>{});
+        transform_piece(std::integral_constant<int, 2>{}); transform_piece(std::integral_constant<int, 3>{});
+        transform_piece(std::integral_constant<int, 4>{}); transform_piece(std::integral_constant<int, 5>{});
+        transform_piece(std::integral_constant<int, 6>{}); transform_piece(std::integral_constant<int, 7>{});
+        transform_piece(std::integral_constant<int, 8>{});
     };
 
     // ---- compute role
     const unsigned rd_u = (unsigned)((fq * CH + wc * 16 + fr) * 16);         // + position group * KC*CH*16
-    const unsigned rd_vt = (unsigned)((wt * 16 + fr) * (KV * 16));           // + ((k ^ fr) * 16) + position group * V_PG
+    const unsigned rd_vt = (unsigned)((wt * 16 + fr) * (KV * 16));           // + ((k ^ (tile >> 1)) * 16) + position group * V_PG
     f32x4 acc[36];
 #pragma unroll
     for (int q = 0; q < 36; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     load_v(0);
     load_u(0);
+    transform_all();
     store_v();
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): the DMA'd weights have landed
     __syncthreads();
-    for (int ks = 0; ks < nks; ++ks) {
-        if (ks + 1 < nks) load_v(ks + 1);              // lands under this slab's MFMAs
-#pragma unroll 1
-        for (int s = 0; s < 4; ++s) {
-            const int kt = 4 * ks + s;
-            if (kt >= nk) break;
-            if (kt + 1 < nk) load_u(kt + 1);           // its buffer was last read before the previous barrier
-            const char *cu = ubuf + (kt & 1) * U_BYTES + rd_u;
-            const char *cv = vbuf + rd_vt + (unsigned)((((4 * s + fq) ^ fr) & 15) * 16);
-            f32x4 fu[2], fv[2];
-            fu[0] = *reinterpret_cast<const f32x4 *>(cu);
-            fv[0] = *reinterpret_cast<const f32x4 *>(cv);
-#pragma unroll
-            for (int g = 0; g < NPG; ++g) {
-                if (g + 1 < NPG) {
-                    fu[(g + 1) & 1] = *reinterpret_cast<const f32x4 *>(cu + (g + 1) * (KC * CH * 16));
-                    fv[(g + 1) & 1] = *reinterpret_cast<const f32x4 *>(cv + (g + 1) * V_PG);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    acc[4 * g + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(fu[g & 1][e], fv[g & 1][e], acc[4 * g + e], 0, 0, 0);
+    // one sub-slab: 36 MFMAs per wave; WEAVE: transform piece g of the next slab's patch rides with MFMA group g
+    auto sub_slab = [&](int kt, int s, auto weave) __attribute__((always_inline)) {
+        if (kt + 1 < nk) load_u(kt + 1);               // its buffer was last read before the previous barrier
+        const char *cu = ubuf + (kt & 1) * U_BYTES + rd_u;
+        const char *cv = vbuf + rd_vt + (unsigned)((((4 * s + fq) ^ (fr >> 1)) & 7) * 16);
+        // fragment reads run one position group ahead of the MFMAs (two register sets)
+        f32x4 fu[2], fv[2];
+        fu[0] = *reinterpret_cast<const f32x4 *>(cu);
+        fv[0] = *reinterpret_cast<const f32x4 *>(cv);
+        auto group = [&](auto gi) __attribute__((always_inline)) {
+            constexpr int g = decltype(gi)::value;
+            if (g + 1 < NPG) {
+                fu[(g + 1) & 1] = *reinterpret_cast<const f32x4 *>(cu + (g + 1) * (KC * CH * 16));
+                fv[(g + 1) & 1] = *reinterpret_cast<const f32x4 *>(cv + (g + 1) * V_PG);
             }
-            __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): next sub-slab's DMA'd weights (and the patch) have landed
-            __syncthreads();
-        }
-        if (ks + 1 < nks) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc[4 * g + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(fu[g & 1][e], fv[g & 1][e], acc[4 * g + e], 0, 0, 0);
+            if constexpr (decltype(weave)::value) transform_piece(gi);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        group(std::integral_constant<int, 0>{}); group(std::integral_constant<int, 1>{}); group(std::integral_constant<int, 2>{});
+        group(std::integral_constant<int, 3>{}); group(std::integral_constant<int, 4>{}); group(std::integral_constant<int, 5>{});
+        group(std::integral_constant<int, 6>{}); group(std::integral_constant<int, 7>{}); group(std::integral_constant<int, 8>{});
+        __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): next sub-slab's DMA'd weights (and the patch) have landed
+        __syncthreads();
+    };
+    for (int ks = 0; ks < nks; ++ks) {
+        const bool more = ks + 1 < nks;                // a further slab follows (then this one is whole: two sub-slabs)
+        if (more) load_v(ks + 1);                      // lands under the first sub-slab's MFMAs
+        sub_slab(2 * ks, 0, std::false_type{});
+        if (2 * ks + 1 < nk) sub_slab(2 * ks + 1, 1, std::true_type{});      // (after the last slab the woven transform chews on stale registers)
+        if (more) {
             store_v();                                 // every wave is past its last read of the V slab
             __syncthreads();
         }
@@ -286,7 +303,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const W4Args p) {
 }
 
 // U = G g Gt in float64, rounded once; layout [Cin/4][9 position groups][4 k][CoutP][4] with the float4 = positions
-// 4g..4g+3 at channel k (CoutP = Cout rounded up to 64, zero rows): exactly the LDS slab, so a workgroup's share of a
+// 4g..4g+3 at channel k (CoutP = Cout rounded up to 32, zero rows): exactly the LDS slab, so a workgroup's share of a
 // slab is 36 contiguous runs of 64 float4.
 __global__ void wino4_weights_kernel(const float *w, int Cout, int Cin, int CoutP, float *u) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -316,7 +333,7 @@ int launch_w4(W4Args a, hipStream_t stream) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_wino4_kernel<ACT, RES>), dim3(a.nblk), dim3(512), LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((conv_wino4_kernel<ACT, RES>), dim3(a.nblk), dim3(256), LDS_BYTES, stream, a);
     return mydet_launch_status();
 }
 
@@ -324,13 +341,13 @@ int launch_w4(W4Args a, hipStream_t stream) {
 
 extern "C" int64_t mydet_wino4_weights_floats(int Cout, int Cin) {
     if (Cout <= 0 || Cin <= 0 || (Cin & 3)) return 0;
-    return (int64_t)36 * Cin * ((Cout + 63) / 64 * 64);
+    return (int64_t)36 * Cin * ((Cout + CH - 1) / CH * CH);
 }
 
 extern "C" int mydet_wino4_weights_f32(const float *w, int Cout, int Cin, float *u, void *stream) {
     if (!w || !u || Cout <= 0 || Cin <= 0) return MYDET_E_BADARG;
     if (Cin & 3) return MYDET_E_UNSUPP;
-    const int CoutP = (Cout + 63) / 64 * 64;
+    const int CoutP = (Cout + CH - 1) / CH * CH;
     const int64_t n = (int64_t)CoutP * Cin;
     hipLaunchKernelGGL(wino4_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin,
                        CoutP, u);
@@ -349,7 +366,7 @@ extern "C" int mydet_conv2d_wino4_f32(const float *x, int64_t ldx, const float *
     W4Args a;
     a.x = x; a.u = u; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
     a.ldx = ldx; a.ldr = residual ? ldr : ldy; a.ldy = ldy;
-    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.CoutP = (Cout + 63) / 64 * 64;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.CoutP = (Cout + CH - 1) / CH * CH;
     a.TH = (H + 3) / 4; a.TW = (W + 3) / 4;
     const int64_t MT = (int64_t)B * a.TH * a.TW;
     if (MT > (int64_t)1 << 30) return MYDET_E_UNSUPP;

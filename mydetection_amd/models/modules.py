@@ -50,12 +50,15 @@ def prepare_conv(owner, slot, conv, bn, depthwise=False):
 
 
 def prepare_wino(owner, slot, w_ohwi):
-    """Transform-domain copy of a prepared 3x3 OHWI weight (ops.wino_weights), or None when the fused Winograd
-    kernel does not cover the shape.  Cached on `owner` next to the weight it was made from."""
+    """Transform-domain copies of a prepared 3x3 OHWI weight: (ops.wino_weights, ops.wino4_weights), each None when
+    its fused Winograd kernel does not cover the shape (F(4x4) only from ops.WINO4_MIN_CIN input channels up).
+    Cached on `owner` next to the weight they were made from."""
     cache = owner.__dict__.setdefault('_prep_cache', {})
     hit = cache.get(slot)
     if hit is None or hit[0] is not w_ohwi:
-        hit = (w_ohwi, ops.wino_weights(w_ohwi) if ops.WINOGRAD else None)
+        u = ops.wino_weights(w_ohwi) if ops.WINOGRAD else None
+        u4 = ops.wino4_weights(w_ohwi) if ops.WINOGRAD and ops.WINOGRAD4 and w_ohwi.shape[3] >= ops.WINO4_MIN_CIN else None
+        hit = (w_ohwi, (u, u4))
         cache[slot] = hit
     return hit[1]
 
@@ -87,8 +90,8 @@ class ConvBnLeaky(nn.Module, FusedConvMixin):
         p = (self.k - 1) // 2
         if w.shape[3] == 3 and self.k == 3 and w.shape[0] == 32 and residual is None:
             return ops.conv2d_stem(x, w, scale, shift, self.s, (p, p, p, p), ops.ACT_LEAKY)
-        u = prepare_wino(self, 'wino', w) if self.k == 3 and self.s == 1 else None
-        return ops.conv2d(x, w, scale, shift, self.k, self.s, (p, p, p, p), ops.ACT_LEAKY, residual=residual, wino=u)
+        u, u4 = prepare_wino(self, 'wino', w) if self.k == 3 and self.s == 1 else (None, None)
+        return ops.conv2d(x, w, scale, shift, self.k, self.s, (p, p, p, p), ops.ACT_LEAKY, residual=residual, wino=u, wino4=u4)
 
 
 class DarkBlock(nn.Module):

@@ -130,9 +130,16 @@ def wino_weights(w_ohwi):
     return u
 
 
-# F(4x4,3x3) for the deep 3x3 layers (Cin >= WINO4_MIN_CIN); MYDET_CONV_WINO4=0 keeps them on F(2x2,3x3)
+# F(4x4,3x3) for the 3x3 layers with Cin >= WINO4_MIN_CIN whose grid fills the chip (>= WINO4_MIN_ITEMS workgroups of
+# 32 tiles x 32 channels; smaller grids stay on F(2x2,3x3), which cuts them along K); MYDET_CONV_WINO4=0 turns it off
 WINOGRAD4 = os.environ.get('MYDET_CONV_WINO4', '1') != '0'
-WINO4_MIN_CIN = int(os.environ.get('MYDET_WINO4_MIN_CIN', '128'))
+WINO4_MIN_CIN = int(os.environ.get('MYDET_WINO4_MIN_CIN', '64'))
+WINO4_MIN_ITEMS = int(os.environ.get('MYDET_WINO4_MIN_ITEMS', '768'))
+
+
+def wino4_items(B, H, W, Cout):
+    """Workgroups of the F(4x4,3x3) kernel for one layer: 32 tiles of 4x4 outputs x 32 output channels each."""
+    return -(-(B * -(-H // 4) * -(-W // 4)) // 32) * -(-Cout // 32)
 
 
 def wino4_weights(w_ohwi):
@@ -155,7 +162,8 @@ def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None
            wino4=None):
     """y = act(conv(x * gate)*scale + shift) + residual.  x logical [B,Cin,H,W]; pad=(top,left,bottom,right);
     gate: optional [B,Cin] per-image channel multipliers (squeeze-excite), 1x1 convs only;
-    wino: optional `wino_weights(w_ohwi)`: 3x3 stride-1 pad-1 layers then run the fused Winograd kernel."""
+    wino / wino4: optional `wino_weights(w_ohwi)` / `wino4_weights(w_ohwi)`: 3x3 stride-1 pad-1 layers then run a fused
+    Winograd kernel -- F(4x4,3x3) when given and the grid fills the chip (or no F(2x2,3x3) weights are given)."""
     require_gpu(x, 'conv2d')
     if x.shape[1] % 4:
         raise ValueError(f'conv2d: Cin = {x.shape[1]} is not a multiple of 4 (the implicit-GEMM kernel reads channels in '
@@ -175,7 +183,7 @@ def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None
         residual, ldr = to_nhwc(residual)
         assert residual.shape == out.shape
     if (wino4 is not None and WINOGRAD and WINOGRAD4 and gate is None and k == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1)
-            and ldy % 4 == 0 and ldr % 4 == 0):
+            and ldy % 4 == 0 and ldr % 4 == 0 and (wino is None or wino4_items(B, H, W, Cout) >= WINO4_MIN_ITEMS)):
         t0 = TIMER.start() if TIMER else None
         code = _lib.lib().mydet_conv2d_wino4_f32(_ptr(x), ldx, _ptr(wino4), _ptr(scale), _ptr(shift), _ptr(residual), ldr,
                                                  _ptr(out), ldy, B, H, W, Cin, Cout, act, _stream())
