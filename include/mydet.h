@@ -228,15 +228,20 @@ int mydet_postprocess_records_f32(const float *bbox, const int64_t *class_idx, c
                                   int B, int64_t N, float conf_thres, double nms_thres,
                                   int32_t *records, void *scratch, void *stream);
 
-/* Fused Winograd F(4x4,3x3) form of the same 3x3 stride-1 pad-1 conv + BN + act (+ residual) as mydet_conv2d_wino_f32
- * (4x fewer multiplies than the direct form; used for the deep layers).  `u` = the transform-domain weights made by
- * mydet_wino4_weights_f32 from the OHWI weight (mydet_wino4_weights_floats(Cout, Cin) floats; Cin % 4 == 0).
- * MYDET_E_UNSUPP (-2) for shapes it does not cover: the caller then uses mydet_conv2d_wino_f32 / _igemm_f32. */
+/* Winograd F(4x4,3x3) form of the same 3x3 stride-1 pad-1 conv + BN + act (+ residual) as mydet_conv2d_wino_f32
+ * (4x fewer multiplies than the direct form; used for the deep layers with chip-filling grids).  `u` = the
+ * transform-domain weights made by mydet_wino4_weights_f32 from the OHWI weight (mydet_wino4_weights_floats(Cout, Cin)
+ * floats; Cin % 4 == 0).  `ws` = device scratch of at least mydet_wino4_workspace_bytes(B, H, W, Cin) bytes
+ * (36 floats per 4x4-output tile and input channel: the transform-domain input, written by a first launch and
+ * streamed by the second); stream-ordered, so one buffer serves every layer of a stream.
+ * MYDET_E_UNSUPP (-2) for shapes it does not cover: the caller then uses mydet_conv2d_wino_f32 / _igemm_f32.
+ * Replaces the same reference code as mydet_conv2d_igemm_f32 (models/modules.py:69-73,94-95). */
 int64_t mydet_wino4_weights_floats(int Cout, int Cin);
 int mydet_wino4_weights_f32(const float *w, int Cout, int Cin, float *u, void *stream);
+int64_t mydet_wino4_workspace_bytes(int B, int H, int W, int Cin);
 int mydet_conv2d_wino4_f32(const float *x, int64_t ldx, const float *u, const float *scale, const float *shift,
-                           const float *residual, int64_t ldr, float *y, int64_t ldy, int B, int H, int W, int Cin,
-                           int Cout, int act, void *stream);
+                           const float *residual, int64_t ldr, float *ws, int64_t ws_bytes, float *y, int64_t ldy,
+                           int B, int H, int W, int Cin, int Cout, int act, void *stream);
 
 /* Bilinear resize of one 8-bit RGB image [H][W][3] -> [oh][ow][3] (rows src_row_bytes / dst_row_bytes apart, so the
  * result can land inside a padded batch buffer), bit-exact with PIL.Image.resize(size, BILINEAR), i.e. with the

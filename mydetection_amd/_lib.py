@@ -22,7 +22,8 @@ SIGNATURES = {
     + [c_ptr],
     'mydet_wino4_weights_floats': [c_int, c_int],
     'mydet_wino4_weights_f32': [c_ptr, c_int, c_int, c_ptr, c_ptr],
-    'mydet_conv2d_wino4_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64] + [c_int] * 6 + [c_ptr],
+    'mydet_wino4_workspace_bytes': [c_int, c_int, c_int, c_int],
+    'mydet_conv2d_wino4_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64] + [c_int] * 6 + [c_ptr],
     'mydet_dwconv_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64] + [c_int] * 11 + [c_ptr, c_int, c_ptr],
     'mydet_channel_sums_f32': [c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr, c_int, c_ptr],
     'mydet_se_gate_f32': [c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
@@ -52,7 +53,7 @@ SIGNATURES = {
 
 
 
-RETURNS_I64 = {'mydet_wino_weights_floats', 'mydet_wino4_weights_floats'}
+RETURNS_I64 = {'mydet_wino_weights_floats', 'mydet_wino4_weights_floats', 'mydet_wino4_workspace_bytes'}
 
 # detection record layout (MYDET_REC_* of include/mydet.h), in int32 words
 REC_TOPK = 512

@@ -1,7 +1,5 @@
-// 3x3 stride-1 pad-1 convolution by Winograd F(4x4,3x3) on the gfx950 FP32 matrix cores, fully fused (input transform
-// while staging, 36 transform-domain GEMMs on v_mfma_f32_16x16x4_f32, output transform + BN / activation / residual in
-// the epilogue): 4x fewer multiplies than the direct form (F(2x2,3x3) of conv_wino.hip: 2.25x), no transformed tensor
-// in HBM.  Used for the deep layers, where the matrix pipe is the bound.
+// 3x3 stride-1 pad-1 convolution by Winograd F(4x4,3x3) on the gfx950 FP32 matrix cores: 4x fewer multiplies than the
+// direct form (F(2x2,3x3) of conv_wino.hip: 2.25x).  Used for the deep layers, where the matrix pipe is the bound.
 //
 //   tile  = 4x4 output pixels (6x6 input patch d, origin (4ty-1, 4tx-1), zero outside the image)
 //   V     = Bt d B      Bt = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
@@ -12,23 +10,22 @@
 // float32 throughout; against float64 the error is ~3e-6 rms of O(1) outputs (the direct form: 2e-7; tests/
 // test_winograd_algebra.py), i.e. 30x inside the 1e-4 the detections are held to.
 //
-// A workgroup of 4 waves owns 32 output channels x 32 tiles; wave (wc, wt) owns channels 16wc.. x tiles 16wt.. for all
-// 36 positions (36 x 4 = 144 accumulator registers).  Two workgroups per CU (72 KB of LDS each, one wave of each per
-// SIMD): they drift apart, so one's barriers, prologue and epilogue run under the other's MFMAs.
-// K = Cin is walked in V slabs of 8 channels, each consumed as two U sub-slabs of 4 channels (one MFMA k-step):
-//   V slab (36 KB, one buffer): every thread stages one (tile, channel): 36 dword buffer loads of the 6x6 patch (a wave
-//           covers 8 tiles x 8 channels: one 32-byte run per pixel), issued at the top of the slab and landing under its
-//           72 MFMAs per wave; after the slab's last MFMA: Bt d B in registers (~150 VALU), nine ds_write_b128.
-//           Out-of-image pixels: voffset 0xFFFFFFFF (hardware range check returns 0); row, column and K advance ride in
-//           the scalar offset.  Layout [position group of 4][tile][k ^ (tile >> 1 & 7)] float4 = positions 4g..4g+3: the
-//           XOR makes both the staging stores (8 channels of 8 tiles) and the fragment reads (16 tiles at one k)
-//           bank-conflict free.
-//   U sub-slab (18 KB, two buffers): the transformed weights are stored in MFMA fragment order in memory
-//           ([k/4][position group][k%4][channel] float4), and the waves copy sub-slab kt+1 global -> LDS with the DMA path
-//           (buffer_load ... lds: no registers, no VALU) under the MFMAs of sub-slab kt.
-// One ds_read_b128 per operand feeds four MFMAs (36 MFMAs : 18 LDS reads per wave and k-step).
-// Output channels are MFMA rows, so a lane ends up with 4 consecutive channels of a tile: after At M A, sixteen
-// 16-byte stores; the residual loads of a lane are all in flight before its first store.
+// Two launches per layer:
+//  1. wino4_input_kernel: V = Bt d B once per (tile, input channel), written to a workspace in MFMA-fragment order
+//     [tile block of 32][k/4][position group of 4][k%4][tile] float4 = positions 4g..4g+3.  An HBM-bound pass (x read once
+//     through L2, 2.25x its size written).  Fusing it into the GEMM kernel was measured and lost: the 36 dword loads per
+//     (tile, channel) run the texture-address unit at 4 lanes/clock -- 100 % busy at two workgroups per CU, repeated by
+//     every output-channel block -- and the ~150 transform VALU per thread issue beside the MFMAs at full price
+//     (profiles/r02_wino4_notes.md).
+//  2. conv_wino4_kernel: a workgroup of 4 waves owns 32 output channels x 32 tiles; wave (wc, wt) owns channels 16wc.. x
+//     tiles 16wt.. for all 36 positions (36 x 4 = 144 accumulator registers).  Two workgroups per CU (72 KB of LDS each,
+//     one wave of each per SIMD).  K = Cin is walked 4 channels (one MFMA k-step) per stage through two LDS stages; both
+//     operands of stage kt+1 -- 18 KB of V and 18 KB of U, each contiguous in memory in exactly the LDS order -- are
+//     copied global -> LDS with the DMA path (buffer_load ... lds: no registers, no VALU) under the 36 MFMAs per wave of
+//     stage kt; ONE barrier per stage.  One ds_read_b128 per operand feeds four MFMAs.  The loop body is DMA issue,
+//     18 LDS reads and 36 MFMAs -- no VALU.
+//     Output channels are MFMA rows, so a lane ends up with 4 consecutive channels of a tile: after At M A, sixteen
+//     16-byte stores; the residual loads of a row are in flight before its first store.
 // Replaces the same ATen chain as conv_wino.hip (models/modules.py:69-73,94-95).
 #include <cstdlib>
 #include <type_traits>
@@ -38,15 +35,15 @@
 namespace {
 
 constexpr unsigned OOB = 0xFFFFFFFFu;
-constexpr int CH = 32, TILES = 32, KC = 4, KV = 8, NPG = 9;
-constexpr int U_BYTES = NPG * KC * CH * 16;            // 18 432: one 4-channel sub-slab of U
-constexpr int V_PG = TILES * KV * 16;                  // 4 096: bytes between position groups of V
-constexpr int V_BYTES = NPG * V_PG;                    // 36 864: one 8-channel slab of V
-constexpr int LDS_BYTES = V_BYTES + 2 * U_BYTES;       // 73 728: two workgroups per CU
+constexpr int CH = 32, TILES = 32, KC = 4, NPG = 9;
+constexpr int U_BYTES = NPG * KC * CH * 16;            // 18 432: one 4-channel stage of U
+constexpr int V_BYTES = NPG * KC * TILES * 16;         // 18 432: one 4-channel stage of V
+constexpr int STAGE = U_BYTES + V_BYTES;               // 36 864
+constexpr int LDS_BYTES = 2 * STAGE;                   // 73 728: two workgroups per CU
 
 struct W4Args {
     const float *x, *u, *scale, *shift, *res;
-    float *y;
+    float *y, *v;                                      // v: transform-domain input (workspace)
     int64_t ldx, ldr, ldy;
     int B, H, W, Cin, Cout, CoutP;
     int TH, TW, MT, ntn, nblk;
@@ -85,165 +82,130 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const float *base, int64_
         o[5] = fmaf(4.0f, x1, fmaf(-5.0f, x3, x5));       \
     }
 
-// row I of Bt applied to a column (x0..x5)
-template <int I>
-__device__ __forceinline__ float w4_bt_row(float x0, float x1, float x2, float x3, float x4, float x5) {
-    if constexpr (I == 0) return fmaf(4.0f, x0, fmaf(-5.0f, x2, x4));
-    if constexpr (I == 1) return (x3 + x4) - 4.0f * (x1 + x2);
-    if constexpr (I == 2) return (x4 - x3) + 4.0f * (x1 - x2);
-    if constexpr (I == 3) return (x4 - x2) + 2.0f * (x3 - x1);
-    if constexpr (I == 4) return (x4 - x2) - 2.0f * (x3 - x1);
-    return fmaf(4.0f, x1, fmaf(-5.0f, x3, x5));
-}
 
-template <int ACT, bool RES>
-__global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const W4Args p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *const vbuf = smem, *const ubuf = smem + V_BYTES;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int item = mydet_xcd_remap(blockIdx.x, p.nblk);
-    const int tpi = p.TH * p.TW;
-    const int nk = p.Cin >> 2, nks = (p.Cin + KV - 1) / KV;       // Cin % 4 == 0; the last V slab may be partial
-    const int m0 = (item / p.ntn) * TILES, n0 = (item % p.ntn) * CH;
-    const int b0 = m0 / tpi;
-    const int wc = wave & 1, wt = wave >> 1;
-    const int fr = lane & 15, fq = lane >> 4;
-
-    // ---- staging role: (tile st, channel sc of the 8-channel slab)
-    const int sc = tid & 7, st = tid >> 3;
+// ---- 1. input transform.  Workgroup = 32 tiles (one tile block) x 8 input channels (two k-quads); thread = (tile,
+// channel): a wave covers 8 tiles x 8 channels, so a patch load touches 8 runs of 32 bytes and a store of one position
+// group writes 8 whole 128-byte lines (8 tiles x float4, per (k-quad, k)).
+__global__ __launch_bounds__(256) void wino4_input_kernel(const W4Args p) {
+    const int tid = threadIdx.x;
+    const int sc = tid & 7, st = ((tid >> 6) << 3) | ((tid >> 3) & 7);       // channel of the 8, tile of the 32
+    const int mb = blockIdx.x, c = blockIdx.y * 8 + sc;
+    const int tpi = p.TH * p.TW, nk = p.Cin >> 2;
+    const int mt = mb * TILES + st;
+    const int b0 = (mb * TILES) / tpi;
     const int64_t img = (int64_t)p.H * p.W * p.ldx;
     // the buffer starts one row + one pixel BEFORE image b0, so that the patch origin (-1, -1) of its first tile is offset 0:
     // the range check sees the voffset only, and a negative one would read as out of range (those addresses are never
     // touched: row -1 and column -1 are masked to OOB below)
     const int64_t lead = (int64_t)(p.W + 1) * p.ldx;
     const __amdgpu_buffer_rsrc_t xr = rsrc(p.x + b0 * img - lead, ((p.B - b0) * img + lead) * 4);
-    // patch pixel (i, j): voffset = the patch origin (or OOB when the pixel is outside the image / the tile past the end);
-    // i * row pitch + j * pixel pitch + slab * 64 bytes ride in the scalar offset
-    unsigned vbase;
-    bool rowok[6], colok[6];
-    {
-        const int mt = m0 + st;
-        const int mm = mt < p.MT ? mt : p.MT - 1;
-        const int b = mm / tpi, r = mm - b * tpi, ty = r / p.TW, tx = r - ty * p.TW;
-        const int iy0 = 4 * ty - 1, ix0 = 4 * tx - 1;
-        vbase = (unsigned)((((((int64_t)(b - b0) * p.H + iy0) * p.W + ix0) * p.ldx + sc) + lead) * 4);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            rowok[i] = mt < p.MT && (unsigned)(iy0 + i) < (unsigned)p.H;
-            colok[i] = (unsigned)(ix0 + i) < (unsigned)p.W;
-        }
-    }
+    const int mm = mt < p.MT ? mt : p.MT - 1;
+    const int b = mm / tpi, r = mm - b * tpi, ty = r / p.TW, tx = r - ty * p.TW;
+    const int iy0 = 4 * ty - 1, ix0 = 4 * tx - 1;
+    const unsigned vbase = mt < p.MT && c < p.Cin
+                               ? (unsigned)((((((int64_t)(b - b0) * p.H + iy0) * p.W + ix0) * p.ldx + c) + lead) * 4)
+                               : OOB;                  // tiles past the end and channels past Cin transform zeros
     const unsigned colstep = (unsigned)(p.ldx * 4), rowstep = (unsigned)(p.W * p.ldx * 4);
-    // U: run r = (position group, k) of a sub-slab is 64 consecutive float4 in memory (layout of wino4_weights_kernel);
-    // a DMA instruction copies two runs (32 lanes each); wave w copies run pairs w, w + 4, ...
-    const __amdgpu_buffer_rsrc_t ur = rsrc(p.u, (int64_t)p.Cin * 36 * p.CoutP * 4);
-    const unsigned urun = (unsigned)p.CoutP * 16u;     // bytes between runs
-    const unsigned uoff = (unsigned)((n0 + (lane & 31)) * 16) + (lane >> 5) * urun;
-    char *const wr_v = vbuf + st * (KV * 16) + ((sc ^ ((st >> 1) & 7)) * 16);      // + position group * V_PG
-
     float gv[36];
-    auto load_v = [&](int ks) __attribute__((always_inline)) {                        // raw patch of slab ks -> registers
-        const unsigned sv = (unsigned)ks * (KV * 4);
-        const unsigned vb = KV * ks + sc < p.Cin ? vbase : OOB;              // channels past Cin (partial last slab): 0
 #pragma unroll
-        for (int q = 0; q < 36; ++q)
-            gv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                  xr, rowok[q / 6] && colok[q % 6] ? vb : OOB,
-                                                  __builtin_amdgcn_readfirstlane(sv + (unsigned)(q / 6) * rowstep + (unsigned)(q % 6) * colstep), 0));
-    };
-    auto load_u = [&](int kt) __attribute__((always_inline)) {                        // sub-slab kt -> ubuf[kt & 1], DMA
-        const unsigned su = (unsigned)kt * 36u * urun;
-        char *dst = ubuf + (kt & 1) * U_BYTES;
+    for (int q = 0; q < 36; ++q) {
+        const bool ok = (unsigned)(iy0 + q / 6) < (unsigned)p.H && (unsigned)(ix0 + q % 6) < (unsigned)p.W;
+        gv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                              xr, ok ? vbase : OOB,
+                                              __builtin_amdgcn_readfirstlane((unsigned)(q / 6) * rowstep + (unsigned)(q % 6) * colstep), 0));
+    }
+    // V = Bt d B in place: the column pass (Bt d), then the row pass; position p = 6i + j ends up in gv[p]
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {
+        float o[6];
+        W4_BT(o, gv[m], gv[6 + m], gv[12 + m], gv[18 + m], gv[24 + m], gv[30 + m])
+#pragma unroll
+        for (int i = 0; i < 6; ++i) gv[6 * i + m] = o[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float o[6];
+        W4_BT(o, gv[6 * i], gv[6 * i + 1], gv[6 * i + 2], gv[6 * i + 3], gv[6 * i + 4], gv[6 * i + 5])
+#pragma unroll
+        for (int m = 0; m < 6; ++m) gv[6 * i + m] = o[m];
+    }
+    if (c < p.Cin) {                                   // Cin % 4 == 0: a k-quad is written whole or not at all
+        f32x4 *dst = reinterpret_cast<f32x4 *>(p.v) + (((int64_t)mb * nk + (c >> 2)) * NPG * KC + (c & 3)) * TILES + st;
+#pragma unroll
+        for (int g = 0; g < NPG; ++g) dst[g * KC * TILES] = f32x4{gv[4 * g], gv[4 * g + 1], gv[4 * g + 2], gv[4 * g + 3]};
+    }
+}
+
+// ---- 2. transform-domain GEMMs + output transform + epilogue
+template <int ACT, bool RES>
+__global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const W4Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int item = mydet_xcd_remap(blockIdx.x, p.nblk);
+    const int tpi = p.TH * p.TW;
+    const int nk = p.Cin >> 2;
+    const int mb = item / p.ntn;
+    const int m0 = mb * TILES, n0 = (item % p.ntn) * CH;
+    const int b0 = m0 / tpi;
+    const int wc = wave & 1, wt = wave >> 1;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    // stage = [U: 9 position groups x 4 k x 32 channels float4 | V: 9 x 4 x 32 tiles float4]; both arrive by DMA in 1 KB
+    // pieces (one per wave instruction), wave w copies pieces w, w + 4, ... of each operand.
+    //   U: piece = two runs of 32 float4 (the block's channels) 16*CoutP bytes apart (layout of wino4_weights_kernel)
+    //   V: the stage is one contiguous 18 KB run of the workspace
+    const __amdgpu_buffer_rsrc_t ur = rsrc(p.u, (int64_t)p.Cin * 36 * p.CoutP * 4);
+    const unsigned urun = (unsigned)p.CoutP * 16u;
+    const unsigned uoff = (unsigned)((n0 + (lane & 31)) * 16) + (lane >> 5) * urun;
+    const __amdgpu_buffer_rsrc_t vr = rsrc(p.v + (int64_t)mb * nk * (V_BYTES / 4), (int64_t)nk * V_BYTES);
+    const unsigned voff = (unsigned)(lane * 16);
+    auto load_stage = [&](int kt) __attribute__((always_inline)) {
+        char *dst = smem + (kt & 1) * STAGE;
+        const unsigned su = (unsigned)kt * 36u * urun, sv = (unsigned)kt * V_BYTES;
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            const int r = wave + 4 * j;                // run pair
-            if (r < 18)
+            const int r = wave + 4 * j;
+            if (r < 18) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (__attribute__((address_space(3))) void *)(dst + r * 1024), 16, uoff,
                                                          __builtin_amdgcn_readfirstlane(su + (unsigned)(2 * r) * urun), 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(vr, (__attribute__((address_space(3))) void *)(dst + U_BYTES + r * 1024), 16, voff,
+                                                         __builtin_amdgcn_readfirstlane(sv + (unsigned)r * 1024u), 0, 0);
+            }
         }
-    };
-    // V = Bt d B in place on gv (position p = 6i + j ends up in gv[p]), cut into nine pieces that ride between the MFMA
-    // groups of the slab's last sub-slab: pieces 0-2 = the column pass (Bt d, two patch columns each), pieces 3-8 = the
-    // row pass (one row of (Bt d) B each)
-    auto bt6 = [&](float &x0, float &x1, float &x2, float &x3, float &x4, float &x5) __attribute__((always_inline)) {
-        float o[6];
-        W4_BT(o, x0, x1, x2, x3, x4, x5)
-        x0 = o[0]; x1 = o[1]; x2 = o[2]; x3 = o[3]; x4 = o[4]; x5 = o[5];
-    };
-    auto transform_piece = [&](auto piece) __attribute__((always_inline)) {
-        constexpr int P = decltype(piece)::value;
-        if constexpr (P < 3) {
-            bt6(gv[2 * P], gv[6 + 2 * P], gv[12 + 2 * P], gv[18 + 2 * P], gv[24 + 2 * P], gv[30 + 2 * P]);
-            bt6(gv[2 * P + 1], gv[7 + 2 * P], gv[13 + 2 * P], gv[19 + 2 * P], gv[25 + 2 * P], gv[31 + 2 * P]);
-        } else {
-            constexpr int I = P - 3;
-            bt6(gv[6 * I], gv[6 * I + 1], gv[6 * I + 2], gv[6 * I + 3], gv[6 * I + 4], gv[6 * I + 5]);
-        }
-    };
-    auto store_v = [&]() __attribute__((always_inline)) {                             // nine ds_write_b128: position group g = gv[4g .. 4g+3]
-#pragma unroll
-        for (int g = 0; g < NPG; ++g)
-            *reinterpret_cast<f32x4 *>(wr_v + g * V_PG) = f32x4{gv[4 * g], gv[4 * g + 1], gv[4 * g + 2], gv[4 * g + 3]};
-    };
-    auto transform_all = [&]() __attribute__((always_inline)) {
-        transform_piece(std::integral_constant<int, 0>{}); transform_piece(std::integral_constant<int, 1>{});
-        transform_piece(std::integral_constant<int, 2>{}); transform_piece(std::integral_constant<int, 3>{});
-        transform_piece(std::integral_constant<int, 4>{}); transform_piece(std::integral_constant<int, 5>{});
-        transform_piece(std::integral_constant<int, 6>{}); transform_piece(std::integral_constant<int, 7>{});
-        transform_piece(std::integral_constant<int, 8>{});
     };
 
-    // ---- compute role
-    const unsigned rd_u = (unsigned)((fq * CH + wc * 16 + fr) * 16);         // + position group * KC*CH*16
-    const unsigned rd_vt = (unsigned)((wt * 16 + fr) * (KV * 16));           // + ((k ^ (tile >> 1)) * 16) + position group * V_PG
+    const unsigned rd_u = (unsigned)((fq * CH + wc * 16 + fr) * 16);                     // + position group * KC*CH*16
+    const unsigned rd_v = (unsigned)(U_BYTES + (fq * TILES + wt * 16 + fr) * 16);         // + position group * KC*TILES*16
     f32x4 acc[36];
 #pragma unroll
     for (int q = 0; q < 36; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    load_v(0);
-    load_u(0);
-    transform_all();
-    store_v();
-    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): the DMA'd weights have landed
+    load_stage(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): the DMA'd stage has landed
     __syncthreads();
-    // one sub-slab: 36 MFMAs per wave; WEAVE: transform piece g of the next slab's patch rides with MFMA group g
-    auto sub_slab = [&](int kt, int s, auto weave) __attribute__((always_inline)) {
-        if (kt + 1 < nk) load_u(kt + 1);               // its buffer was last read before the previous barrier
-        const char *cu = ubuf + (kt & 1) * U_BYTES + rd_u;
-        const char *cv = vbuf + rd_vt + (unsigned)((((4 * s + fq) ^ (fr >> 1)) & 7) * 16);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_stage(kt + 1);           // its buffer was last read before the previous barrier
+        const char *cu = smem + (kt & 1) * STAGE + rd_u;
+        const char *cv = smem + (kt & 1) * STAGE + rd_v;
         // fragment reads run one position group ahead of the MFMAs (two register sets)
         f32x4 fu[2], fv[2];
         fu[0] = *reinterpret_cast<const f32x4 *>(cu);
         fv[0] = *reinterpret_cast<const f32x4 *>(cv);
-        auto group = [&](auto gi) __attribute__((always_inline)) {
-            constexpr int g = decltype(gi)::value;
+#pragma unroll
+        for (int g = 0; g < NPG; ++g) {
             if (g + 1 < NPG) {
                 fu[(g + 1) & 1] = *reinterpret_cast<const f32x4 *>(cu + (g + 1) * (KC * CH * 16));
-                fv[(g + 1) & 1] = *reinterpret_cast<const f32x4 *>(cv + (g + 1) * V_PG);
+                fv[(g + 1) & 1] = *reinterpret_cast<const f32x4 *>(cv + (g + 1) * (KC * TILES * 16));
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 acc[4 * g + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(fu[g & 1][e], fv[g & 1][e], acc[4 * g + e], 0, 0, 0);
-            if constexpr (decltype(weave)::value) transform_piece(gi);
             __builtin_amdgcn_sched_barrier(0);
-        };
-        group(std::integral_constant<int, 0>{}); group(std::integral_constant<int, 1>{}); group(std::integral_constant<int, 2>{});
-        group(std::integral_constant<int, 3>{}); group(std::integral_constant<int, 4>{}); group(std::integral_constant<int, 5>{});
-        group(std::integral_constant<int, 6>{}); group(std::integral_constant<int, 7>{}); group(std::integral_constant<int, 8>{});
-        __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): next sub-slab's DMA'd weights (and the patch) have landed
-        __syncthreads();
-    };
-    for (int ks = 0; ks < nks; ++ks) {
-        const bool more = ks + 1 < nks;                // a further slab follows (then this one is whole: two sub-slabs)
-        if (more) load_v(ks + 1);                      // lands under the first sub-slab's MFMAs
-        sub_slab(2 * ks, 0, std::false_type{});
-        if (2 * ks + 1 < nk) sub_slab(2 * ks + 1, 1, std::true_type{});      // (after the last slab the woven transform chews on stale registers)
-        if (more) {
-            store_v();                                 // every wave is past its last read of the V slab
-            __syncthreads();
         }
+        __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): the next stage has landed
+        __syncthreads();
     }
 
     // ---- epilogue: lane = tile m0 + 16wt + fr, components = channels n0 + 16wc + 4fq + (0..3)
@@ -333,6 +295,7 @@ int launch_w4(W4Args a, hipStream_t stream) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
+    hipLaunchKernelGGL(wino4_input_kernel, dim3((a.MT + TILES - 1) / TILES, (a.Cin + 7) / 8), dim3(256), 0, stream, a);
     hipLaunchKernelGGL((conv_wino4_kernel<ACT, RES>), dim3(a.nblk), dim3(256), LDS_BYTES, stream, a);
     return mydet_launch_status();
 }
@@ -354,29 +317,37 @@ extern "C" int mydet_wino4_weights_f32(const float *w, int Cout, int Cin, float 
     return mydet_launch_status();
 }
 
+extern "C" int64_t mydet_wino4_workspace_bytes(int B, int H, int W, int Cin) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3)) return 0;
+    const int64_t MT = (int64_t)B * ((H + 3) / 4) * ((W + 3) / 4);
+    return (MT + TILES - 1) / TILES * (Cin >> 2) * V_BYTES;
+}
+
 extern "C" int mydet_conv2d_wino4_f32(const float *x, int64_t ldx, const float *u, const float *scale, const float *shift,
-                                      const float *residual, int64_t ldr, float *y, int64_t ldy, int B, int H, int W,
-                                      int Cin, int Cout, int act, void *stream) {
-    if (!x || !u || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || act < 0 || act > 2) return MYDET_E_BADARG;
+                                      const float *residual, int64_t ldr, float *ws, int64_t ws_bytes, float *y, int64_t ldy,
+                                      int B, int H, int W, int Cin, int Cout, int act, void *stream) {
+    if (!x || !u || !y || !ws || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || act < 0 || act > 2) return MYDET_E_BADARG;
     if ((ldx & 3) || ldx < Cin || ldy < Cout || (residual && ldr < Cout)) return MYDET_E_BADARG;
-    if (((uintptr_t)x & 15) || ((uintptr_t)u & 15) || ((uintptr_t)y & 15) || (residual && ((uintptr_t)residual & 15)) ||
-        (scale && ((uintptr_t)scale & 15)) || (shift && ((uintptr_t)shift & 15)))
+    if (((uintptr_t)x & 15) || ((uintptr_t)u & 15) || ((uintptr_t)y & 15) || ((uintptr_t)ws & 15) ||
+        (residual && ((uintptr_t)residual & 15)) || (scale && ((uintptr_t)scale & 15)) || (shift && ((uintptr_t)shift & 15)))
         return MYDET_E_BADARG;
     if ((Cin & 3) || (Cout & 3) || (ldy & 3) || (residual && (ldr & 3))) return MYDET_E_UNSUPP;
+    if (ws_bytes < mydet_wino4_workspace_bytes(B, H, W, Cin)) return MYDET_E_BADARG;
     W4Args a;
-    a.x = x; a.u = u; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+    a.x = x; a.u = u; a.scale = scale; a.shift = shift; a.res = residual; a.y = y; a.v = ws;
     a.ldx = ldx; a.ldr = residual ? ldr : ldy; a.ldy = ldy;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.CoutP = (Cout + CH - 1) / CH * CH;
     a.TH = (H + 3) / 4; a.TW = (W + 3) / 4;
     const int64_t MT = (int64_t)B * a.TH * a.TW;
     if (MT > (int64_t)1 << 30) return MYDET_E_UNSUPP;
-    // 32-bit byte offsets inside a workgroup's window: the images its 32 tiles touch
+    // 32-bit byte offsets inside a workgroup's window: the images its 32 tiles touch, its stages of V, all of U
     const int64_t span = TILES / ((int64_t)a.TH * a.TW) + 2;
     const int64_t ldmax = ldx > ldy ? (ldx > a.ldr ? ldx : a.ldr) : (ldy > a.ldr ? ldy : a.ldr);
     if ((int64_t)H * W * ldmax * 4 * span >= 0x7FFFFFF0ll || (int64_t)36 * Cin * a.CoutP * 4 >= 0x7FFFFFF0ll) return MYDET_E_UNSUPP;
     a.MT = (int)MT;
     a.ntn = a.CoutP / CH;
     a.nblk = (int)((MT + TILES - 1) / TILES) * a.ntn;
+    if ((MT + TILES - 1) / TILES > 0x7FFFFFFF || (Cin + 7) / 8 > 65535) return MYDET_E_UNSUPP;
     hipStream_t s = (hipStream_t)stream;
     const bool res = residual != nullptr;
     switch (act) {

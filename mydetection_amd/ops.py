@@ -106,6 +106,21 @@ def conv_workspace(device):
     return _WORKSPACE[key]
 
 
+_WINO4_WS = {}
+
+
+def wino4_workspace(device, nbytes):
+    """Per-device scratch for the transform-domain input of the F(4x4,3x3) kernel: grows to the largest layer seen
+    (stream-ordered reuse; one stream per process).  A hipGraph must be captured after an eager pass has sized it."""
+    key = (device.type, device.index)
+    ws = _WINO4_WS.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('wino4_workspace: the workspace would grow during stream capture; run the model once eagerly first')
+        ws = _WINO4_WS[key] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+    return ws
+
+
 def conv_out_size(n, k, stride, pad_lo, pad_hi):
     return (n + pad_lo + pad_hi - k) // stride + 1
 
@@ -184,9 +199,10 @@ def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None
         assert residual.shape == out.shape
     if (wino4 is not None and WINOGRAD and WINOGRAD4 and gate is None and k == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1)
             and ldy % 4 == 0 and ldr % 4 == 0 and (wino is None or wino4_items(B, H, W, Cout) >= WINO4_MIN_ITEMS)):
+        ws = wino4_workspace(x.device, _lib.lib().mydet_wino4_workspace_bytes(B, H, W, Cin))
         t0 = TIMER.start() if TIMER else None
         code = _lib.lib().mydet_conv2d_wino4_f32(_ptr(x), ldx, _ptr(wino4), _ptr(scale), _ptr(shift), _ptr(residual), ldr,
-                                                 _ptr(out), ldy, B, H, W, Cin, Cout, act, _stream())
+                                                 _ptr(ws), ws.numel() * 4, _ptr(out), ldy, B, H, W, Cin, Cout, act, _stream())
         if t0:      # priced with the direct form's flops: the algorithmic work of the layer
             name = f'conv_wino4 {Cin}->{Cout} k3s1 {H}x{W}' if TIMER_DETAIL else 'conv_wino4'
             TIMER.stop(name, t0, 2.0 * B * Ho * Wo * Cout * 9 * Cin,
