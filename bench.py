@@ -296,9 +296,11 @@ def main():
 
     if args.config == 'yolov3_80':
         # Dominant kernel = the conv family with the most time per step, priced with the ALGORITHMIC flops of its layers
-        # (2*MACs of the direct form).  The Winograd kernel issues 2.25x fewer multiplies than that.
+        # (2*MACs of the direct form).  The Winograd kernels issue 2.25x (F(2x2)) / 4x (F(4x4)) fewer multiplies than that.
         kernels = {'conv_igemm': ('conv_igemm_kernel (implicit GEMM, v_mfma_f32_32x32x2_f32)', 1.0),
-                   'conv_wino': ('conv_wino_kernel (fused Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32)', 2.25)}
+                   'conv_wino': ('conv_wino_kernel (fused Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32)', 2.25),
+                   'conv_wino4': ('wino4_input_kernel + conv_wino4_kernel (Winograd F(4x4,3x3): input-transform launch + DMA-fed '
+                                  'v_mfma_f32_16x16x4_f32 GEMMs with fused output transform; timed as one unit)', 4.0)}
         fams = {k: summ[k] for k in kernels if k in summ}
         dom = max(fams, key=lambda k: fams[k][1])
         n_k, ms_k, flops_k = fams[dom]

@@ -35,11 +35,14 @@
 namespace {
 
 constexpr unsigned OOB = 0xFFFFFFFFu;
-constexpr int CH = 32, TILES = 32, KC = 4, NPG = 9;
+constexpr int NW = 4;                                  // waves per workgroup of the GEMM kernel
+constexpr int CH = 8 * NW, TILES = 32, KC = 4, NPG = 9; // output channels / tiles per workgroup, k per stage, position groups
 constexpr int U_BYTES = NPG * KC * CH * 16;            // 18 432: one 4-channel stage of U
+constexpr int UP = U_BYTES / 1024;                     // its 1 KB pieces
 constexpr int V_BYTES = NPG * KC * TILES * 16;         // 18 432: one 4-channel stage of V
 constexpr int STAGE = U_BYTES + V_BYTES;               // 36 864
 constexpr int LDS_BYTES = 2 * STAGE;                   // 73 728: two workgroups per CU
+constexpr int COUT_PAD = 64;                           // U rows are padded to this many output channels
 
 struct W4Args {
     const float *x, *u, *scale, *shift, *res;
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const W4Args p) {
 
 // ---- 2. transform-domain GEMMs + output transform + epilogue
 template <int ACT, bool RES>
-__global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const W4Args p) {
+__global__ __launch_bounds__(64 * NW, 2) void conv_wino4_kernel(const W4Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const W4Args p) {
     const int mb = item / p.ntn;
     const int m0 = mb * TILES, n0 = (item % p.ntn) * CH;
     const int b0 = m0 / tpi;
-    const int wc = wave & 1, wt = wave >> 1;
+    const int wc = wave % (NW / 2), wt = wave / (NW / 2);
     const int fr = lane & 15, fq = lane >> 4;
 
     // stage = [U: 9 position groups x 4 k x 32 channels float4 | V: 9 x 4 x 32 tiles float4]; both arrive by DMA in 1 KB
@@ -164,14 +167,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const W4Args p) {
         char *dst = smem + (kt & 1) * STAGE;
         const unsigned su = (unsigned)kt * 36u * urun, sv = (unsigned)kt * V_BYTES;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int r = wave + 4 * j;
-            if (r < 18) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (__attribute__((address_space(3))) void *)(dst + r * 1024), 16, uoff,
-                                                         __builtin_amdgcn_readfirstlane(su + (unsigned)(2 * r) * urun), 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(vr, (__attribute__((address_space(3))) void *)(dst + U_BYTES + r * 1024), 16, voff,
-                                                         __builtin_amdgcn_readfirstlane(sv + (unsigned)r * 1024u), 0, 0);
-            }
+        for (int j = 0; j < (UP + 18 + NW - 1) / NW; ++j) {
+            const int i = wave + NW * j;               // index in [U pieces | V pieces]
+            if (i < UP)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (__attribute__((address_space(3))) void *)(dst + i * 1024), 16, uoff,
+                                                         __builtin_amdgcn_readfirstlane(su + (unsigned)(2 * i) * urun), 0, 0);
+            else if (i < UP + 18)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(vr, (__attribute__((address_space(3))) void *)(dst + U_BYTES + (i - UP) * 1024), 16, voff,
+                                                         __builtin_amdgcn_readfirstlane(sv + (unsigned)(i - UP) * 1024u), 0, 0);
         }
     };
 
@@ -181,11 +184,44 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const W4Args p) {
 #pragma unroll
     for (int q = 0; q < 36; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // ---- epilogue addressing: lane = tile m0 + 16wt + fr, components = channels n0 + 16wc + 4fq + (0..3); output pixel
+    // (a, c) of the tile: voffset = the tile's first pixel (or OOB), (a*W + c) pixels ride in the scalar offset
+    const int n = n0 + wc * 16 + fq * 4;
+    const bool nok = n < p.Cout;                       // Cout % 4 == 0
+    const int64_t oimg = (int64_t)p.H * p.W;
+    const __amdgpu_buffer_rsrc_t yr = rsrc(p.y + b0 * oimg * p.ldy, (p.B - b0) * oimg * p.ldy * 4);
+    const __amdgpu_buffer_rsrc_t rr = rsrc(RES ? p.res + b0 * oimg * p.ldr : p.y, (p.B - b0) * oimg * (RES ? p.ldr : p.ldy) * 4);
+    unsigned ybase, rbase;
+    bool orow[4], ocol[4];
+    {
+        const int mt = m0 + wt * 16 + fr;
+        const bool tok = mt < p.MT && nok;
+        const int mm = mt < p.MT ? mt : p.MT - 1;
+        const int b = mm / tpi, r = mm - b * tpi, ty = r / p.TW, tx = r - ty * p.TW;
+        const int oy = 4 * ty, ox = 4 * tx;
+        const int64_t pix = ((int64_t)(b - b0) * p.H + oy) * p.W + ox;
+        ybase = (unsigned)((pix * p.ldy + n) * 4);
+        rbase = (unsigned)((pix * p.ldr + n) * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            orow[i] = tok && oy + i < p.H;
+            ocol[i] = ox + i < p.W;
+        }
+    }
+    f32x4 rv[16];                                      // residual of the 4x4 outputs: loaded under the last stage's MFMAs
+
     load_stage(0);
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): the DMA'd stage has landed
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) load_stage(kt + 1);           // its buffer was last read before the previous barrier
+        if (RES && kt == nk - 1) {
+#pragma unroll
+            for (int o = 0; o < 16; ++o)
+                rv[o] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                      rr, orow[o >> 2] && ocol[o & 3] ? rbase : OOB,
+                                                      __builtin_amdgcn_readfirstlane((unsigned)(((o >> 2) * p.W + (o & 3)) * p.ldr * 4)), 0));
+        }
         const char *cu = smem + (kt & 1) * STAGE + rd_u;
         const char *cv = smem + (kt & 1) * STAGE + rd_v;
         // fragment reads run one position group ahead of the MFMAs (two register sets)
@@ -204,52 +240,35 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const W4Args p) {
                 acc[4 * g + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(fu[g & 1][e], fv[g & 1][e], acc[4 * g + e], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        // (also after the last stage: the residual loads issued under it are then complete before the epilogue -- leaving
+        // that to the compiler's own vmcnt bookkeeping next to LDS-DMA requests produced wrong residuals)
         __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): the next stage has landed
         __syncthreads();
     }
 
-    // ---- epilogue: lane = tile m0 + 16wt + fr, components = channels n0 + 16wc + 4fq + (0..3)
-    const int n = n0 + wc * 16 + fq * 4;
-    const bool nok = n < p.Cout;                       // Cout % 4 == 0
+    // ---- epilogue: output transform Y = At M A in place on the accumulators: the column pass leaves
+    // s[a][m] = sum_i At[a][i] M[i][m] in acc[6a + m], the row pass takes out[c] = sum_m s[a][m] At[c][m]
     const int nc = nok ? n : 0;
     const f32x4 scl = p.scale ? *reinterpret_cast<const f32x4 *>(p.scale + nc) : f32x4{1.f, 1.f, 1.f, 1.f};
     const f32x4 sft = p.shift ? *reinterpret_cast<const f32x4 *>(p.shift + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
-    const int64_t oimg = (int64_t)p.H * p.W;
-    const __amdgpu_buffer_rsrc_t yr = rsrc(p.y + b0 * oimg * p.ldy, (p.B - b0) * oimg * p.ldy * 4);
-    const __amdgpu_buffer_rsrc_t rr = rsrc(RES ? p.res + b0 * oimg * p.ldr : p.y, (p.B - b0) * oimg * (RES ? p.ldr : p.ldy) * 4);
-    const int mt = m0 + wt * 16 + fr;
-    const bool tok = mt < p.MT && nok;
-    const int mm = mt < p.MT ? mt : p.MT - 1;
-    const int b = mm / tpi, r = mm - b * tpi, ty = r / p.TW, tx = r - ty * p.TW;
-    const int oy = 4 * ty, ox = 4 * tx;
-    const int64_t pix = ((int64_t)(b - b0) * p.H + oy) * p.W + ox;
-    // output transform Y = At M A, one output row a at a time (the whole 4x4 result plus its residuals would not fit
-    // the register file next to the 144 accumulators): s[m] = sum_i At[a][i] M[i][m], out[c] = sum_m s[m] At[c][m]
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {
+        const f32x4 p1 = acc[6 + m] + acc[12 + m], m1 = acc[6 + m] - acc[12 + m];
+        const f32x4 p2 = acc[18 + m] + acc[24 + m], m2 = acc[18 + m] - acc[24 + m];
+        acc[m] = acc[m] + p1 + p2;
+        acc[6 + m] = m1 + 2.0f * m2;
+        acc[12 + m] = p1 + 4.0f * p2;
+        acc[18 + m] = m1 + 8.0f * m2 + acc[30 + m];
+    }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        unsigned yo[4];
-        f32x4 rv[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const bool ok = tok && oy + a < p.H && ox + c < p.W;
-            const int64_t px = pix + (int64_t)a * p.W + c;
-            yo[c] = ok ? (unsigned)((px * p.ldy + n) * 4) : OOB;
-            if (RES) rv[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ok ? (unsigned)((px * p.ldr + n) * 4) : OOB, 0, 0));
-        }
-        f32x4 s[6];
-#pragma unroll
-        for (int m = 0; m < 6; ++m) {
-            if (a == 0) s[m] = acc[m] + (acc[6 + m] + acc[12 + m]) + (acc[18 + m] + acc[24 + m]);
-            if (a == 1) s[m] = (acc[6 + m] - acc[12 + m]) + 2.0f * (acc[18 + m] - acc[24 + m]);
-            if (a == 2) s[m] = (acc[6 + m] + acc[12 + m]) + 4.0f * (acc[18 + m] + acc[24 + m]);
-            if (a == 3) s[m] = (acc[6 + m] - acc[12 + m]) + 8.0f * (acc[18 + m] - acc[24 + m]) + acc[30 + m];
-        }
-        const f32x4 pp = s[1] + s[2], qq = s[3] + s[4], dd = s[1] - s[2], ee = s[3] - s[4];
+        const f32x4 pp = acc[6 * a + 1] + acc[6 * a + 2], qq = acc[6 * a + 3] + acc[6 * a + 4];
+        const f32x4 dd = acc[6 * a + 1] - acc[6 * a + 2], ee = acc[6 * a + 3] - acc[6 * a + 4];
         f32x4 out[4];
-        out[0] = s[0] + pp + qq;
+        out[0] = acc[6 * a] + pp + qq;
         out[1] = dd + 2.0f * ee;
         out[2] = pp + 4.0f * qq;
-        out[3] = dd + 8.0f * ee + s[5];
+        out[3] = dd + 8.0f * ee + acc[6 * a + 5];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             f32x4 v = out[c] * scl + sft;
@@ -258,14 +277,18 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const W4Args p) {
                 if (ACT == MYDET_ACT_LEAKY) v[e] = v[e] > 0.0f ? v[e] : v[e] * 0.1f;
                 if (ACT == MYDET_ACT_SWISH) v[e] = v[e] * mydet_sigmoid_fast(v[e]);
             }
-            if (RES) v += rv[c];
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, yo[c], 0, 0);
+            if (RES) v += rv[4 * a + c];
+            // the pixel offset goes into the voffset, NOT the scalar offset: with an SGPR soffset the compiler leaves no
+            // wait state between a 16-byte store and the VALU that next overwrites its data registers, and on gfx950
+            // that store then picked up part of the next pixel's values (tests: test_conv_winograd4_repeatable)
+            const unsigned yo = ybase + (unsigned)((a * p.W + c) * p.ldy * 4);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, orow[a] && ocol[c] ? yo : OOB, 0, 0);
         }
     }
 }
 
 // U = G g Gt in float64, rounded once; layout [Cin/4][9 position groups][4 k][CoutP][4] with the float4 = positions
-// 4g..4g+3 at channel k (CoutP = Cout rounded up to 32, zero rows): exactly the LDS slab, so a workgroup's share of a
+// 4g..4g+3 at channel k (CoutP = Cout rounded up to 64, zero rows): exactly the LDS slab, so a workgroup's share of a
 // slab is 36 contiguous runs of 64 float4.
 __global__ void wino4_weights_kernel(const float *w, int Cout, int Cin, int CoutP, float *u) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -296,7 +319,7 @@ int launch_w4(W4Args a, hipStream_t stream) {
         attr_set = true;
     }
     hipLaunchKernelGGL(wino4_input_kernel, dim3((a.MT + TILES - 1) / TILES, (a.Cin + 7) / 8), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL((conv_wino4_kernel<ACT, RES>), dim3(a.nblk), dim3(256), LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((conv_wino4_kernel<ACT, RES>), dim3(a.nblk), dim3(64 * NW), LDS_BYTES, stream, a);
     return mydet_launch_status();
 }
 
@@ -304,13 +327,13 @@ int launch_w4(W4Args a, hipStream_t stream) {
 
 extern "C" int64_t mydet_wino4_weights_floats(int Cout, int Cin) {
     if (Cout <= 0 || Cin <= 0 || (Cin & 3)) return 0;
-    return (int64_t)36 * Cin * ((Cout + CH - 1) / CH * CH);
+    return (int64_t)36 * Cin * ((Cout + COUT_PAD - 1) / COUT_PAD * COUT_PAD);
 }
 
 extern "C" int mydet_wino4_weights_f32(const float *w, int Cout, int Cin, float *u, void *stream) {
     if (!w || !u || Cout <= 0 || Cin <= 0) return MYDET_E_BADARG;
     if (Cin & 3) return MYDET_E_UNSUPP;
-    const int CoutP = (Cout + CH - 1) / CH * CH;
+    const int CoutP = (Cout + COUT_PAD - 1) / COUT_PAD * COUT_PAD;
     const int64_t n = (int64_t)CoutP * Cin;
     hipLaunchKernelGGL(wino4_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin,
                        CoutP, u);
@@ -336,7 +359,7 @@ extern "C" int mydet_conv2d_wino4_f32(const float *x, int64_t ldx, const float *
     W4Args a;
     a.x = x; a.u = u; a.scale = scale; a.shift = shift; a.res = residual; a.y = y; a.v = ws;
     a.ldx = ldx; a.ldr = residual ? ldr : ldy; a.ldy = ldy;
-    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.CoutP = (Cout + CH - 1) / CH * CH;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.CoutP = (Cout + COUT_PAD - 1) / COUT_PAD * COUT_PAD;
     a.TH = (H + 3) / 4; a.TW = (W + 3) / 4;
     const int64_t MT = (int64_t)B * a.TH * a.TW;
     if (MT > (int64_t)1 << 30) return MYDET_E_UNSUPP;
@@ -345,7 +368,7 @@ extern "C" int mydet_conv2d_wino4_f32(const float *x, int64_t ldx, const float *
     const int64_t ldmax = ldx > ldy ? (ldx > a.ldr ? ldx : a.ldr) : (ldy > a.ldr ? ldy : a.ldr);
     if ((int64_t)H * W * ldmax * 4 * span >= 0x7FFFFFF0ll || (int64_t)36 * Cin * a.CoutP * 4 >= 0x7FFFFFF0ll) return MYDET_E_UNSUPP;
     a.MT = (int)MT;
-    a.ntn = a.CoutP / CH;
+    a.ntn = (Cout + CH - 1) / CH;
     a.nblk = (int)((MT + TILES - 1) / TILES) * a.ntn;
     if ((MT + TILES - 1) / TILES > 0x7FFFFFFF || (Cin + 7) / 8 > 65535) return MYDET_E_UNSUPP;
     hipStream_t s = (hipStream_t)stream;

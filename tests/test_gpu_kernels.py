@@ -107,6 +107,31 @@ def test_conv_winograd4_vs_fp64(dev, case):
     _conv_case(dev, k=3, s=1, wino4=True, **case)
 
 
+@pytest.mark.parametrize('case', [
+    dict(B=4, Cin=512, Cout=1024, H=12, W=12, act=1),                  # deep K, one round of workgroups
+    dict(B=32, Cin=128, Cout=256, H=40, W=40, act=1, residual=True),   # several rounds, residual
+    dict(B=8, Cin=256, Cout=512, H=20, W=20, act=0, bias_only=True),
+])
+def test_conv_winograd4_repeatable(dev, case):
+    """The F(4x4,3x3) pair of launches gives bit-identical results run after run (every LDS stage is fenced by a DMA
+    wait + barrier, the workspace is written whole before it is read): a race would show as run-to-run differences."""
+    from mydetection_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, Cin, Cout, H, W = (case[k] for k in ('B', 'Cin', 'Cout', 'H', 'W'))
+    x = torch.randn(B, Cin, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) / (Cin * 9) ** 0.5).to(dev)
+    scale = None if case.get('bias_only') else (torch.rand(Cout, generator=g) + 0.5).to(dev)
+    shift = (torch.randn(Cout, generator=g) * 0.1).to(dev)
+    res = torch.randn(B, Cout, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last) if case.get('residual') else None
+    u4 = ops.wino4_weights(w)
+    outs = [ops.conv2d(x, w, scale, shift, 3, 1, (1, 1, 1, 1), case['act'], residual=res, wino4=u4).clone() for _ in range(6)]
+    direct = ops.conv2d(x, w, scale, shift, 3, 1, (1, 1, 1, 1), case['act'], residual=res)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    assert (outs[0] - direct).abs().max().item() <= 1e-4 * max(1.0, direct.abs().max().item())
+
+
+
 def test_conv_winograd_unsupported_shapes_stay_direct(dev):
     from mydetection_amd import ops
     assert ops.wino_weights(torch.zeros(64, 3, 3, 12, device=dev)) is None     # Cin % 8
