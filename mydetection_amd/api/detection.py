@@ -45,6 +45,10 @@ class Detector():
         if weights_path:
             self.model.load_state_dict(torch.load(weights_path)['model'])
         self.on_cpu = False
+        # hipGraph replay of forward + post-process per (batch, H, W, conf, nms), captured the second time a shape is seen
+        # (a one-off shape is not worth two warm-up passes); MYDET_GRAPH=0 keeps every call eager
+        self.use_graph = os.environ.get('MYDET_GRAPH', '1') != '0'
+        self._graphs, self._graph_seen = {}, {}
 
     def _init_preprocess(self, cfg):
         self.divisibe = cfg['general.input_divisibility']
@@ -171,17 +175,35 @@ class Detector():
     def _records_by_size(self, pil_imgs, **kwargs):
         """Detection records of a list of PIL images, grouped by network input size: yields (indices, records) with the
         boxes already in the coordinates of the original images."""
-        from ..utils.structures import batched_post_process
         conf_thres = kwargs.get('conf_thres', self.conf_thres)
         nms_thres = kwargs.get('nms_thres', self.nms_thres)
         for idxs, x, pads, hws in self.preprocess_batch(pil_imgs, **kwargs):
-            with torch.no_grad():
-                bb, ci, sc = self.model.forward_candidates(x)
-                rec = batched_post_process(bb, ci, sc, conf_thres, nms_thres)
+            rec = self._records(x, conf_thres, nms_thres)
             if any(p is not None for p in pads):
                 ops.records_to_original_(rec, pads)
             rec['img_hw'] = hws
             yield idxs, rec
+
+    _MAX_GRAPHS = 6
+
+    def _records(self, x, conf_thres, nms_thres):
+        """Detection records of one network input batch (boxes in network-input coordinates): a hipGraph replay when
+        this (shape, thresholds) has been seen before, the eager launch sequence otherwise."""
+        from ..utils.structures import batched_post_process
+        key = (tuple(x.shape), float(conf_thres), float(nms_thres))
+        if self.use_graph:
+            g = self._graphs.get(key)
+            if g is None and self._graph_seen.get(key, 0) >= 1:
+                from ..graph import GraphedPath
+                if len(self._graphs) >= self._MAX_GRAPHS:            # each graph owns its activations: drop the oldest
+                    self._graphs.pop(next(iter(self._graphs)))
+                g = self._graphs[key] = GraphedPath(self.model, x, conf_thres, nms_thres)
+            if g is not None:
+                return {k: v.clone() for k, v in g(x).items()}       # the graph's own record buffers are overwritten by the next replay
+            self._graph_seen[key] = self._graph_seen.get(key, 0) + 1
+        with torch.no_grad():
+            bb, ci, sc = self.model.forward_candidates(x)
+            return batched_post_process(bb, ci, sc, conf_thres, nms_thres)
 
     def predict_batch(self, pil_imgs, **kwargs):
         """Batched form of detect_one (the reference loops image by image, api/detection.py:67-74): images that share a

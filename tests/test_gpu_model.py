@@ -332,6 +332,17 @@ def test_device_preprocess_and_batched_detector(model):
         assert torch.equal(one.cats, d.cats)
         np.testing.assert_allclose(one.scores.cpu().numpy(), d.scores.cpu().numpy(), rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(one.bboxes.cpu().numpy(), d.bboxes.cpu().numpy(), rtol=1e-5, atol=1e-4)
+    # the second call with a shape is captured into a hipGraph, later ones replay it: same detections, bit for bit
+    assert det.use_graph and any(k[0][0] == 1 for k in det._graphs), 'three detect_one calls: the batch-of-1 path is a graph by now'
+    for _ in range(3):
+        again = det.predict_batch(imgs, **kw)
+        for d, e in zip(batch, again):
+            assert torch.equal(d.cats, e.cats) and torch.equal(d.scores, e.scores) and torch.equal(d.bboxes, e.bboxes)
+    assert any(k[0][0] == 3 for k in det._graphs) and len(det._graphs) == 2
+    det.use_graph = False
+    eager = det.predict_batch(imgs, **kw)
+    for d, e in zip(batch, eager):
+        assert torch.equal(d.cats, e.cats) and torch.equal(d.scores, e.scores) and torch.equal(d.bboxes, e.bboxes)
 
 
 def test_full_size_properties_batch32_640(model):
