@@ -50,6 +50,7 @@ struct W4Args {
     int64_t ldx, ldr, ldy;
     int B, H, W, Cin, Cout, CoutP;
     int TH, TW, MT, ntn, nblk;
+    int nmb, nbn, rn_log2;                             // item order of the GEMM kernel (see there)
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -145,11 +146,19 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino4_kernel(const W4Args p) 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int item = mydet_xcd_remap(blockIdx.x, p.nblk);
+    // Item order: an XCD's share of the grid is a contiguous id range (mydet_xcd_remap), and each 64 consecutive ids --
+    // the workgroups its 32 CUs run together -- form a block of RM tile blocks x RN channel blocks (RM * RN = 64, RN = 8
+    // from 256 output channels up).  They walk K together, so a V stage is fetched from HBM once per RN workgroups
+    // and a U stage once per RM; with the tile-block-major order (RM = 2 at Cout = 1024) the deep layers re-read U
+    // a dozen times over.  Ids of the padded grid that fall outside return at once.
+    const int id = mydet_xcd_remap(blockIdx.x, p.nblk);
+    const int bi = id >> 6, w = id & 63;
+    const int mb = (bi / p.nbn) * (64 >> p.rn_log2) + (w >> p.rn_log2);
+    const int nb = (bi % p.nbn) * (1 << p.rn_log2) + (w & ((1 << p.rn_log2) - 1));
+    if (mb >= p.nmb || nb >= p.ntn) return;
     const int tpi = p.TH * p.TW;
     const int nk = p.Cin >> 2;
-    const int mb = item / p.ntn;
-    const int m0 = mb * TILES, n0 = (item % p.ntn) * CH;
+    const int m0 = mb * TILES, n0 = nb * CH;
     const int b0 = m0 / tpi;
     const int wc = wave % (NW / 2), wt = wave / (NW / 2);
     const int fr = lane & 15, fq = lane >> 4;
@@ -369,7 +378,13 @@ extern "C" int mydet_conv2d_wino4_f32(const float *x, int64_t ldx, const float *
     if ((int64_t)H * W * ldmax * 4 * span >= 0x7FFFFFF0ll || (int64_t)36 * Cin * a.CoutP * 4 >= 0x7FFFFFF0ll) return MYDET_E_UNSUPP;
     a.MT = (int)MT;
     a.ntn = (Cout + CH - 1) / CH;
-    a.nblk = (int)((MT + TILES - 1) / TILES) * a.ntn;
+    a.nmb = (int)((MT + TILES - 1) / TILES);
+    a.rn_log2 = 0;
+    while ((1 << a.rn_log2) < a.ntn && a.rn_log2 < 3) ++a.rn_log2;
+    a.nbn = (a.ntn + (1 << a.rn_log2) - 1) >> a.rn_log2;
+    const int64_t nbm = (a.nmb + (64 >> a.rn_log2) - 1) / (64 >> a.rn_log2);
+    if (nbm * a.nbn * 64 > 0x7FFFFFFF) return MYDET_E_UNSUPP;
+    a.nblk = (int)(nbm * a.nbn * 64);
     if ((MT + TILES - 1) / TILES > 0x7FFFFFFF || (Cin + 7) / 8 > 65535) return MYDET_E_UNSUPP;
     hipStream_t s = (hipStream_t)stream;
     const bool res = residual != nullptr;

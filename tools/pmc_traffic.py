@@ -17,7 +17,8 @@ import sys
 from collections import defaultdict
 
 # (substring of the kernel name, family, FETCH_SIZE correction or None = uncalibrated: report x1 and x2)
-FAMILIES = [('conv_wino_kernel', 'conv_wino', None), ('conv_igemm_kernel', 'conv_igemm', 2.0), ('conv_fixup', 'conv_igemm_fixup', 2.0),
+FAMILIES = [('conv_wino4_kernel', 'conv_wino4_gemm', 2.0), ('wino4_input_kernel', 'wino4_input', None), ('wino4_weights', None, None),
+            ('conv_wino_kernel', 'conv_wino', None), ('conv_igemm_kernel', 'conv_igemm', 2.0), ('conv_fixup', 'conv_igemm_fixup', 2.0),
             ('conv_stem', 'conv_stem', None), ('upsample_concat', 'upsample_concat', 2.0), ('decode_kernel', 'decode', 2.0),
             ('postprocess', 'postprocess', None), ('dwconv', 'dwconv', 2.0), ('sepconv', 'sepconv_nodes', 2.0),
             ('mbconv_expand_dw', 'mbconv_expand_dw', 2.0), ('se_gate', 'se_gate', None), ('se_mean', 'se_gate', None),
@@ -57,4 +58,14 @@ for fam in fetch:
     else:
         e.update({'fetch_correction': corr, 'hbm_read_bytes_per_launch': corr * rd, 'hbm_bytes_per_launch': corr * rd + wr})
     out[fam] = e
+# bench.py times the F(4x4) Winograd layer as one unit (input-transform launch + GEMM launch): the same unit here.  The GEMM
+# kernel's loads are all 16-byte DMA (x2 correction); the input kernel's patch loads are dwords (x1 .. x2)
+if 'conv_wino4_gemm' in out and 'wino4_input' in out:
+    g, t = out['conv_wino4_gemm'], out['wino4_input']
+    out['conv_wino4'] = {'launches': g['launches'], 'unit': 'wino4_input_kernel + conv_wino4_kernel',
+                         'hbm_read_bytes_per_launch': g['hbm_read_bytes_per_launch'] + t['hbm_read_bytes_per_launch_x1'],
+                         'hbm_read_bytes_per_launch_upper': g['hbm_read_bytes_per_launch'] + t['hbm_read_bytes_per_launch_x2'],
+                         'hbm_write_bytes_per_launch': g['hbm_write_bytes_per_launch'] + t['hbm_write_bytes_per_launch'],
+                         'hbm_bytes_per_launch': g['hbm_bytes_per_launch'] + t['hbm_bytes_per_launch'],
+                         'hbm_bytes_per_launch_upper': g['hbm_bytes_per_launch'] + t['hbm_bytes_per_launch_upper']}
 print(json.dumps(out, indent=1))
