@@ -41,6 +41,7 @@ struct DecodeArgs {
     int box_span, cls_span;      // floats of a pixel actually needed (multiples of 4)
     int same;                    // box and cls are the same tensor
     int PIX, row;                // pixels per tile, LDS row length (odd)
+    int tpc;                     // threads per candidate: 1, 2 or 4 (tiles with <= 128 / <= 64 candidates: single-anchor heads)
     unsigned qc, qb, mc, mb;     // float4 per row (cls, box) and their magic reciprocals: i / q == (i * m) >> 20
     float *bbox;
     int64_t *cidx;
@@ -128,21 +129,36 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs p) {
         __syncthreads();
         if (tile + (int)gridDim.x < L.ntiles)                  // flies under the compute phase
             tile_load<NV, NVB>(p, L, tile + gridDim.x, v, vb);
-        for (int c = threadIdx.x; c < p.PIX * p.A; c += 256) {
+        // tpc > 1: tpc neighbouring lanes share candidate c -- each scans its share of the classes, lane exchanges pick the
+        // winner (a tie goes to the lower share, i.e. the first maximum, as in the sequential scan)
+        const int tl = p.tpc == 4 ? 2 : (p.tpc == 2 ? 1 : 0);
+        const int part = threadIdx.x & (p.tpc - 1);
+        const int cstep = 256 >> tl;
+        const int cshare = (p.C + p.tpc - 1) >> tl;
+        const int k_lo = part * cshare < p.C ? part * cshare : p.C - 1;
+        const int k_hi = k_lo + cshare < p.C ? k_lo + cshare : p.C;
+        for (int c = (int)(threadIdx.x >> tl); c < p.PIX * p.A; c += cstep) {
             const int a = c / p.PIX, px = c - a * p.PIX;
-            if (px >= npx) continue;
+            if (px >= npx) continue;                   // (both lanes of a pair leave together)
             const float *rowp = sm + px * p.row;
             const float *cl = rowp + a * p.cls_astride + p.cls_c0;
             // class max / first argmax (strict >: the first maximum wins, as torch.max)
-            float best = cl[0];
-            int bi = 0;
-            for (int k0 = 1; k0 < p.C; k0 += 8) {      // 8 LDS reads in flight, then the ordered compare chain
+            float best = cl[k_lo];
+            int bi = k_lo;
+            for (int k0 = k_lo + 1; k0 < k_hi; k0 += 8) {      // 8 LDS reads in flight, then the ordered compare chain
                 float x[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = cl[k0 + j < p.C ? k0 + j : p.C - 1];   // clamped repeats never win
+                for (int j = 0; j < 8; ++j) x[j] = cl[k0 + j < k_hi ? k0 + j : k_hi - 1];   // clamped repeats never win
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
                     if (x[j] > best) { best = x[j]; bi = k0 + j; }
+            }
+            for (int sft = 1; sft < p.tpc; sft <<= 1) {
+                const float ob = __shfl_xor(best, sft);
+                const int obi = __shfl_xor(bi, sft);
+                const bool take = (part & sft) ? !(best > ob) : (ob > best);     // the upper share wins only when strictly greater
+                best = take ? ob : best;
+                bi = take ? obi : bi;
             }
             float cmax;
             if (best < 5.0f && best > -80.0f) {
@@ -155,6 +171,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs p) {
                     if (sv > cmax) { cmax = sv; bi = k; }
                 }
             }
+            if (part) continue;                        // lane 2c finishes the candidate
             const float *t = rowp + box_col + a * p.box_astride + p.box_c0;
             const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
             const int64_t pix = pix0 + px;
@@ -255,7 +272,9 @@ extern "C" int mydet_decode_levels_f32(int mode, int nlevels, const mydet_decode
     if (const char *e = getenv("MYDET_DECODE_PIX")) p.PIX = atoi(e);      // tuning knob
     while (p.PIX > 1 && !fits(p.PIX)) p.PIX >>= 1;
     if (!fits(p.PIX)) return MYDET_E_UNSUPP;
-    while (p.PIX * A < 256 && fits(p.PIX * 2)) p.PIX <<= 1;
+    if (!getenv("MYDET_DECODE_PIX"))
+        while (p.PIX * A < 256 && fits(p.PIX * 2)) p.PIX <<= 1;
+    p.tpc = C < 16 ? 1 : (p.PIX * A <= 64 ? 4 : (p.PIX * A <= 128 ? 2 : 1));
     p.mc = magic20(p.qc, p.PIX * p.qc);
     p.mb = magic20(p.qb, p.PIX * p.qb);
     if (!p.mc || !p.mb) return MYDET_E_UNSUPP;
