@@ -398,7 +398,7 @@ int launch(const ConvArgs &a0, int slots, hipStream_t stream) {
     if (splits > nk / 4) splits = nk / 4;
     const size_t need = (size_t)rem * (splits > 0 ? splits : 0) * BM * BN * sizeof(float);
     // only long-K layers: on short ones the two extra launches cost more than the spared round
-    const bool split = !a.gate && rem > 0 && splits >= 2 && a0.ws && need <= a0.ws_bytes &&
+    const bool split = rem > 0 && splits >= 2 && a0.ws && need <= a0.ws_bytes &&
                        (small || (nk >= 32 && rounds >= 2 && rem * 2 <= slots));
     a.tile0 = 0; a.splits = 1;
     a.nblk = split ? total - rem : total;
@@ -407,8 +407,13 @@ int launch(const ConvArgs &a0, int slots, hipStream_t stream) {
         rc = cin ? launch_act<BM, BN, WM, WN, BK, true>(a, lds, stream) : launch_act<BM, BN, WM, WN, BK, false>(a, lds, stream);
     if (rc || !split) return rc;
     a.tile0 = total - rem; a.splits = splits; a.nblk = rem * splits;
-    if (cin) rc = launch_inst<BM, BN, WM, WN, BK, true, MYDET_ACT_NONE, false, false, true>(a, lds, stream);
-    else rc = launch_inst<BM, BN, WM, WN, BK, false, MYDET_ACT_NONE, false, false, true>(a, lds, stream);
+    if (a.gate) {       // SE-gated project conv: the gate rides on the A operand, so the K slices sum like any others
+        if (cin) rc = launch_inst<BM, BN, WM, WN, BK, true, MYDET_ACT_NONE, false, true, true>(a, lds, stream);
+        else rc = launch_inst<BM, BN, WM, WN, BK, false, MYDET_ACT_NONE, false, true, true>(a, lds, stream);
+    } else {
+        if (cin) rc = launch_inst<BM, BN, WM, WN, BK, true, MYDET_ACT_NONE, false, false, true>(a, lds, stream);
+        else rc = launch_inst<BM, BN, WM, WN, BK, false, MYDET_ACT_NONE, false, false, true>(a, lds, stream);
+    }
     if (rc) return rc;
     return launch_fixup_act<BM, BN, WM, WN>(a, rem, stream);
 }

@@ -373,7 +373,8 @@ def test_dwconv(dev, k, s, pad, C, H, W, act):
 def test_se_gate_and_gated_conv(dev):
     from mydetection_amd import ops
     g = torch.Generator().manual_seed(4)
-    for C, Cse, H, W, Cout in ((96, 4, 40, 40, 24), (1152, 48, 5, 5, 192), (16, 4, 33, 17, 16)):
+    # (the two 1152-channel cases are small grids with long K: cut along K over the chip, gate and all)
+    for C, Cse, H, W, Cout in ((96, 4, 40, 40, 24), (1152, 48, 5, 5, 192), (16, 4, 33, 17, 16), (1152, 48, 20, 20, 192)):
         x = torch.randn(3, C, H, W, generator=g)
         w1, b1 = torch.randn(Cse, C, generator=g) * 0.1, torch.randn(Cse, generator=g) * 0.1
         w2, b2 = torch.randn(C, Cse, generator=g) * 0.3, torch.randn(C, generator=g) * 0.1
