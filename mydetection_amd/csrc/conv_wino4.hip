@@ -134,9 +134,13 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const W4Args p) {
         for (int m = 0; m < 6; ++m) gv[6 * i + m] = o[m];
     }
     if (c < p.Cin) {                                   // Cin % 4 == 0: a k-quad is written whole or not at all
+        // non-temporal: V is read back by the next launch from HBM / the Infinity Cache, not from this XCD's L2 (-5 %);
+        // staging the block's 36 KB through LDS for 1 KB-contiguous stores was measured and changes nothing -- the
+        // launch is bound by the 2.25 x input bytes it writes (3.9 TB/s with the loads removed)
         f32x4 *dst = reinterpret_cast<f32x4 *>(p.v) + (((int64_t)mb * nk + (c >> 2)) * NPG * KC + (c & 3)) * TILES + st;
 #pragma unroll
-        for (int g = 0; g < NPG; ++g) dst[g * KC * TILES] = f32x4{gv[4 * g], gv[4 * g + 1], gv[4 * g + 2], gv[4 * g + 3]};
+        for (int g = 0; g < NPG; ++g)
+            __builtin_nontemporal_store(f32x4{gv[4 * g], gv[4 * g + 1], gv[4 * g + 2], gv[4 * g + 3]}, dst + g * KC * TILES);
     }
 }
 
