@@ -581,3 +581,25 @@ def test_mbconv_expand_dw_vs_fp64(dev, k, s, cin, hw):
     ex = ops.conv2d(xd, args[0], args[1], args[2], 1, 1, (0, 0, 0, 0), ops.ACT_SWISH)
     old, _ = ops.dwconv(ex, args[3], args[4], args[5], k, s, pad, ops.ACT_SWISH, squeeze=True)
     assert (out - old).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_last_conv_padded_output_channels(dev):
+    """The FCOS head's dense 3x3 last conv (88 -> 81 = conf + 80 classes, reference models/rpns.py:245-266) is computed
+    with 84 output channels (zero weight rows) so that the Winograd kernels take it: the 81-channel view must equal
+    the float64 convolution, and the three padding channels must hold exactly the bias-free zeros."""
+    from mydetection_amd.models.rpns import _LastConv
+    torch.manual_seed(3)
+    m = _LastConv(88, 81, 3, 1, padding=1).to(dev).eval()
+    with torch.no_grad():
+        m.weight.normal_(0, 0.05)
+        m.bias.normal_(0, 0.5)
+    for B, H in ((2, 20), (32, 80)):                     # F(2x2) path / F(4x4) path (1200 workgroups)
+        x = torch.randn(B, 88, H, H, device=dev).contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            y = m(x)
+        assert tuple(y.shape) == (B, 81, H, H) and y.stride(1) == 1 and y.stride(3) == 84
+        ref = F.conv2d(x.double().cpu(), m.weight.double().cpu(), m.bias.double().cpu(), padding=1)
+        assert (y.cpu().double() - ref).abs().max().item() <= 6e-5 * max(1.0, ref.abs().max().item())
+        pad = torch.as_strided(y, (B, 3, H, H), y.stride(), y.storage_offset() + 81)
+        assert torch.equal(pad, torch.zeros_like(pad))
+
