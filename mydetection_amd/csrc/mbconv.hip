@@ -342,6 +342,104 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float *partial, int 
         gate[(int64_t)b * C + c] = mydet_sigmoid((((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane]) + b2[c]);
 }
 
+// Whole squeeze-excite tail of one image in ONE workgroup (1024 threads): mean over the S slice sums, reduce conv +
+// swish, expand conv + sigmoid.  The two-launch form above spent 19 us per block on launch and dependency latency for a
+// few hundred KB of L2-resident reads; S*C <= ~70 k floats per image on the D1 shapes, so one CU per image reads it in
+// about a microsecond.  Thread (q, ph) sums slices ph, ph + P, ... of channel quad q (P = 1024 / (C/4) phases, 16-byte
+// loads), the phases are added in order 0..P-1 (fixed order: deterministic), then the two small matrix-vector products
+// run as in se_gate_kernel with 16 waves.
+__global__ __launch_bounds__(1024) void se_fused_kernel(float *partial, int S, int C, int HW, const float *w1,
+                                                        const float *b1, int Cse, const float *w2t, const float *b2,
+                                                        float *gate, int P) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *mean = sm;                                  // [C]
+    float *hid = sm + C;                               // [Cse] (+ pad to a multiple of 4)
+    f32x4 *red = reinterpret_cast<f32x4 *>(sm + C + ((Cse + 3) & ~3));      // [P][C/4]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int Q = C >> 2;
+    float *pb = partial + (int64_t)b * (S + 1) * C;
+    const int q = tid % Q, ph = tid / Q;
+    if (ph < P) {
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        int sl = ph;
+        for (; sl + P < S; sl += 2 * P) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(pb + (int64_t)sl * C + q * 4);
+            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(pb + (int64_t)(sl + P) * C + q * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a0[j] += v0[j]; a1[j] += v1[j]; }
+        }
+        if (sl < S) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(pb + (int64_t)sl * C + q * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a0[j] += v0[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a0[j] += a1[j];
+        red[ph * Q + q] = a0;
+    }
+    __syncthreads();
+    if (tid < Q) {
+        f32x4 t = red[tid];
+        for (int k = 1; k < P; ++k) {
+            const f32x4 o = red[k * Q + tid];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] += o[j];
+        }
+        const float inv = 1.0f / (float)HW;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] *= inv;
+        *reinterpret_cast<f32x4 *>(mean + tid * 4) = t;
+        *reinterpret_cast<f32x4 *>(pb + (int64_t)S * C + tid * 4) = t;      // slice S keeps the mean, as before
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    // reduce conv: a wave per output channel, two output channels and four 64-channel strides in flight (eight
+    // independent load / fma streams; each channel's own summation order is fixed)
+    for (int o0 = wave; o0 < Cse; o0 += 32) {
+        const int o1 = o0 + 16 < Cse ? o0 + 16 : o0;   // surplus slot redoes o0, result discarded
+        const float *wr0 = w1 + (int64_t)o0 * C, *wr1 = w1 + (int64_t)o1 * C;
+        float a[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        int c = lane;
+        for (; c + 192 < C; c += 256) {
+            const float m0 = mean[c], m1 = mean[c + 64], m2 = mean[c + 128], m3 = mean[c + 192];
+            a[0][0] = fmaf(wr0[c], m0, a[0][0]); a[1][0] = fmaf(wr1[c], m0, a[1][0]);
+            a[0][1] = fmaf(wr0[c + 64], m1, a[0][1]); a[1][1] = fmaf(wr1[c + 64], m1, a[1][1]);
+            a[0][2] = fmaf(wr0[c + 128], m2, a[0][2]); a[1][2] = fmaf(wr1[c + 128], m2, a[1][2]);
+            a[0][3] = fmaf(wr0[c + 192], m3, a[0][3]); a[1][3] = fmaf(wr1[c + 192], m3, a[1][3]);
+        }
+        for (; c < C; c += 64) {
+            a[0][0] = fmaf(wr0[c], mean[c], a[0][0]);
+            a[1][0] = fmaf(wr1[c], mean[c], a[1][0]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float acc = (a[u][0] + a[u][1]) + (a[u][2] + a[u][3]);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+            const int o = o0 + 16 * u;
+            if (lane == 0 && o < Cse) {
+                acc += b1[o];
+                hid[o] = acc * mydet_sigmoid(acc);
+            }
+        }
+    }
+    __syncthreads();
+    // expand conv + sigmoid: a thread per channel, k in order over four interleaved chains, eight loads in flight
+    for (int c = tid; c < C; c += 1024) {
+        float e[4] = {0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 7 < Cse; k += 8) {
+            float w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = w2t[(int64_t)(k + j) * C + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j & 3] = fmaf(w[j], hid[k + j], e[j & 3]);
+        }
+        for (; k < Cse; ++k) e[k & 3] = fmaf(w2t[(int64_t)k * C + c], hid[k], e[k & 3]);
+        gate[(int64_t)b * C + c] = mydet_sigmoid(((e[0] + e[1]) + (e[2] + e[3])) + b2[c]);
+    }
+}
+
 // ----------------------------------------------------------------------------------------------- max pool
 __global__ __launch_bounds__(256) void maxpool3s2_kernel(const float *x, int64_t ldx, float *y, int64_t ldy, int C,
                                                          int H, int W, int Ho, int Wo, int64_t total) {
@@ -511,6 +609,17 @@ extern "C" int mydet_se_gate_f32(float *partial, int S, int B, int HW, int C, co
                                  int Cse, const float *w2t, const float *b2, float *gate, void *stream) {
     if (!partial || !w1 || !b1 || !w2t || !b2 || !gate || B <= 0 || B > 65535 || HW <= 0 || C <= 0 || Cse <= 0 || S <= 0)
         return MYDET_E_BADARG;
+    if ((C & 3) == 0 && (C >> 2) <= 1024 && C >= 4) {      // one launch: a workgroup per image
+        int P = 1024 / (C >> 2);
+        P = P > 32 ? 32 : P;
+        P = P > S ? S : P;
+        const size_t l1 = ((size_t)C + ((Cse + 3) & ~3) + (size_t)P * C) * sizeof(float);
+        if (l1 <= 64 * 1024) {
+            hipLaunchKernelGGL(se_fused_kernel, dim3(B), dim3(1024), l1, (hipStream_t)stream, partial, S, C, HW, w1, b1, Cse,
+                               w2t, b2, gate, P);
+            return mydet_launch_status();
+        }
+    }
     const size_t lds = (size_t)(C + Cse) * sizeof(float);
     if (lds > 64 * 1024) return MYDET_E_UNSUPP;
     hipLaunchKernelGGL(se_mean_kernel, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, partial, S, C, HW);
