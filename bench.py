@@ -241,11 +241,13 @@ def main():
     torch.cuda.synchronize()
 
     if graphed is None:
-        ops.TIMER = ops.KernelTimer()                            # HIP events on the launch stream
+        ops.TIMER = ops.KernelTimer(chain=True)                  # HIP events on the launch stream; one event per launch boundary
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        if ops.TIMER is not None:
+            ops.TIMER.cut()                                      # the exchange between steps is not a timed launch
         rec = step()
     torch.cuda.synchronize()
     barrier()

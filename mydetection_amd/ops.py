@@ -27,11 +27,18 @@ class KernelTimer:
     """Optional per-launch timing with HIP events recorded on the launch stream (bench.py uses it to
     price the dominant kernel inside the timed region).  Disabled (None) by default: zero overhead."""
 
-    def __init__(self):
+    def __init__(self, chain=False):
         self.spans = {}
         self.bytes = {}                  # name -> algorithmic bytes (operands read once + result written once)
+        # chain=True: the event that closes one launch also opens the next one (every launch of the step is timed and
+        # they run back to back on one in-order stream, so "end of launch i" IS "start of launch i+1"): half the
+        # event records -- each is a small packet on the GPU's queue -- inside the timed region
+        self.chain = chain
+        self._tail = None
 
     def start(self):
+        if self.chain and self._tail is not None:
+            return self._tail
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()                      # torch's current stream == the stream handed to the C ABI
         return ev
@@ -39,8 +46,13 @@ class KernelTimer:
     def stop(self, name, start_ev, work=0.0, nbytes=0.0):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
+        self._tail = ev
         self.spans.setdefault(name, []).append((start_ev, ev, work))
         self.bytes[name] = self.bytes.get(name, 0.0) + nbytes
+
+    def cut(self):
+        """Forget the chain (call where untimed GPU work, a synchronisation or a step boundary intervenes)."""
+        self._tail = None
 
     def summary(self):
         """name -> (launches, total_ms, total_work); call after torch.cuda.synchronize()."""
