@@ -260,6 +260,22 @@ def main():
         torch.cuda.synchronize()
         timer, ops.TIMER = ops.TIMER, None
 
+    # NMS latency proper: the post-process launch alone on this step's candidates, its own start / stop events per launch
+    # (the chained timer of the timed region charges any inter-launch gap to the next kernel)
+    with torch.no_grad():
+        cand = model.forward_candidates(x)
+    nms_spans = []
+    for i in range(120):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        batched_post_process(*cand, conf, nms)
+        e1.record()
+        if i >= 20:
+            nms_spans.append((e0, e1))
+    torch.cuda.synchronize()
+    nms_spans = sorted(a.elapsed_time(b) for a, b in nms_spans)
+    del cand
+
     if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -286,8 +302,11 @@ def main():
     stages = {k: {'launches_per_step': v[0] / args.steps, 'ms_per_step': round(v[1] / args.steps, 4)} for k, v in summ.items()}
     kernel_ms = sum(v[1] for v in summ.values()) / args.steps
     pp_spans = sorted(a.elapsed_time(b) for a, b, _ in timer.spans['postprocess'])
-    stages['postprocess']['p50_ms'] = round(statistics.median(pp_spans), 4)
-    stages['postprocess']['p95_ms'] = round(pp_spans[min(len(pp_spans) - 1, int(len(pp_spans) * 0.95))], 4)
+    stages['postprocess']['in_step_p50_ms'] = round(statistics.median(pp_spans), 4)
+    stages['postprocess']['p50_ms'] = round(statistics.median(nms_spans), 4)
+    stages['postprocess']['p95_ms'] = round(nms_spans[min(len(nms_spans) - 1, int(len(nms_spans) * 0.95))], 4)
+    stages['postprocess']['p50_note'] = ('p50/p95: 100 back-to-back launches on the step\'s candidates after the timed region, own start/stop '
+                                         'events per launch; in_step_p50_ms: the launch inside the timed steps (chained events)')
     stages['postprocess']['mean_detections_per_image'] = round(float(rec['count'].float().mean()), 1)
     dec_ms, dec_bytes = summ['decode'][1], summ['decode'][2]
     stages['decode']['achieved_GBs'] = round(dec_bytes / (dec_ms * 1e-3) / 1e9, 1)
@@ -360,6 +379,9 @@ def main():
         'warmup': args.warmup,
         'ms_per_step': round(elapsed / args.steps * 1e3, 3),
         'kernel_ms_per_step': round(kernel_ms, 3),
+        'timer': ('HIP events on the launch stream; eager runs chain them (the event closing one launch opens the next), so '
+                  'per-kernel times include inter-launch gaps and kernel_ms_per_step ~ ms_per_step by construction'
+                  if not args.graph else 'HIP events on the launch stream around each launch of an eager re-run after the replayed timed region'),
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,

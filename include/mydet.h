@@ -198,7 +198,9 @@ int mydet_decode_f32(int mode,
  *   topk highest (ties: lowest candidate index); per class ascending: greedy NMS on
  *   x1y1x2y2 = (cx-w/2, cy-h/2, cx+w/2, cy+h/2), suppress when (double)IoU > nms_thres;
  *   survivors ordered class ascending, score descending (ties: lowest index).
- * In : bbox [B,N,4], class_idx [B,N] i64, score [B,N].   N < 2^20, class ids < 2^12.
+ * In : bbox [B,N,4], class_idx [B,N] i64, score [B,N].   N < 2^20, class ids in [0, 2^12): an image in which a
+ *      candidate that passes the filter / top-k carries a class id outside that range gets
+ *      count = MYDET_COUNT_BAD_CLASS (-1) and all-zero rows instead of silently aliased classes.
  * Out: count [B] i32; out_bbox [B,topk,4]; out_class [B,topk] i64; out_score [B,topk];
  *      out_index [B,topk] i32 = candidate index in [0,N) of each survivor (rows >= count
  *      are zero-filled).
@@ -217,6 +219,7 @@ int mydet_postprocess_f32(const float *bbox, const int64_t *class_idx, const flo
  *   [CLASS] 512 i64 | [INDEX] 512 i32          (entries >= count are zero)
  * records: B * MYDET_REC_WORDS words, 16-byte aligned.  scratch: B*N*8 bytes.
  */
+#define MYDET_COUNT_BAD_CLASS (-1)
 #define MYDET_REC_TOPK   512
 #define MYDET_REC_COUNT  0
 #define MYDET_REC_BBOX   4

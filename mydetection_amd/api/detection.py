@@ -48,7 +48,8 @@ class Detector():
         # hipGraph replay of forward + post-process per (batch, H, W, conf, nms), captured the second time a shape is seen
         # (a one-off shape is not worth two warm-up passes); MYDET_GRAPH=0 keeps every call eager
         self.use_graph = os.environ.get('MYDET_GRAPH', '1') != '0'
-        self._graphs, self._graph_seen = {}, {}
+        from ..graph import GraphCache
+        self._graphs = GraphCache(int(os.environ.get('MYDET_MAX_GRAPHS', self._MAX_GRAPHS)))
 
     def _init_preprocess(self, cfg):
         self.divisibe = cfg['general.input_divisibility']
@@ -99,7 +100,7 @@ class Detector():
         out = [None] * len(pil_imgs)
         for idxs, rec in self._records_by_size(pil_imgs, **kwargs):
             rows = batched_to_json(rec, [img_ids[j] for j in idxs], eval_type, cat_map)
-            counts = rec['count'].cpu().tolist()
+            counts = ops.check_counts(rec['count'].cpu().tolist())
             o = 0
             for j, k in zip(idxs, counts):
                 out[j] = rows[o:o + k]
@@ -186,21 +187,24 @@ class Detector():
 
     _MAX_GRAPHS = 6
 
+    def reset_graphs(self):
+        """Forget every captured hipGraph (after editing parameters in place, or to release the graphs' activation pools)."""
+        self._graphs.clear()
+
     def _records(self, x, conf_thres, nms_thres):
         """Detection records of one network input batch (boxes in network-input coordinates): a hipGraph replay when
         this (shape, thresholds) has been seen before, the eager launch sequence otherwise."""
         from ..utils.structures import batched_post_process
         key = (tuple(x.shape), float(conf_thres), float(nms_thres))
         if self.use_graph:
-            g = self._graphs.get(key)
-            if g is None and self._graph_seen.get(key, 0) >= 1:
+            cache = self._graphs
+            g = cache.lookup(key)                                    # LRU; drops a graph captured before a weight change
+            if g is None and cache.should_capture(key):
                 from ..graph import GraphedPath
-                if len(self._graphs) >= self._MAX_GRAPHS:            # each graph owns its activations: drop the oldest
-                    self._graphs.pop(next(iter(self._graphs)))
-                g = self._graphs[key] = GraphedPath(self.model, x, conf_thres, nms_thres)
+                g = cache.insert(key, GraphedPath(self.model, x, conf_thres, nms_thres))   # each graph owns its activations
             if g is not None:
                 return {k: v.clone() for k, v in g(x).items()}       # the graph's own record buffers are overwritten by the next replay
-            self._graph_seen[key] = self._graph_seen.get(key, 0) + 1
+            cache.note_eager(key)
         with torch.no_grad():
             bb, ci, sc = self.model.forward_candidates(x)
             return batched_post_process(bb, ci, sc, conf_thres, nms_thres)

@@ -25,6 +25,18 @@ static inline int mydet_cu_count() {
     return n;
 }
 
+// True the first time it is called for the CURRENT device with this `mask` (one bit per device ordinal): function
+// attributes such as the > 64 KiB dynamic-LDS opt-in are per device, so a process that drives several devices must
+// set them on each one (one process per GPU is the deployment, but nothing here relies on it).
+static inline bool mydet_first_on_device(unsigned long long &mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;      // unknown ordinal: always opt in
+    const unsigned long long bit = 1ull << dev;
+    if (mask & bit) return false;
+    mask |= bit;
+    return true;
+}
+
 __device__ __forceinline__ float mydet_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
 
 // Logistic for the swish epilogues of the conv / depthwise / fusion kernels: v_exp_f32 on -v*log2(e) (product formed

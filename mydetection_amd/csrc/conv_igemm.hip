@@ -323,11 +323,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fixup_kernel(const ConvArgs
 template <int BM, int BN, int WM, int WN, int BK, bool CIN32, int ACT, bool RES, bool GATE = false, bool SPLIT = false>
 int launch_inst(const ConvArgs &a, size_t lds, hipStream_t stream) {
     auto kern = &conv_igemm_kernel<BM, BN, WM, WN, BK, CIN32, ACT, RES, GATE, SPLIT>;
-    static bool attr_set = false;                  // > 64 KiB of dynamic LDS needs the opt-in once
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;                  // > 64 KiB of dynamic LDS needs the opt-in once per device
+    if (mydet_first_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(WM * WN * 64), lds, stream, a);
     return mydet_launch_status();

@@ -408,13 +408,12 @@ template <int ACT, bool RES, int NW>
 int launch_nw(WinoArgs a, hipStream_t stream) {
     constexpr int TILES = 8 * NW, NT = 64 * NW;
     constexpr int LDS = (U_BYTES + 8 * 4 * TILES * 16) * (NW == 8 ? 2 : 1);
-    static bool attr_set = false;                  // > 64 KiB of dynamic LDS needs the opt-in once
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;                  // > 64 KiB of dynamic LDS needs the opt-in once per device
+    if (mydet_first_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino_kernel<ACT, RES, NW, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino_kernel<ACT, RES, NW, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
     }
     a.nblk = (int)(((int64_t)a.MT + TILES - 1) / TILES) * a.ntn;
     a.nk = a.Cin >> 3;

@@ -325,11 +325,10 @@ __global__ void wino4_weights_kernel(const float *w, int Cout, int Cin, int Cout
 
 template <int ACT, bool RES>
 int launch_w4(W4Args a, hipStream_t stream) {
-    static bool attr_set = false;                      // > 64 KiB of dynamic LDS needs the opt-in once
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;                      // > 64 KiB of dynamic LDS needs the opt-in once per device
+    if (mydet_first_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino4_kernel<ACT, RES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
     }
     hipLaunchKernelGGL(wino4_input_kernel, dim3((a.MT + TILES - 1) / TILES, (a.Cin + 7) / 8), dim3(256), 0, stream, a);
     hipLaunchKernelGGL((conv_wino4_kernel<ACT, RES>), dim3(a.nblk), dim3(64 * NW), LDS_BYTES, stream, a);

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(NT) void postprocess_kernel(const PPArgs p) {
     __shared__ int s_cls[KMAX], s_segend[KMAX];
     __shared__ int s_cnt[3];
     __shared__ unsigned long long s_removed[8];
-    __shared__ int s_n, s_nsel;
+    __shared__ int s_n, s_nsel, s_bad;
 
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(NT) void postprocess_kernel(const PPArgs p) {
     unsigned long long *keys = p.scratch + (int64_t)b * p.N;
     const int N = (int)p.N;
 
-    if (tid == 0) { s_n = 0; s_nsel = 0; }
+    if (tid == 0) { s_n = 0; s_nsel = 0; s_bad = 0; }
     __syncthreads();
     // 1. filter (>= in float32, as `self.scores >= conf_thres`)
     //    Eight independent loads in flight per thread; a wave reserves its slots with ONE LDS atomic (ballot +
@@ -226,13 +226,15 @@ __global__ __launch_bounds__(NT) void postprocess_kernel(const PPArgs p) {
                 const int pos = atomicAdd(&s_nsel, 1);
                 const unsigned idx = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
                 const unsigned su = (unsigned)(k >> 32);
-                const unsigned long long c = (unsigned long long)ci[idx] & 0xFFFull;
-                s_key[pos] = (c << CLS_SHIFT) | ((unsigned long long)(~su) << IDX_BITS) | (unsigned long long)idx;
+                const unsigned long long c = (unsigned long long)ci[idx];       // negative ids wrap to huge values
+                if (c > 0xFFFull) s_bad = 1;                                    // the sort key has 12 class bits
+                s_key[pos] = ((c & 0xFFFull) << CLS_SHIFT) | ((unsigned long long)(~su) << IDX_BITS) | (unsigned long long)idx;
             }
         }
     }
     __syncthreads();
     const int nsel = s_nsel;
+    const bool bad = s_bad != 0;       // a selected candidate's class id is outside [0, 4096): fail the image loudly
     for (int k = 2; k <= KMAX; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             if (tid < KMAX) {
@@ -402,7 +404,8 @@ __global__ __launch_bounds__(NT) void postprocess_kernel(const PPArgs p) {
             if (w < myw) before += pc;
             total += pc;
         }
-        if (tid < nsel) {
+        if (bad) total = 0;
+        if (tid < nsel && !bad) {
             const unsigned long long kept = ~s_removed[myw];
             if ((kept >> (tid & 63)) & 1ull) {
                 const int pos = before + __popcll(kept & ((1ull << (tid & 63)) - 1ull));
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(NT) void postprocess_kernel(const PPArgs p) {
         p.oscore[b * p.oscore_st + r] = 0.f;
         p.oidx[b * p.oidx_st + r] = 0;
     }
-    if (tid <= p.count_pad) p.count[b * p.count_st + tid] = tid == 0 ? total : 0;
+    if (tid <= p.count_pad) p.count[b * p.count_st + tid] = tid == 0 ? (bad ? MYDET_COUNT_BAD_CLASS : total) : 0;
 }
 
 }  // namespace

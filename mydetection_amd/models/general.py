@@ -60,6 +60,18 @@ class OneStageBBox(torch.nn.Module):
         self.check_gt_assignment = cfg.get('train.check_gt_assignment', False)
         self.bb_format = cfg.get('general.pred_bbox_format', 'cxcywh')
         self.input_format = cfg['general.input_format']
+        self.weights_epoch = 0
+
+    # captured hipGraphs (graph.GraphedPath) record the addresses of the kernel-ready parameter copies; the epoch tells
+    # them that the parameters were replaced (in-place edits of single tensors are seen by the eager path through the
+    # tensors' version counters, but not by a captured graph: call Detector.reset_graphs() after such an edit)
+    def load_state_dict(self, *args, **kwargs):
+        self.weights_epoch += 1
+        return super().load_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.weights_epoch += 1
+        return super()._apply(fn, *args, **kwargs)
 
     def forward_candidates(self, x):
         '''x [B,3,H,W] -> (bbox [B,N,4], class_idx [B,N] i64, score [B,N]) on the device.'''

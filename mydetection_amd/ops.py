@@ -123,14 +123,24 @@ _WINO4_WS = {}
 
 def wino4_workspace(device, nbytes):
     """Per-device scratch for the transform-domain input of the F(4x4,3x3) kernel: grows to the largest layer seen
-    (stream-ordered reuse; one stream per process).  A hipGraph must be captured after an eager pass has sized it."""
+    (stream-ordered reuse; one stream per process).  A hipGraph must be captured after an eager pass has sized it.
+    Growth REPLACES the buffer: whoever recorded its address (a captured hipGraph) keeps the superseded tensor alive
+    through `live_workspaces` -- graph.GraphedPath does -- so a replay never writes into memory the caching allocator
+    has handed to someone else."""
     key = (device.type, device.index)
     ws = _WINO4_WS.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
-        if torch.cuda.is_current_stream_capturing():
+        if device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
             raise RuntimeError('wino4_workspace: the workspace would grow during stream capture; run the model once eagerly first')
         ws = _WINO4_WS[key] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
     return ws
+
+
+def live_workspaces(device):
+    """The scratch tensors launches on `device` are currently handed (split-K workspace, F(4x4) transform-domain
+    input).  A captured launch sequence holds on to this list for as long as it can be replayed."""
+    key = (device.type, device.index)
+    return [t for t in (_WORKSPACE.get(key), _WINO4_WS.get(key)) if t is not None]
 
 
 def conv_out_size(n, k, stride, pad_lo, pad_hi):
@@ -569,7 +579,8 @@ def postprocess(bbox, class_idx, score, conf_thres, nms_thres, topk=TOPK):
 
     Returns dict of device tensors: count [B] i32, bbox [B,512,4], class_idx [B,512] i64, score [B,512],
     index [B,512] i32 -- all views of 'records' (int32 [B, REC_WORDS]), which the kernel writes directly in the
-    wire layout of the all-gather (parallel.gather_detections).
+    wire layout of the all-gather (parallel.gather_detections).  Class ids must lie in [0, 4096): an image whose
+    selected candidates break that gets count = -1 (`check_counts` raises on it) instead of aliased classes.
     """
     require_gpu(bbox, 'postprocess')
     assert bbox.dtype == torch.float32 and score.dtype == torch.float32 and class_idx.dtype == torch.int64
@@ -586,6 +597,16 @@ def postprocess(bbox, class_idx, score, conf_thres, nms_thres, topk=TOPK):
         TIMER.stop('postprocess', t0, float(B))
     _lib.check(code, 'mydet_postprocess_records_f32')
     return record_views(records)
+
+
+def check_counts(counts):
+    """Raise on the kernel's error sentinel in a host copy of the per-image counts (include/mydet.h:
+    MYDET_COUNT_BAD_CLASS)."""
+    bad = [b for b, k in enumerate(counts) if k < 0]
+    if bad:
+        raise ValueError(f'postprocess: class ids outside [0, 4096) among the selected candidates of image(s) {bad}; '
+                         'the class-aware NMS key holds 12 class bits')
+    return counts
 
 
 def bboxes_iou(a, b, xyxy=False):

@@ -77,6 +77,7 @@ def gather_detections(rec, group=None, always=False, total=None):
 def records_to_objects(rec, img_hw=None, bb_format='cxcywh'):
     """Fixed-size records -> List[ImageObjects] (one host sync for the counts)."""
     from .utils.structures import ImageObjects
-    counts = rec['count'].cpu().tolist()
+    from .ops import check_counts
+    counts = check_counts(rec['count'].cpu().tolist())
     return [ImageObjects(rec['bbox'][b, :k], rec['class_idx'][b, :k], None, rec['score'][b, :k], bb_format, img_hw)
             for b, k in enumerate(counts)]

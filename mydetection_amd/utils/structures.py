@@ -90,7 +90,7 @@ class ImageObjects():
         return self.bboxes.contiguous(), self.cats.contiguous(), self.scores.contiguous()
 
     def _from_records(self, rec, b=0):
-        k = int(rec['count'][b])          # the one host sync: how many survived
+        k = ops.check_counts([int(rec['count'][b])])[0]          # the one host sync: how many survived
         return ImageObjects(rec['bbox'][b, :k], rec['class_idx'][b, :k], None, rec['score'][b, :k],
                             self._bb_format, img_hw=self.img_hw)
 
@@ -226,7 +226,7 @@ def batched_to_json(rec, img_ids, eval_type='x1y1wh', catIdx2id=None) -> list:
         raise NotImplementedError()
     table, host_map = _category_table(catIdx2id, rec['bbox'].device)
     rows, cat = ops.detections_to_json(rec['bbox'], rec['score'], rec['class_idx'], rec['count'], table)
-    counts = rec['count'].cpu().tolist()
+    counts = ops.check_counts(rec['count'].cpu().tolist())
     rows, cat = rows.cpu(), cat.cpu()
     out = []
     for b, (k, img_id) in enumerate(zip(counts, img_ids)):

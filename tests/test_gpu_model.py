@@ -333,16 +333,103 @@ def test_device_preprocess_and_batched_detector(model):
         np.testing.assert_allclose(one.scores.cpu().numpy(), d.scores.cpu().numpy(), rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(one.bboxes.cpu().numpy(), d.bboxes.cpu().numpy(), rtol=1e-5, atol=1e-4)
     # the second call with a shape is captured into a hipGraph, later ones replay it: same detections, bit for bit
-    assert det.use_graph and any(k[0][0] == 1 for k in det._graphs), 'three detect_one calls: the batch-of-1 path is a graph by now'
+    assert det.use_graph and any(k[0][0] == 1 for k in det._graphs.graphs), 'three detect_one calls: the batch-of-1 path is a graph by now'
     for _ in range(3):
         again = det.predict_batch(imgs, **kw)
         for d, e in zip(batch, again):
             assert torch.equal(d.cats, e.cats) and torch.equal(d.scores, e.scores) and torch.equal(d.bboxes, e.bboxes)
-    assert any(k[0][0] == 3 for k in det._graphs) and len(det._graphs) == 2
+    assert any(k[0][0] == 3 for k in det._graphs.graphs) and len(det._graphs.graphs) == 2
     det.use_graph = False
     eager = det.predict_batch(imgs, **kw)
     for d, e in zip(batch, eager):
         assert torch.equal(d.cats, e.cats) and torch.equal(d.scores, e.scores) and torch.equal(d.bboxes, e.bboxes)
+
+
+def test_graph_survives_workspace_growth_and_weight_reload(model, monkeypatch):
+    """A captured hipGraph replays raw addresses: (1) when a larger layer makes ops.wino4_workspace swap its buffer
+    for a bigger one, the superseded buffer must stay allocated while a graph that recorded it can still be replayed
+    -- a replay must give the eager records and must not touch tensors allocated after the growth; (2) a graph
+    captured before load_state_dict must not be replayed with the old kernel-ready weights."""
+    from mydetection_amd import ops, synth
+    from mydetection_amd.api import Detector
+    from mydetection_amd.utils.structures import batched_post_process
+    m, cfg = model
+    monkeypatch.setattr(ops, 'WINO4_MIN_ITEMS', 1)            # every 3x3 layer with Cin >= 64 on the F(4x4) pair -> uses the workspace
+    dev = torch.device('cuda', torch.cuda.current_device())
+    ops._WINO4_WS.pop((dev.type, dev.index), None)            # start from no workspace: the small shape sizes it
+    det = Detector(model_and_cfg=(m, cfg))
+    conf, nms = 0.005, 0.45
+    small = synth.make_images(1, 128, seed=5).cuda()
+    large = synth.make_images(2, 256, seed=6).cuda()
+    with torch.no_grad():
+        eager_small = {k: v.clone() for k, v in batched_post_process(*m.forward_candidates(small), conf, nms).items()}
+    assert int(eager_small['count'][0]) > 0
+    det._records(small, conf, nms)                             # seen once
+    first = det._records(small, conf, nms)                     # captured + replayed
+    assert len(det._graphs.graphs) == 1
+    g = next(iter(det._graphs.graphs.values()))
+    ws_small = ops.live_workspaces(dev)[-1]
+    assert any(t.data_ptr() == ws_small.data_ptr() for t in g._held[0])
+    for k in ('count', 'bbox', 'score', 'class_idx', 'index'):
+        assert torch.equal(first[k], eager_small[k]), k
+    with torch.no_grad():                                      # a larger input, eagerly: the workspace is replaced
+        m.forward_candidates(large)
+    ws_large = ops.live_workspaces(dev)[-1]
+    assert ws_large.numel() > ws_small.numel() and ws_large.data_ptr() != ws_small.data_ptr()
+    ptr_small, n_small = ws_small.data_ptr(), ws_small.numel()
+    del ws_small
+    torch.cuda.synchronize()
+    # bystanders: fresh allocations of the superseded buffer's size class; had that block gone back to the caching
+    # allocator, one of these would sit on it and the replay's transform launch would scribble over it
+    bystanders = [torch.full((n_small,), 7.25, dtype=torch.float32, device=dev) for _ in range(4)]
+    assert all(b.data_ptr() != ptr_small for b in bystanders)
+    again = det._records(small, conf, nms)                     # replay of the graph captured with the OLD workspace
+    torch.cuda.synchronize()
+    for k in ('count', 'bbox', 'score', 'class_idx', 'index'):
+        assert torch.equal(again[k], eager_small[k]), k
+    for b in bystanders:
+        assert bool((b == 7.25).all())
+    # (2) new weights: the cached graph is dropped, the records follow the new parameters
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd2 = dict(sd)
+    key = 'rpn.heads.conv_0.bias'
+    sd2[key] = sd[key] + 0.5
+    m.load_state_dict(sd2, strict=True)
+    try:
+        assert g.stale()
+        with torch.no_grad():
+            eager_new = batched_post_process(*m.forward_candidates(small), conf, nms)
+        got = det._records(small, conf, nms)
+        assert g not in det._graphs.graphs.values()
+        assert not torch.equal(eager_new['score'], eager_small['score'])
+        for k in ('count', 'bbox', 'score', 'class_idx', 'index'):
+            assert torch.equal(got[k], eager_new[k]), k
+    finally:
+        m.load_state_dict(sd, strict=True)
+        ops._WINO4_WS.pop((dev.type, dev.index), None)
+
+
+def test_postprocess_flags_out_of_range_class_ids():
+    """Class ids outside the 12 bits of the NMS sort key must not alias silently: the image's count becomes -1 and the
+    host readers raise (include/mydet.h: MYDET_COUNT_BAD_CLASS)."""
+    from mydetection_amd import ops
+    from mydetection_amd.parallel import records_to_objects
+    rng = np.random.Generator(np.random.PCG64(3))
+    n = 300
+    bb = torch.from_numpy(rng.uniform(10, 200, size=(2, n, 4)).astype(np.float32)).cuda()
+    sc = torch.from_numpy(rng.uniform(0.1, 1.0, size=(2, n)).astype(np.float32)).cuda()
+    ci = torch.from_numpy(rng.integers(0, 80, size=(2, n))).cuda()
+    ci[1, 17] = 4096 + 3                                       # would alias to class 3
+    rec = ops.postprocess(bb, ci, sc, 0.05, 0.45)
+    cnt = rec['count'].cpu().tolist()
+    assert cnt[0] > 0 and cnt[1] == -1
+    assert not bool(rec['bbox'][1].any()) and not bool(rec['score'][1].any())
+    with pytest.raises(ValueError):
+        records_to_objects(rec)
+    ci[1, 17] = -5
+    assert ops.postprocess(bb, ci, sc, 0.05, 0.45)['count'].cpu().tolist()[1] == -1
+    sc[1, 17] = 0.0                                            # below the threshold: never selected, never looked at
+    assert ops.postprocess(bb, ci, sc, 0.05, 0.45)['count'].cpu().tolist()[1] > 0
 
 
 def test_full_size_properties_batch32_640(model):

@@ -194,3 +194,66 @@ def test_detector_geometry_matches_reference_golden(golden):
         canvas[top:top + pil.height, left:left + pil.width] = np.array(pil)
         t = image_ops.format_tensor_img(image_ops.to_tensor(PIL.Image.fromarray(canvas)), fmt)
         assert np.array_equal(t.numpy(), ref), (i, mode)
+
+
+def test_graph_cache_policy_and_workspace_refs():
+    """Host bookkeeping behind the captured hipGraphs (no GPU call): the LRU moves hits to the young end, an eviction
+    forgets the evicted key's sightings and doubles the sightings a key needs before it is captured (a workload cycling
+    through more shapes than the cache holds stops capturing), stale graphs are dropped on lookup; a superseded
+    F(4x4) workspace stays alive for whoever holds `ops.live_workspaces`."""
+    import torch
+    from mydetection_amd import ops
+    from mydetection_amd.graph import GraphCache
+
+    class G:
+        def __init__(self):
+            self.old = False
+
+        def stale(self):
+            return self.old
+
+    c = GraphCache(capacity=2)
+    assert not c.should_capture('a')
+    c.note_eager('a')
+    assert c.should_capture('a')
+    ga = c.insert('a', G())
+    c.note_eager('b')
+    gb = c.insert('b', G())
+    assert c.lookup('a') is ga                      # hit: 'a' becomes the youngest
+    c.note_eager('c')
+    c.insert('c', G())                              # evicts 'b' (the oldest), not 'a'
+    assert c.lookup('b') is None and c.lookup('a') is ga and c.evictions == 1 and c.need == 2
+    assert 'b' not in c.seen
+    c.note_eager('b')
+    assert not c.should_capture('b')                # needs two sightings now
+    c.note_eager('b')
+    assert c.should_capture('b')
+    # cycling through 5 keys with room for 2: captures die out instead of happening on every other call
+    c = GraphCache(capacity=2)
+    for _ in range(200):
+        for k in 'vwxyz':
+            if c.lookup(k) is None:
+                if c.should_capture(k):
+                    c.insert(k, G())
+                else:
+                    c.note_eager(k)
+    assert c.captures < 40, c.captures
+    ga.old = True
+    c2 = GraphCache(capacity=2)
+    c2.insert('a', ga)
+    assert c2.lookup('a') is None and 'a' not in c2.graphs
+    del gb
+
+    dev = torch.device('cpu')
+    ops._WINO4_WS.pop((dev.type, dev.index), None)
+    ws1 = ops.wino4_workspace(dev, 1024)
+    held = ops.live_workspaces(dev)
+    p1 = ws1.data_ptr()
+    del ws1
+    ws2 = ops.wino4_workspace(dev, 1 << 20)
+    assert ws2.data_ptr() != p1 and any(t.data_ptr() == p1 for t in held)       # the old block is still owned by `held`
+    assert ops.wino4_workspace(dev, 4096) is ws2                                 # no shrink, no churn
+    ops._WINO4_WS.pop((dev.type, dev.index), None)
+    with __import__('pytest').raises(ValueError):
+        ops.check_counts([3, -1, 0])
+    assert ops.check_counts([0, 5]) == [0, 5]

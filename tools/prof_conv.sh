@@ -1,9 +1,11 @@
 #!/bin/bash
 # Per-kernel durations of one bench_conv.py configuration (rocprofv3 kernel trace).  usage: prof_conv.sh <bench_conv args>
+# every GPU command runs under `timeout -k 5`: an abort or a stuck process cannot hold the GPU lease for minutes
+T=${MYDET_TOOL_TIMEOUT:-300}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/prof_conv; mkdir -p $R/gpurun_out/prof_conv
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_conv -- python3 $R/tools/bench_conv.py "$@" > $R/gpurun_out/prof_conv/log.txt 2>&1 || { tail -5 $R/gpurun_out/prof_conv/log.txt; exit 1; }
+timeout -k 5 $T rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_conv -- python3 $R/tools/bench_conv.py "$@" > $R/gpurun_out/prof_conv/log.txt 2>&1 || { tail -5 $R/gpurun_out/prof_conv/log.txt; exit 1; }
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob('$R/gpurun_out/prof_conv/**/*kernel_trace.csv', recursive=True)[0]

@@ -1,10 +1,12 @@
 #!/bin/bash
 # Durations of every dispatch of kernels matching $1 in one bench.py run, grouped by grid size.
 #   trace_kernel.sh <substring> <bench args...>
+# every GPU command runs under `timeout -k 5`: an abort or a stuck process cannot hold the GPU lease for minutes
+T=${MYDET_TOOL_TIMEOUT:-300}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; SUB=$1; shift
 rm -rf $R/gpurun_out/trace; mkdir -p $R/gpurun_out/trace
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline "$@" > $R/gpurun_out/trace/log.txt 2>&1 || { tail -5 $R/gpurun_out/trace/log.txt; exit 1; }
+timeout -k 5 $T rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline "$@" > $R/gpurun_out/trace/log.txt 2>&1 || { tail -5 $R/gpurun_out/trace/log.txt; exit 1; }
 python3 - "$SUB" <<PY
 import csv, glob, collections, sys
 sub = sys.argv[1]
