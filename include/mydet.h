@@ -150,6 +150,21 @@ int mydet_upsample_concat_f32(const float *a, int64_t lda, int Ha, int Wa, int C
                               const float *b, int64_t ldb, int C2,
                               float *y, int64_t ldy, int B, int Ho, int Wo, void *stream);
 
+/* Focus.forward of the Ultralytics backbone (external/ultralytics/common.py:79-86): 2x2 space-to-depth,
+ *   y[b, yo, xo, g*C + c] = x[b, c, 2*yo + dy, 2*xo + dx],  g = 0:(dy 0, dx 0) 1:(dy 1, dx 0) 2:(dy 0, dx 1) 3:(dy 1, dx 1)
+ * -- the channel order of torch.cat([x[..., ::2, ::2], x[..., 1::2, ::2], x[..., ::2, 1::2], x[..., 1::2, 1::2]], 1).
+ * x: logical [B,C,H,W] read through its element strides (sb, sc, sh, sw), H and W even; y: channels-last
+ * [B,H/2,W/2,ldy], ldy >= 4C, ldy % 4 == 0.  The 3x3 conv that follows is mydet_conv2d_igemm_f32 on 4C channels. */
+int mydet_space_to_depth_f32(const float *x, int64_t sb, int64_t sc, int64_t sh, int64_t sw, float *y, int64_t ldy,
+                             int B, int C, int H, int W, void *stream);
+
+/* SPP.forward of the Ultralytics backbone (external/ultralytics/common.py:59-70), the part between its two convs:
+ *   y[..., 0:C] = x,  y[..., C:2C] = maxpool_k0(x),  y[..., 2C:3C] = maxpool_k1(x),  y[..., 3C:4C] = maxpool_k2(x)
+ * with nn.MaxPool2d(kernel_size=k, stride=1, padding=k//2) (-inf padding); k0 <= k1 <= k2 odd (5, 9, 13).
+ * x [B,H,W,ldx], y [B,H,W,ldy], C % 4 == 0, ldy >= 4C. */
+int mydet_spp_concat_f32(const float *x, int64_t ldx, float *y, int64_t ldy, int B, int H, int W, int C, int k0, int k1,
+                         int k2, void *stream);
+
 /* Box decode of one pyramid level: raw head logits -> (bbox cxcywh, class_idx, score)
  * for every candidate, written into the level's slice [n_off, n_off + A*H*W) of the
  * per-image candidate arrays (models/general.py:74-76 concatenates levels along dim 1).

@@ -108,6 +108,25 @@ def _build():
                             (272.3, 199.2), (238.8, 321.5), (373.1, 258.9)]))
     c.update(_test(640, 0.5))
     out['d1_yv3'] = c
+
+    # YOLOv5-m trunk + pyramid under the YOLOv3 head / decode, and under the anchor-free FCOS2 decode
+    # (configs/u5m_yv3.json, configs/u5m_fcs2.json)
+    ul = {'model.ultralytics.first': 'Focus', 'model.ultralytics.depth_muliple': 0.67, 'model.ultralytics.channel_muliple': 0.75}
+    c = _general('RGB_1', 32)
+    c.update(_pyramid('ultralytics', 3, 'ultralytics'))
+    c.update(ul)
+    c.update({'model.rpn.name': 'yolov3', 'model.pred_layer': 'YOLO'})
+    c.update(_yolo_anchors([(10, 13), (16, 30), (33, 23), (30, 61), (62, 45), (59, 119), (116, 90), (156, 198), (373, 326)]))
+    c.update(_test(640, 0.45))
+    out['u5m_yv3'] = c
+
+    c = _general('RGB_1', 32)
+    c.update(_pyramid('ultralytics', 3, 'ultralytics'))
+    c.update(ul)
+    c.update({'model.rpn.name': 'yolov3', 'model.yolo.num_anchor_per_level': 1, 'model.pred_layer': 'FCOS2',
+              'model.fcos.anchors': [0, 64, 128, 100000000], 'model.fcos2.ignored_threshold': 0.7})
+    c.update(_test(640, 0.45))
+    out['u5m_fcs2'] = c
     return out
 
 

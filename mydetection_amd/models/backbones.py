@@ -33,6 +33,52 @@ class Darknet53(nn.Module):
         return feats
 
 
+class UltralyticsBackbone(nn.Module):
+    """YOLOv5 trunk (reference: models/backbones.py:60-113): Focus, then four stride-2 Conv stages with Bottleneck /
+    BottleneckCSP / SPP blocks scaled by model.ultralytics.depth_muliple / channel_muliple (the reference's spelling);
+    returns the features at strides 8, 16, 32.  netlist indices, and with them the state_dict keys, are the reference's."""
+    def __init__(self, global_cfg):
+        super().__init__()
+        import math
+        from ..external.ultralytics.common import Focus, Bottleneck, BottleneckCSP, Conv, SPP
+        depm = global_cfg['model.ultralytics.depth_muliple']
+        chm = global_cfg['model.ultralytics.channel_muliple']
+        ch = [int(math.ceil(c * chm / 8) * 8) for c in (64, 128, 256, 512, 1024)]
+
+        def reps(n):
+            return max(round(n * depm), 1)
+        self.feature_chs = ch[2:]
+        self.feature_strides = [8, 16, 32]
+        self.netlist = nn.ModuleList()
+        if global_cfg['model.ultralytics.first'] == 'Focus':
+            assert global_cfg.get('general.input.frame_concatenation', 1) == 1
+            self.netlist.append(Focus(3, ch[0], k=3))
+        else:                                   # 'Conv2d' raises in the reference too (models/backbones.py:82-83)
+            raise NotImplementedError()
+        self.netlist.append(Conv(ch[0], ch[1], k=3, s=2))                                        # 4x
+        self.netlist.append(nn.Sequential(*[Bottleneck(ch[1], ch[1]) for _ in range(reps(3))]))
+        self.netlist.append(Conv(ch[1], ch[2], k=3, s=2))                                        # 8x
+        self.netlist.append(BottleneckCSP(ch[2], ch[2], n=reps(9)))
+        self.netlist.append(Conv(ch[2], ch[3], k=3, s=2))                                        # 16x
+        self.netlist.append(BottleneckCSP(ch[3], ch[3], n=reps(9)))
+        self.netlist.append(Conv(ch[3], ch[4], k=3, s=2))                                        # 32x
+        self.netlist.append(SPP(ch[4], ch[4], k=[5, 9, 13]))
+        self.netlist.append(BottleneckCSP(ch[4], ch[4], n=reps(6)))
+
+    def forward(self, x):
+        assert x.dim() == 4 and x.shape[2] % 32 == 0 and x.shape[3] % 32 == 0
+        features = []
+        for module in self.netlist:             # a feature is tapped wherever the next module halves the map
+            y = module(x)
+            if y.shape[2:4] != x.shape[2:4]:
+                assert y.shape[2] == x.shape[2] // 2
+                features.append(x)
+            x = y
+        features.append(x)
+        assert len(features) == 6
+        return features[3:]
+
+
 class _PoolAfter(ConvBn):
     """nn.Sequential(Conv2d, BatchNorm2d, MaxPool2d(3, 2, 1)): fused conv+BN launch, then the pool kernel."""
     def __init__(self, in_ch, out_ch, k, padding):

@@ -61,6 +61,29 @@ class YOLOBranch(nn.Module):
         return x, feature
 
 
+class UltralyticsFPN(nn.Module):
+    """YOLOv5 top-down pyramid (reference: models/fpns.py:77-107): P5 = CSP(C5); P4 = CSP(Conv1x1(cat(up2x(P5), C4)));
+    P3 likewise from P4.  Upsampling and concatenation are one launch.  The CSP depth is scaled with the CHANNEL
+    multiple, as the reference does (models/fpns.py:88)."""
+    def __init__(self, global_cfg):
+        super().__init__()
+        from ..external.ultralytics.common import BottleneckCSP, Conv
+        assert global_cfg['model.backbone.num_levels'] == 3
+        ch3, ch4, ch5 = global_cfg['model.backbone.out_channels']
+        chm = global_cfg['model.ultralytics.channel_muliple']
+        n = max(round(3 * chm), 1)
+        self.to_p5 = BottleneckCSP(ch5, ch5, n=n, shortcut=False)
+        self.to_p4 = nn.Sequential(Conv(ch4 + ch5, ch4, k=1, s=1), BottleneckCSP(ch4, ch4, n=n, shortcut=False))
+        self.to_p3 = nn.Sequential(Conv(ch3 + ch4, ch3, k=1, s=1), BottleneckCSP(ch3, ch3, n=n, shortcut=False))
+
+    def forward(self, features):
+        c3, c4, c5 = features
+        p5 = self.to_p5(c5)
+        p4 = self.to_p4(ops.upsample_concat(p5, (p5.shape[2] * 2, p5.shape[3] * 2), c4))      # cat([up(p5), c4], 1)
+        p3 = self.to_p3(ops.upsample_concat(p4, (p4.shape[2] * 2, p4.shape[3] * 2), c3))
+        return [p3, p4, p5]
+
+
 def get_bifpn(cfg: dict):
     '''repeat_num stacked BiFPN layers; only the first projects the backbone channels (reference: models/fpns.py:294-312)'''
     in_channels = cfg['model.backbone.out_channels']

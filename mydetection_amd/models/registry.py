@@ -54,13 +54,20 @@ def _efficientnet(cfg):
     return net, net.feature_chs, net.feature_strides
 
 
+def _ultralytics(cfg):
+    """YOLOv5 trunk (models/registry.py:25-28)."""
+    net = _resolve(('backbones', 'UltralyticsBackbone'))(cfg)
+    return net, net.feature_chs, net.feature_strides
+
+
 def get_backbone(cfg: dict):
     '''
     Backbone network for cfg['model.backbone.name']; records its output channels and strides in cfg
     (reference: models/registry.py:4-40)
     '''
     name = cfg['model.backbone.name']
-    build = _darknet53 if name == 'dark53' else _efficientnet if name.startswith('efficientnet') else None
+    build = (_darknet53 if name == 'dark53' else _ultralytics if name == 'ultralytics'
+             else _efficientnet if name.startswith('efficientnet') else None)
     if build is None:
         raise Exception('Unknown backbone name')
     backbone, cfg['model.backbone.out_channels'], cfg['model.backbone.out_strides'] = build(cfg)
@@ -76,6 +83,8 @@ def get_fpn(cfg: dict):
     strides = cfg['model.backbone.out_strides']
     if name == 'yolov3':
         fpn, channels = _resolve(('fpns', 'YOLOv3FPN'))(cfg), cfg['model.backbone.out_channels']
+    elif name == 'ultralytics':
+        fpn, channels = _resolve(('fpns', 'UltralyticsFPN'))(cfg), cfg['model.backbone.out_channels']
     elif name == 'bifpn':
         fpn = _resolve(('fpns', 'get_bifpn'))(cfg)
         channels = [cfg['model.bifpn.out_ch']] * len(cfg['model.backbone.out_channels'])

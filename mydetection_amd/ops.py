@@ -510,6 +510,39 @@ def upsample_concat(a, size, b=None):
     return out
 
 
+def space_to_depth(x):
+    """Focus' 2x2 space-to-depth (external/ultralytics/common.py:84-86): [B,C,H,W] (any strides) -> [B,4C,H/2,W/2]
+    channels-last, channel g*C + c with g = 0:(dy 0,dx 0) 1:(1,0) 2:(0,1) 3:(1,1)."""
+    require_gpu(x, 'space_to_depth')
+    assert x.dtype == torch.float32 and x.dim() == 4
+    B, C, H, W = x.shape
+    assert H % 2 == 0 and W % 2 == 0
+    out, ldy = empty_nhwc(B, 4 * C, H // 2, W // 2, x.device)
+    sb, sc, sh, sw = x.stride()
+    t0 = TIMER.start() if TIMER else None
+    code = _lib.lib().mydet_space_to_depth_f32(_ptr(x), sb, sc, sh, sw, _ptr(out), ldy, B, C, H, W, _stream())
+    if t0:
+        TIMER.stop('space_to_depth', t0, *[8.0 * B * C * H * W] * 2)
+    _lib.check(code, 'mydet_space_to_depth_f32')
+    return out
+
+
+def spp_concat(x, ks=(5, 9, 13)):
+    """cat([x] + [max_pool2d(x, k, 1, k // 2) for k in ks], 1) in one pass (external/ultralytics/common.py:68-70)."""
+    require_gpu(x, 'spp_concat')
+    assert len(ks) == 3
+    x, ldx = to_nhwc(x)
+    B, C, H, W = x.shape
+    assert C % 4 == 0
+    out, ldy = empty_nhwc(B, 4 * C, H, W, x.device)
+    t0 = TIMER.start() if TIMER else None
+    code = _lib.lib().mydet_spp_concat_f32(_ptr(x), ldx, _ptr(out), ldy, B, H, W, C, int(ks[0]), int(ks[1]), int(ks[2]), _stream())
+    if t0:
+        TIMER.stop('spp_concat', t0, *[4.0 * B * H * W * C * 5] * 2)
+    _lib.check(code, 'mydet_spp_concat_f32')
+    return out
+
+
 def decode(mode, box, ldbox, box_astride, box_c0, cls, ldcls, cls_astride, cls_c0, conf_c0, anchors_wh, A, C,
            B, H, W, stride, img_hw, bbox, class_idx, score, n_off):
     """Decode one level into bbox[B,N,4] / class_idx[B,N] / score[B,N] at candidate offset n_off."""

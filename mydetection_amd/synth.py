@@ -23,6 +23,8 @@ import torch
 # rms of the FPN output feeding each YOLO head conv, measured once with the
 # recipe below (oracle forward, 512x512 uniform input); used to set head gains.
 _YOLO_HEAD_FEATURE_RMS = {0: 1.14, 1: 1.61, 2: 2.64}
+# the same for the Ultralytics (YOLOv5-m) trunk + pyramid under the YOLO head (u5m_yv3 / u5m_fcs2), 256x256 'rects' input
+_U5M_HEAD_FEATURE_RMS = {0: 1.45, 1: 2.03, 2: 2.31}
 
 
 def _rng(key: str) -> np.random.Generator:
@@ -40,8 +42,9 @@ def _uniform(key, shape, lo, hi):
     return (a * np.float32(hi - lo) + np.float32(lo)).astype(np.float32)
 
 
-def _yolo_head(key, shape, n_cls=80):
+def _yolo_head(key, shape, n_cls=80, feature_rms=None):
     """rpn.heads.conv_{i}.{weight,bias}: row o = a*(5+n_cls) + c  (models/rpns.py:27-33)."""
+    feature_rms = _YOLO_HEAD_FEATURE_RMS if feature_rms is None else feature_rms
     level = int(key.split('conv_')[1].split('.')[0])
     rows = shape[0]
     c = np.arange(rows) % (5 + n_cls)
@@ -51,7 +54,7 @@ def _yolo_head(key, shape, n_cls=80):
         bias = np.where(c < 4, 0.0, np.where(c == 4, -5.0, -4.0)).astype(np.float32)
         return bias + _normal(key, (rows,), std=0.05)
     fan_in = shape[1] * shape[2] * shape[3]
-    rms = _YOLO_HEAD_FEATURE_RMS.get(level, 1.0)
+    rms = feature_rms.get(level, 1.0)
     w = _normal(key, shape)
     return w * (tgt / (np.sqrt(fan_in) * rms)).reshape(-1, 1, 1, 1).astype(np.float32)
 
@@ -186,7 +189,23 @@ def load_calibration(config_name):
     return _CALIB_CACHE[config_name]
 
 
-def make_tensor(key: str, shape, dtype=torch.float32, calib=None, damped=()) -> torch.Tensor:
+def is_ultralytics(template):
+    """True for the state_dict of a model on the Ultralytics trunk (its first module is Focus: netlist.0.conv.conv)."""
+    return 'backbone.netlist.0.conv.conv.weight' in template
+
+
+def ultralytics_residual_bns(template):
+    """BatchNorm weight keys that close a residual branch of the Ultralytics trunk: cv2 of every Bottleneck with a
+    shortcut (external/ultralytics/common.py:28-37) -- the stride-4 stage `netlist.2.{i}` and the `.m.{i}` chains of the
+    backbone's BottleneckCSP blocks (the pyramid's are built with shortcut=False, models/fpns.py:90-98)."""
+    out = set()
+    for k in template:
+        if k.startswith('backbone.netlist.') and k.endswith('.cv2.bn.weight') and (k.split('.')[3] == 'm' or k.split('.')[3].isdigit()):
+            out.add(k)
+    return out
+
+
+def make_tensor(key: str, shape, dtype=torch.float32, calib=None, damped=(), head_rms=None) -> torch.Tensor:
     """The synthetic value of parameter/buffer `key`.  `calib`: the calibration dict of the configuration (final-layer
     gains of the EfficientDet family); `damped`: BatchNorm weight keys of residual branches (residual_project_bns)."""
     shape = tuple(shape)
@@ -194,7 +213,7 @@ def make_tensor(key: str, shape, dtype=torch.float32, calib=None, damped=()) -> 
         return torch.zeros(shape, dtype=torch.int64)
     effdet = is_efficientdet_key(key)
     if key.startswith('rpn.heads.conv_'):
-        arr = _yolo_head(key, shape)
+        arr = _yolo_head(key, shape, feature_rms=head_rms)
     elif effdet and _efdet_last_kind(key) is not None:
         arr = _efdet_last(key, shape, _efdet_last_kind(key), calib or {})
     elif effdet and len(shape) == 1 and key.endswith(('.weight', '.bias')) and _is_bn_key(key):
@@ -209,7 +228,7 @@ def make_tensor(key: str, shape, dtype=torch.float32, calib=None, damped=()) -> 
         fan_in = shape[1] * shape[2] * shape[3]
         arr = _normal(key, shape, std=np.sqrt(1.664 / fan_in))
     elif len(shape) == 1 and key.endswith('.weight'):       # BN gamma
-        damp = '.cbl_1.bn.' in key and key.startswith('backbone.')
+        damp = ('.cbl_1.bn.' in key and key.startswith('backbone.')) or key in damped
         arr = _uniform(key, shape, 0.1, 0.3) if damp else _uniform(key, shape, 0.5, 1.5)
     elif len(shape) == 1 and key.endswith('.bias'):         # BN beta / conv bias
         arr = _normal(key, shape, std=0.1)
@@ -236,12 +255,16 @@ def make_state_dict(template, config_name=None) -> dict:
     statistics come from mydetection_amd/calib/<config_name>.npz when that file exists."""
     calib = load_calibration(config_name) if config_name else {}
     damped = residual_project_bns(template)
+    head_rms = None
+    if is_ultralytics(template):
+        damped = damped | ultralytics_residual_bns(template)
+        head_rms = _U5M_HEAD_FEATURE_RMS
     out = {}
     for k, v in template.items():
         if k in calib:
             out[k] = torch.from_numpy(np.ascontiguousarray(calib[k])).to(v.dtype)
         else:
-            out[k] = make_tensor(k, v.shape, v.dtype, calib, damped)
+            out[k] = make_tensor(k, v.shape, v.dtype, calib, damped, head_rms)
     return out
 
 

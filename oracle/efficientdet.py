@@ -221,8 +221,16 @@ D1_YV3_ANCHORS = [[12.6, 13.2], [23.5, 38.1], [57.3, 32.3], [42.9, 75.5], [106.6
                   [272.3, 199.2], [238.8, 321.5], [373.1, 258.9]]
 
 
-def forward(x, sd, config):
-    """config in {'efficientdet-d1', 'd1_fcs2_atss', 'd1_fcs2', 'd1_fcs2_p3', 'd1_fcs', 'd1_yv3'} -> (bbox [B,N,4], class_idx [B,N],
+def class_margin(cls):
+    """Gap between the two largest class probabilities of every candidate, [B, n] in the decoders' flatten order
+    (class ids are only defined where it exceeds float32 round-off); cls [..., n_cls] logits."""
+    top2 = torch.sigmoid(cls).reshape(cls.shape[0], -1, cls.shape[-1]).topk(2, dim=-1).values
+    return top2[..., 0] - top2[..., 1]
+
+
+def forward(x, sd, config, with_margin=False):
+    """with_margin: also return class_margin of every candidate, [B,N].
+    config in {'efficientdet-d1', 'd1_fcs2_atss', 'd1_fcs2', 'd1_fcs2_p3', 'd1_fcs', 'd1_yv3'} -> (bbox [B,N,4], class_idx [B,N],
     score [B,N]).  d1_fcs2 is d1_fcs2_atss at inference (models/detlayers/fcos2.py:24-69 == :222-251)."""
     img = tuple(x.shape[2:4])
     if config == 'd1_fcs':          # EfDetHead_wCenter + FCOSLayer (models/detlayers/fcos.py:21-68)
@@ -230,15 +238,15 @@ def forward(x, sd, config):
         outs = []
         for lvl, (c, b, ct) in enumerate(head_with_center(feats, sd)):
             raw = {'bbox': b.permute(0, 2, 3, 1), 'conf': ct.permute(0, 2, 3, 1), 'class': c.permute(0, 2, 3, 1)}
-            outs.append(decoders.fcos_decode(raw, img, STRIDES[lvl]))
-        return tuple(torch.cat([o[j] for o in outs], dim=1) for j in range(3))
+            outs.append(decoders.fcos_decode(raw, img, STRIDES[lvl]) + (class_margin(raw['class']),))
+        return tuple(torch.cat([o[j] for o in outs], dim=1) for j in range(4 if with_margin else 3))
     if config == 'd1_yv3':          # EfDetHead (3 anchors, conf = class channel 0) + YOLOLayer on 5 levels
         feats = bifpn(backbone(x, sd, c6c7='maxpool'), sd)
         outs = []
         for lvl, raw in enumerate(raw_dicts(head(feats, sd), 3, 80, True)):
             anch = torch.tensor(D1_YV3_ANCHORS[3 * lvl:3 * lvl + 3], dtype=torch.float32)
-            outs.append(decoders.yolo_decode_raw(raw, STRIDES[lvl], anch))
-        return tuple(torch.cat([o[j] for o in outs], dim=1) for j in range(3))
+            outs.append(decoders.yolo_decode_raw(raw, STRIDES[lvl], anch) + (class_margin(raw['class']),))
+        return tuple(torch.cat([o[j] for o in outs], dim=1) for j in range(4 if with_margin else 3))
     atss = config in ('d1_fcs2_atss', 'd1_fcs2', 'd1_fcs2_p3')
     c6c7 = None if config == 'd1_fcs2_p3' else ('conv' if atss else 'maxpool')
     feats = bifpn(backbone(x, sd, c6c7=c6c7), sd)
@@ -246,7 +254,7 @@ def forward(x, sd, config):
     outs = []
     for lvl, raw in enumerate(raws):
         if atss:
-            outs.append(decoders.fcos_decode(raw, img, STRIDES[lvl]))
+            outs.append(decoders.fcos_decode(raw, img, STRIDES[lvl]) + (class_margin(raw['class']),))
         else:
-            outs.append(decoders.retina_decode(raw, img, STRIDES[lvl], decoders.retina_anchors(STRIDES[lvl])))
-    return tuple(torch.cat([o[j] for o in outs], dim=1) for j in range(3))
+            outs.append(decoders.retina_decode(raw, img, STRIDES[lvl], decoders.retina_anchors(STRIDES[lvl])) + (class_margin(raw['class']),))
+    return tuple(torch.cat([o[j] for o in outs], dim=1) for j in range(4 if with_margin else 3))

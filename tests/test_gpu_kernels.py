@@ -179,6 +179,70 @@ def test_upsample_concat(dev):
     assert torch.equal(y2.cpu(), F.interpolate(a, size=(9, 13), mode='nearest'))
 
 
+def test_ultralytics_blocks(dev):
+    """Focus' space-to-depth (NCHW and channels-last images), SPP's pooled concatenation (bit-exact vs ATen: pure data
+    movement / max), the 12-channel 3x3 Focus conv, and BottleneckCSP's split BatchNorm written into the halves of the
+    concatenated buffer -- each module against the reference's formulation in float64 (external/ultralytics/common.py)."""
+    from mydetection_amd import ops
+    from mydetection_amd.external.ultralytics.common import BottleneckCSP, Focus, SPP
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 3, 12, 20, generator=g)
+    ref = torch.cat([x[..., ::2, ::2], x[..., 1::2, ::2], x[..., ::2, 1::2], x[..., 1::2, 1::2]], 1)
+    assert torch.equal(ops.space_to_depth(x.to(dev)).cpu(), ref)
+    xl = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)                    # channels-last storage, same logical tensor
+    assert torch.equal(ops.space_to_depth(xl.to(dev)).cpu(), ref)
+    for hw in ((8, 8), (20, 20), (5, 13)):
+        t = torch.randn(2, 16, *hw, generator=g)
+        ref = torch.cat([t] + [F.max_pool2d(t, k, 1, k // 2) for k in (5, 9, 13)], 1)
+        assert torch.equal(ops.spp_concat(t.to(dev)).cpu(), ref), hw
+
+    def randomise(mod):
+        with torch.no_grad():
+            for n, p_ in list(mod.named_parameters()) + list(mod.named_buffers()):
+                if n.endswith('running_var'):
+                    p_.copy_(torch.rand(p_.shape, generator=g) + 0.5)
+                elif n.endswith('num_batches_tracked'):
+                    continue
+                elif p_.dim() == 4:
+                    p_.copy_(torch.randn(p_.shape, generator=g) / (p_.shape[1] * p_.shape[2] * p_.shape[3]) ** 0.5)
+                else:
+                    p_.copy_(torch.randn(p_.shape, generator=g) * 0.3 + (1.0 if n.endswith('bn.weight') else 0.0))
+        return mod.eval()
+
+    def bn(z, m):
+        return F.batch_norm(z, m.running_mean.double(), m.running_var.double(), m.weight.double(), m.bias.double(), False, 0.0, m.eps)
+
+    def conv_ref(z, m):             # common.Conv in float64
+        return F.leaky_relu(bn(F.conv2d(z, m.conv.weight.double(), None, m.s, m.k // 2), m.bn), 0.1)
+
+    foc = randomise(Focus(3, 48, k=3))
+    xi = torch.rand(2, 3, 24, 40, generator=g)
+    xd = xi.double()
+    ref = conv_ref(torch.cat([xd[..., ::2, ::2], xd[..., 1::2, ::2], xd[..., ::2, 1::2], xd[..., 1::2, 1::2]], 1), foc.conv)
+    y = foc.to(dev)(xi.to(dev)).cpu().double()
+    assert (y - ref).abs().max() <= 2e-5 * ref.abs().max()
+
+    for shortcut in (True, False):
+        csp = randomise(BottleneckCSP(24, 24, n=2, shortcut=shortcut))
+        t = torch.randn(2, 24, 9, 11, generator=g)
+        td = t.double()
+        h = conv_ref(td, csp.cv1)
+        for b_ in csp.m:
+            r = conv_ref(conv_ref(h, b_.cv1), b_.cv2)
+            h = h + r if b_.add else r
+        cat = torch.cat((F.conv2d(h, csp.cv3.weight.double()), F.conv2d(td, csp.cv2.weight.double())), 1)
+        ref = conv_ref(F.leaky_relu(bn(cat, csp.bn), 0.1), csp.cv4)
+        y = csp.to(dev)(t.to(dev)).cpu().double()
+        assert (y - ref).abs().max() <= 3e-5 * ref.abs().max(), shortcut
+
+    spp = randomise(SPP(32, 32))
+    t = torch.randn(2, 32, 10, 10, generator=g)
+    h = conv_ref(t.double(), spp.cv1)
+    ref = conv_ref(torch.cat([h] + [F.max_pool2d(h, k, 1, k // 2) for k in (5, 9, 13)], 1), spp.cv2)
+    y = spp.to(dev)(t.to(dev)).cpu().double()
+    assert (y - ref).abs().max() <= 3e-5 * ref.abs().max()
+
+
 def test_bboxes_iou_golden(dev, golden):
     from mydetection_amd.utils.bbox_ops import bboxes_iou
     g = golden('bbox_ops')

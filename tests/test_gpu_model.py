@@ -45,30 +45,144 @@ def test_stage_parity_vs_reference_golden(model, golden):
     assert raws[0]['bbox'].shape == (1, 3, 64, 64, 4) and raws[0]['class'].shape == (1, 3, 64, 64, 80)
 
 
-def test_end_to_end_vs_reference_golden(model, golden):
+def _class_ids_exact_where_safe(got, ref, margin, what):
+    """Class ids are exact wherever the reference's two largest class probabilities differ by more than float32
+    round-off (the fixture stores that gap per candidate); such candidates must be all but a handful."""
+    safe = margin > 2e-5
+    assert safe.mean() > 0.995, f'{what}: fixture has too many tied classes'
+    np.testing.assert_array_equal(got[safe], ref[safe], err_msg=what)
+
+
+def _check_yolo_golden(m, g, what):
+    """Candidates and detections of a YOLO-head model against a fixture made by the imported reference: every candidate
+    within north_star's 1e-4, class ids exact where the fixture says they are well defined, detections at the three
+    settings exact (count, class ids, order; scores / boxes 1e-4) whenever the fixture's decision margin exceeds twice
+    the score error observed here -- thousands of long-tailed scores pass 0.005, so gaps at the top-512 cut are ~1e-6
+    (oracle/gen_golden.py:gen_yolov3) -- and in every case equal to the oracle's post_process of THESE candidates."""
     from mydetection_amd import synth
-    m, cfg = model
-    g = golden('yolov3_b1_512')
-    x = synth.make_images(1, 512, seed=0).cuda()
+    from oracle import postprocess as opp
+    x = synth.make_images(int(g['batch']), int(g['size']), seed=int(g['image_seed'])).cuda()
     with torch.no_grad():
-        dts = m(x)
-    assert len(dts) == 1
-    d = dts[0]
-    assert d.bboxes.shape == (16128, 4) and d.cats.dtype == torch.int64
+        d = m(x)[0]
+    n = g['bboxes_0'].shape[0]
+    assert d.bboxes.shape == (n, 4) and d.cats.dtype == torch.int64
     cats, scores, boxes = d.cats.cpu().numpy(), d.scores.cpu().numpy(), d.bboxes.cpu().numpy()
     np.testing.assert_allclose(scores, g['scores_0'], rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(boxes, g['bboxes_0'], rtol=RTOL, atol=ATOL)
-    # class ids: exact wherever the reference's top-2 class logits are not within round-off of each other
-    mism = np.nonzero(cats != g['cats_0'])[0]
-    assert len(mism) <= 2, f'{len(mism)} class-id mismatches'
-    # post-processing at the three reference settings
+    _class_ids_exact_where_safe(cats, g['cats_0'], g['cls_margin_0'], what)
+    err = float(np.abs(scores - g['scores_0']).max())
+    exact_tags = 0
     for tag in ('ap', 'mid', 'demo'):
-        r = d.post_process(float(g[f'pp_{tag}_conf']), float(g[f'pp_{tag}_nms']))
+        conf, nms = float(g[f'pp_{tag}_conf']), float(g[f'pp_{tag}_nms'])
+        r = d.post_process(conf, nms)
+        ob, oc, os_, _ = opp.post_process(boxes, cats, scores, conf, nms)
+        assert len(r) == len(oc)
+        np.testing.assert_array_equal(r.cats.cpu().numpy(), oc)
+        np.testing.assert_array_equal(r.scores.cpu().numpy(), os_)
+        np.testing.assert_array_equal(r.bboxes.cpu().numpy(), ob)
         ref_c, ref_s, ref_b = g[f'pp_{tag}_cats_0'], g[f'pp_{tag}_scores_0'], g[f'pp_{tag}_bboxes_0']
-        assert len(r) == len(ref_c), f'{tag}: {len(r)} vs {len(ref_c)} detections'
-        np.testing.assert_array_equal(r.cats.cpu().numpy(), ref_c)
-        np.testing.assert_allclose(r.scores.cpu().numpy(), ref_s, rtol=RTOL, atol=ATOL)
-        np.testing.assert_allclose(r.bboxes.cpu().numpy(), ref_b, rtol=RTOL, atol=ATOL)
+        same = len(r) == len(ref_c) and np.array_equal(r.cats.cpu().numpy(), ref_c)
+        if float(g[f'pp_{tag}_margin']) > 2 * err:
+            assert same, f'{what} {tag}: decisions differ from the reference although its margin {float(g[f"pp_{tag}_margin"]):.1e} > 2 x {err:.1e}'
+        if same:
+            exact_tags += 1
+            np.testing.assert_allclose(r.scores.cpu().numpy(), ref_s, rtol=RTOL, atol=ATOL)
+            np.testing.assert_allclose(r.bboxes.cpu().numpy(), ref_b, rtol=RTOL, atol=ATOL)
+        else:       # a decision inside the round-off band flipped: the detection sets may differ by the candidates involved
+            assert abs(len(r) - len(ref_c)) <= 4, f'{what} {tag}: {len(r)} vs {len(ref_c)} detections'
+    assert exact_tags >= 2, f'{what}: detections equal the reference\'s at only {exact_tags} of 3 settings'
+    return err
+
+
+def test_end_to_end_vs_reference_golden(model, golden):
+    """BASELINE configs[0] shape (batch 1, 512 x 512) against the imported reference."""
+    m, cfg = model
+    _check_yolo_golden(m, golden('yolov3_b1_512'), 'yolov3 512')
+
+
+def test_end_to_end_vs_reference_golden_640(model, golden):
+    """The benchmark resolution (640 x 640, batch 1) pinned by the imported reference itself: stage samples, head logits,
+    all 25 200 candidates, detections at three settings."""
+    from mydetection_amd import synth
+    m, cfg = model
+    g = golden('yolov3_b1_640')
+    x = synth.make_images(1, 640, seed=int(g['image_seed'])).cuda()
+    with torch.no_grad():
+        c = m.backbone(x)
+        p = m.fpn(c)
+        raws = m.rpn(p)
+    for key, feats in (('backbone', c), ('fpn', p)):
+        for lvl, f in enumerate(feats):
+            assert tuple(g[f'{key}_{lvl}_shape']) == tuple(f.shape)
+            f = f.contiguous().cpu().numpy()
+            np.testing.assert_allclose(f.reshape(-1)[g[f'{key}_{lvl}_idx']], g[f'{key}_{lvl}_val'], rtol=RTOL, atol=ATOL)
+            np.testing.assert_allclose(np.sqrt((f.astype(np.float64) ** 2).sum()), g[f'{key}_{lvl}_l2'], rtol=1e-5)
+    for lvl, raw in enumerate(raws):
+        head = raw.packed['box'][0].contiguous().cpu().numpy()
+        np.testing.assert_allclose(head.reshape(-1)[g[f'head_{lvl}_idx']], g[f'head_{lvl}_val'], rtol=RTOL, atol=ATOL)
+    assert g['bboxes_0'].shape == (25200, 4)
+    _check_yolo_golden(m, g, 'yolov3 640')
+
+
+def test_ultralytics_plugins_vs_reference_golden(golden):
+    """Registry plug-ins 'ultralytics' backbone + FPN (Focus, Conv, Bottleneck, BottleneckCSP, SPP) under the YOLO head,
+    configs/u5m_yv3.json, against the imported reference (batch 1, 256 x 256): stage samples, head logits, every
+    candidate within 1e-4, class ids exact where defined, detections at three settings; and 'u5m_fcs2' (the same trunk
+    under the anchor-free FCOS2 decode) end to end against its CPU oracle composition."""
+    from mydetection_amd import synth
+    from mydetection_amd.models.general import name_to_model
+    g = golden('u5m_yv3_b1_256')
+    m, cfg = name_to_model('u5m_yv3')
+    m.load_state_dict(synth.make_state_dict(m.state_dict(), 'u5m_yv3'), strict=True)
+    m = m.eval().cuda()
+    x = synth.make_images(1, 256, seed=int(g['image_seed'])).cuda()
+    with torch.no_grad():
+        c = m.backbone(x)
+        p = m.fpn(c)
+        raws = m.rpn(p)
+    for key, feats in (('backbone', c), ('fpn', p)):
+        for lvl, f in enumerate(feats):
+            assert tuple(g[f'{key}_{lvl}_shape']) == tuple(f.shape)
+            f = f.contiguous().cpu().numpy()
+            np.testing.assert_allclose(f.reshape(-1)[g[f'{key}_{lvl}_idx']], g[f'{key}_{lvl}_val'], rtol=RTOL, atol=ATOL)
+            np.testing.assert_allclose(np.sqrt((f.astype(np.float64) ** 2).sum()), g[f'{key}_{lvl}_l2'], rtol=1e-5)
+    for lvl, raw in enumerate(raws):
+        head = raw.packed['box'][0].contiguous().cpu().numpy()
+        assert tuple(g[f'head_{lvl}_shape']) == head.shape
+        np.testing.assert_allclose(head.reshape(-1)[g[f'head_{lvl}_idx']], g[f'head_{lvl}_val'], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(raws[2].packed['box'][0].contiguous().cpu().numpy(), g['head_2_full'], rtol=RTOL, atol=ATOL)
+    _check_yolo_golden(m, g, 'u5m_yv3 256')
+    # a batch of 2 at 320 x 256 against the oracle (non-square, every level odd-sized somewhere)
+    from oracle import ultralytics as ou
+    x2 = synth.make_images(2, (320, 256), seed=11)
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ob, oc, os_ = ou.forward(x2, sd)
+        bb, ci, sc = m.forward_candidates(x2.cuda())
+    np.testing.assert_allclose(sc.cpu().numpy(), os_.numpy(), rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(bb.cpu().numpy(), ob.numpy(), rtol=RTOL, atol=ATOL)
+    # u5m_fcs2: same trunk, one anchor, FCOS2 decode (configs/u5m_fcs2.json)
+    from oracle import decoders
+    m2, cfg2 = name_to_model('u5m_fcs2')
+    sd2 = synth.make_state_dict(m2.state_dict(), 'u5m_fcs2')
+    m2.load_state_dict(sd2, strict=True)
+    m2 = m2.eval().cuda()
+    with torch.no_grad():
+        bb, ci, sc = m2.forward_candidates(x2.cuda())
+        outs = []
+        for lvl, r in enumerate(oy_head(ou.forward_features(x2, sd2), sd2)):
+            t = r.permute(0, 2, 3, 1)
+            outs.append(decoders.fcos_decode({'bbox': t[..., 0:4], 'conf': t[..., 4:5], 'class': t[..., 5:]}, (320, 256), (8, 16, 32)[lvl]))
+    ob, oc, os_ = (torch.cat([o[j] for o in outs], dim=1) for j in range(3))
+    assert bb.shape == ob.shape
+    np.testing.assert_allclose(sc.cpu().numpy(), os_.numpy(), rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(bb.cpu().numpy(), ob.numpy(), rtol=RTOL, atol=ATOL)
+    assert (ci.cpu() != oc).float().mean().item() < 1e-3
+
+
+def oy_head(feats, sd):
+    from oracle import yolov3 as oy
+    return oy.yolo_head(feats, sd)
 
 
 def test_batch_consistency_and_post_process_vs_oracle(model):
@@ -108,12 +222,18 @@ def test_forward_vs_oracle_640_batch2(model):
     sd = {k: v.cpu() for k, v in m.state_dict().items()}
     torch.set_num_threads(max(1, torch.get_num_threads()))
     with torch.no_grad():
-        ob, oc, os_ = oy.forward(x, sd)
+        ob, oc, os_, raws = oy.forward(x, sd, return_raw=True)
         bb, ci, sc = m.forward_candidates(x.cuda())
     assert bb.shape == (2, 25200, 4)
     np.testing.assert_allclose(sc.cpu().numpy(), os_.numpy(), rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(bb.cpu().numpy(), ob.numpy(), rtol=RTOL, atol=ATOL)
-    assert (ci.cpu() != oc).sum().item() <= 4
+    # class ids exact wherever the oracle's own two largest class probabilities are further apart than round-off
+    margin = []
+    for r in raws:
+        t = torch.sigmoid(r.view(2, 3, 85, *r.shape[2:])[:, :, 5:].permute(0, 1, 3, 4, 2)).reshape(2, -1, 80).topk(2, dim=-1).values
+        margin.append(t[..., 0] - t[..., 1])
+    for i in range(2):
+        _class_ids_exact_where_safe(ci[i].cpu().numpy(), oc[i].numpy(), torch.cat(margin, dim=1)[i].numpy(), f'yolov3 640 image {i}')
 
 
 def test_detector_api(model, tmp_path):
@@ -147,14 +267,6 @@ def effdet(request):
     return name, m.eval().cuda(), cfg
 
 
-def _assert_class_ids(got, ref, margin, what):
-    """Class ids are exact wherever the reference's two largest class probabilities differ by more than float32
-    round-off (the fixture stores that gap per candidate); such candidates must be all but a handful."""
-    safe = margin > 2e-5
-    assert safe.mean() > 0.995, f'{what}: fixture has too many tied classes'
-    np.testing.assert_array_equal(got[safe], ref[safe], err_msg=what)
-
-
 def test_effdet_family_vs_reference_golden(effdet, golden):
     """Full path through the registry seam (EfficientNet-B1 -> 4x BiFPN -> EfDetHead -> Retina/FCOS/YOLO decode ->
     post_process) against the imported reference (batch 1, 256x256): north_star's gate -- boxes/scores within 1e-4
@@ -185,7 +297,7 @@ def test_effdet_family_vs_reference_golden(effdet, golden):
     assert d.bboxes.shape == (n, 4)
     np.testing.assert_allclose(d.scores.cpu().numpy(), g['scores_0'], rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(d.bboxes.cpu().numpy(), g['bboxes_0'], rtol=RTOL, atol=ATOL)
-    _assert_class_ids(d.cats.cpu().numpy(), g['cats_0'], g['cls_margin_0'], name)
+    _class_ids_exact_where_safe(d.cats.cpu().numpy(), g['cats_0'], g['cls_margin_0'], name)
     for tag in ('ap', 'mid', 'demo'):
         r = d.post_process(float(g[f'pp_{tag}_conf']), float(g[f'pp_{tag}_nms']))
         ref_c, ref_s, ref_b = g[f'pp_{tag}_cats_0'], g[f'pp_{tag}_scores_0'], g[f'pp_{tag}_bboxes_0']
@@ -199,40 +311,53 @@ def test_effdet_family_vs_reference_golden(effdet, golden):
 def test_effdet_family_vs_oracle_640(effdet):
     """640x640 (benchmark resolution), batch 2, against the float32 CPU oracle (= the reference's arithmetic,
     tests/test_oracle_golden.py): every score and box within 1e-4 (rtol and atol), class ids exact wherever the
-    oracle's own top-2 class gap exceeds round-off, and the post-processed detections of every image identical
-    (count, classes, order) at the AP and demo thresholds."""
+    oracle's own top-2 class gap exceeds round-off, and the post-processed detections of BOTH images identical
+    (count, candidate indices, classes, order) at the AP and demo thresholds -- all four (image, threshold) pairs: the
+    images are picked so that no decision of theirs sits within 1e-5 of a boundary."""
     from mydetection_amd import synth
     from mydetection_amd.utils.structures import batched_post_process
     from oracle import efficientdet as oe, postprocess as opp
     name, m, cfg = effdet
-    x = synth.make_normalized_images(2, 640, seed=7)
     sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    nms = cfg['test.nms_thres']
+    # two images all of whose decisions are margin-safe under the ORACLE's own float32 scores at both thresholds (a detection
+    # set is only defined then): chosen here, deterministically, from the seed sequence 7, 8, ...
+    chosen = []
+    for seed in range(7, 31):
+        xi = synth.make_normalized_images(1, 640, seed=seed)
+        with torch.no_grad():
+            _, c1, s1 = oe.forward(xi, sd, name)
+        if all(opp.decision_margins(s1[0].numpy(), c1[0].numpy(), conf, eps=1e-5) is None for conf in (0.005, 0.5)):
+            chosen.append(xi)
+            if len(chosen) == 2:
+                break
+    assert len(chosen) == 2, f'{name}: no two margin-safe image seeds in 7..30'
+    x = torch.cat(chosen, dim=0)
     with torch.no_grad():
-        ob, oc, os_ = oe.forward(x, sd, name)
+        ob, oc, os_, margin = oe.forward(x, sd, name, with_margin=True)
         bb, ci, sc = m.forward_candidates(x.cuda())
     assert bb.shape == ob.shape and bb.shape[1] == {'efficientdet-d1': 76725, 'd1_yv3': 25575, 'd1_fcs2_p3': 8400}.get(name, 8525)
     np.testing.assert_allclose(sc.cpu().numpy(), os_.numpy(), rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(bb.cpu().numpy(), ob.numpy(), rtol=RTOL, atol=ATOL)
+    for i in range(2):
+        _class_ids_exact_where_safe(ci[i].cpu().numpy(), oc[i].numpy(), margin[i].numpy(), f'{name} 640 image {i}')
     flips = (ci.cpu() != oc)
-    assert flips.sum().item() <= 4, f'{flips.sum().item()} class-id differences'     # exact up to numerically tied classes
-    compared = 0
     for conf in (0.005, 0.5):
-        rec = batched_post_process(bb, ci, sc, conf, cfg['test.nms_thres'])
+        rec = batched_post_process(bb, ci, sc, conf, nms)
         for i in range(2):
-            rb, rc, rs, src = opp.post_process(ob[i].numpy(), oc[i].numpy(), os_[i].numpy(), conf, cfg['test.nms_thres'])
+            rb, rc, rs, src = opp.post_process(ob[i].numpy(), oc[i].numpy(), os_[i].numpy(), conf, nms)
             k = int(rec['count'][i])
             assert len(src) >= 50
             order = torch.argsort(os_[i], descending=True, stable=True)
             sel = order[os_[i][order] >= conf][:512]             # the candidates that enter NMS
-            if flips[i][sel].any() or opp.decision_margins(os_[i].numpy(), oc[i].numpy(), conf, eps=1e-5) is not None:
-                continue            # a decision of this image hinges on float32 round-off: the detection set is not defined
-            compared += 1
+            assert not flips[i][sel].any(), 'a class tie among the candidates that enter NMS'
+            # (the batch-of-2 oracle forward may round differently from the solo runs that chose the images: re-check)
+            assert opp.decision_margins(os_[i].numpy(), oc[i].numpy(), conf, eps=5e-6) is None
             assert k == len(src), f'{name} conf {conf} image {i}: {k} vs {len(src)} detections'
             np.testing.assert_array_equal(rec['index'][i, :k].cpu().numpy().astype(np.int64), src)
             np.testing.assert_array_equal(rec['class_idx'][i, :k].cpu().numpy(), rc)
             np.testing.assert_allclose(rec['score'][i, :k].cpu().numpy(), rs, rtol=RTOL, atol=ATOL)
             np.testing.assert_allclose(rec['bbox'][i, :k].cpu().numpy(), rb, rtol=RTOL, atol=ATOL)
-    assert compared >= 2, 'fewer than two margin-safe (image, threshold) pairs: pick another image seed'
 
 
 @pytest.mark.parametrize('name,batch', [('efficientdet-d1', 16), ('d1_fcs2_atss', 32)])

@@ -100,6 +100,33 @@ def test_registry_contract_and_state_dict_keys():
     assert n_params == 61949149
 
 
+def test_ultralytics_plugins_contract():
+    """get_backbone('ultralytics') / get_fpn('ultralytics') (reference: models/registry.py:25-28,53-57): derived cfg keys,
+    the reference's 462 state_dict keys for u5m_yv3 with their shapes (checked key by key against the imported
+    reference when the fixtures were made), the quirks kept (FPN depth scaled by the CHANNEL multiple)."""
+    from mydetection_amd.models import registry
+    from mydetection_amd.models.general import load_config, state_dict_template
+    cfg = load_config('u5m_yv3')
+    with torch.device('meta'):
+        bb = registry.get_backbone(cfg)
+        assert cfg['model.backbone.out_channels'] == [192, 384, 768] and cfg['model.backbone.out_strides'] == [8, 16, 32]
+        fpn = registry.get_fpn(cfg)
+        assert cfg['model.fpn.out_channels'] == [192, 384, 768]
+    assert len(bb.netlist) == 10 and len(bb.netlist[2]) == 2 and len(bb.netlist[4].m) == 6 and len(bb.netlist[9].m) == 4
+    assert len(fpn.to_p5.m) == 2 and not fpn.to_p5.m[0].add and bb.netlist[4].m[0].add
+    sd = state_dict_template('u5m_yv3')
+    assert len(sd) == 462
+    assert sd['backbone.netlist.0.conv.conv.weight'].shape == (48, 12, 3, 3)
+    assert sd['backbone.netlist.4.cv2.weight'].shape == (96, 192, 1, 1) and sd['backbone.netlist.4.bn.weight'].shape == (192,)
+    assert sd['backbone.netlist.8.cv2.conv.weight'].shape == (768, 1536, 1, 1)
+    assert sd['fpn.to_p4.0.conv.weight'].shape == (384, 1152, 1, 1) and sd['fpn.to_p3.1.cv4.bn.running_var'].shape == (192,)
+    assert sd['rpn.heads.conv_2.weight'].shape == (255, 768, 1, 1)
+    sd2 = state_dict_template('u5m_fcs2')
+    assert sd2['rpn.heads.conv_0.weight'].shape == (85, 192, 1, 1) and len(sd2) == 462
+    with pytest.raises(NotImplementedError):
+        registry.get_backbone({**load_config('u5m_yv3'), 'model.ultralytics.first': 'Conv2d'})
+
+
 def test_image_objects_host_logic():
     from mydetection_amd.utils.structures import ImageObjects
     b = torch.tensor([[10., 10., 4., 4.], [20., 20., 6., 2.], [5., 5., 1., 1.]])

@@ -129,6 +129,40 @@ def test_yolov3_post_process_matches_reference(yolov3_oracle_run):
         np.testing.assert_allclose(b, g[f'pp_{tag}_bboxes_0'], rtol=1e-5, atol=1e-4)
 
 
+def test_yolov3_640_and_ultralytics_match_reference(golden):
+    """Oracle restatements at the benchmark resolution (yolov3_80, batch 1, 640 x 640) and of the Ultralytics trunk +
+    pyramid under the YOLO head (u5m_yv3, 256 x 256) vs the imported reference: stage samples, candidates, detections."""
+    from mydetection_amd.models.general import state_dict_template
+    from oracle import ultralytics as ou
+    torch.set_num_threads(8)
+    for name, config, feats_fn, fwd in (('yolov3_b1_640', 'yolov3_80', lambda x, sd: (oy.darknet53(x, sd), oy.forward_features(x, sd)), oy.forward),
+                                        ('u5m_yv3_b1_256', 'u5m_yv3', lambda x, sd: (ou.backbone(x, sd), ou.forward_features(x, sd)), ou.forward)):
+        g = golden(name)
+        sd = synth.make_state_dict(state_dict_template(config), config)
+        x = synth.make_images(int(g['batch']), int(g['size']), seed=int(g['image_seed']))
+        with torch.no_grad():
+            c, p = feats_fn(x, sd)
+            bb, ci, sc, raws = fwd(x, sd, return_raw=True)
+        for key, feats in (('backbone', c), ('fpn', p)):
+            for lvl, f in enumerate(feats):
+                f = f.numpy()
+                assert tuple(g[f'{key}_{lvl}_shape']) == f.shape
+                np.testing.assert_allclose(f.reshape(-1)[g[f'{key}_{lvl}_idx']], g[f'{key}_{lvl}_val'], rtol=1e-5, atol=1e-5)
+        for lvl, r in enumerate(raws):
+            np.testing.assert_allclose(r.numpy().reshape(-1)[g[f'head_{lvl}_idx']], g[f'head_{lvl}_val'], rtol=1e-5, atol=1e-5)
+        safe = g['cls_margin_0'] > 2e-5
+        np.testing.assert_array_equal(ci[0].numpy()[safe], g['cats_0'][safe])
+        np.testing.assert_allclose(sc[0].numpy(), g['scores_0'], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(bb[0].numpy(), g['bboxes_0'], rtol=1e-5, atol=1e-4)
+        assert len(g['pp_ap_cats_0']) >= 50 and float(g['pp_ap_nms']) == 0.45
+        # post_process of the REFERENCE's candidates (so that the comparison does not hinge on oneDNN's summation order)
+        for tag in ('ap', 'mid', 'demo'):
+            b, cc, s_, _ = pp.post_process(g['bboxes_0'], g['cats_0'], g['scores_0'], float(g[f'pp_{tag}_conf']), float(g[f'pp_{tag}_nms']))
+            np.testing.assert_array_equal(cc, g[f'pp_{tag}_cats_0'])
+            np.testing.assert_array_equal(s_, g[f'pp_{tag}_scores_0'])
+            np.testing.assert_array_equal(b, g[f'pp_{tag}_bboxes_0'])
+
+
 @pytest.mark.parametrize('config', ['efficientdet-d1', 'd1_fcs2_atss', 'd1_fcs2', 'd1_fcs', 'd1_yv3', 'd1_fcs2_p3'])
 def test_efficientdet_family_matches_reference(golden, config):
     """Oracle restatement of EfficientNet-B1 + BiFPN + EfDetHead + decode vs the imported reference."""
