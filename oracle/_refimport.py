@@ -129,7 +129,7 @@ def reference_config(config_name):
     return cfg
 
 
-def build_reference_model(config_name):
+def build_reference_model(config_name, recipe='conditioned'):
     """Reference OneStageBBox for configs/<name>.json (or a DERIVED composition) filled with the synthetic weights."""
     import io
     install()
@@ -138,6 +138,6 @@ def build_reference_model(config_name):
     with no_pretrained(), contextlib.redirect_stdout(io.StringIO()):
         from models.general import OneStageBBox
         model = OneStageBBox(cfg)
-    model.load_state_dict(synth.make_state_dict(model.state_dict(), config_name), strict=True)
+    model.load_state_dict(synth.make_state_dict(model.state_dict(), config_name, recipe), strict=True)
     model.eval()
     return model, cfg

@@ -1,6 +1,7 @@
 """Build-container tool: measure BatchNorm running statistics for the EfficientDet-family configs.
 
     python -m oracle.calibrate_bn efficientdet-d1 d1_fcs2_atss
+    python -m oracle.calibrate_bn --stiff efficientdet-d1 d1_fcs2_atss      # the ill-conditioned second parameter set
 
 Runs the imported reference model (eval mode) on two synthetic 512x512 images with a forward
 pre-hook on every BatchNorm2d that sets its running_mean / running_var to the batch statistics of
@@ -23,9 +24,10 @@ MEAN = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
 STD = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
 
 
-def calibrate(name):
-    synth._CALIB_CACHE[name] = {}                       # start from the uncalibrated recipe
-    model, cfg = _refimport.build_reference_model(name)
+def calibrate(name, recipe='conditioned'):
+    ck = name if recipe == 'conditioned' else f'{name}.{recipe}'
+    synth._CALIB_CACHE[ck] = {}                         # start from the uncalibrated recipe
+    model, cfg = _refimport.build_reference_model(name, recipe)
     x = synth.make_images(2, 512, seed=100)
     if cfg['general.input_format'] == 'RGB_1_norm':
         x = (x - MEAN) / STD
@@ -59,12 +61,13 @@ def calibrate(name):
            if k.endswith(('running_mean', 'running_var'))}
     out.update(spread)
     os.makedirs(os.path.join(ROOT, 'mydetection_amd', 'calib'), exist_ok=True)
-    np.savez_compressed(os.path.join(ROOT, 'mydetection_amd', 'calib', name + '.npz'), **out)
-    synth._CALIB_CACHE.pop(name, None)
-    print(name, len(out), 'tensors', sum(v.size for v in out.values()), 'floats')
+    np.savez_compressed(os.path.join(ROOT, 'mydetection_amd', 'calib', ck + '.npz'), **out)
+    synth._CALIB_CACHE.pop(ck, None)
+    print(ck, len(out), 'tensors', sum(v.size for v in out.values()), 'floats')
 
 
 if __name__ == '__main__':
     torch.set_num_threads(8)
-    for n in sys.argv[1:] or ['efficientdet-d1', 'd1_fcs2_atss']:
-        calibrate(n)
+    args = [a for a in sys.argv[1:] if a != '--stiff']
+    for n in args or ['efficientdet-d1', 'd1_fcs2_atss']:
+        calibrate(n, 'stiff' if '--stiff' in sys.argv else 'conditioned')
