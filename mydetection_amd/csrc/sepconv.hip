@@ -12,7 +12,10 @@
 // 5x5 / 10x10 levels do not pay a launch each.
 //
 // One 256-thread workgroup owns an 8x8 output tile of one image, all channels:
-//   1. the 10x10 halo of pre(x) -> LDS (float4 per thread, inputs read once; out-of-image pixels are the conv's zeros)
+//   0. requests that do not depend on the halo go out first (depthwise taps -> LDS, first weight fragments -> registers)
+//   1. the 10x10 halo of pre(x) -> LDS (float4 per thread, inputs read once; out-of-image pixels are the conv's zeros);
+//      every load is unconditional at clamped coordinates and specialised by the node's input modes, so that a batch of
+//      halo entries is in flight at once (a run-time mode switch around each load made hipcc wait for every single one)
 //   2. depthwise 3x3 on the VALU from LDS (same fmaf order as dwconv_kernel), results kept in registers, then stored
 //      over the halo as the [64 px][C+1] operand tile (odd stride: conflict-free fragment reads)
 //   3. pointwise conv on FP32 MFMA, computed transposed (A = weights, B = pixels: v_mfma_f32_16x16x4_f32), so a lane
@@ -131,11 +134,137 @@ __device__ __forceinline__ SpItem sp_decode(const SpArgs &a, int item) {
     return it;
 }
 
+// one fused input at in-image (clamped) coordinates, branch-free: MODE 0 same size, 1 nearest-2x of the half-size map,
+// 2 3x3/2 max pool of the double-size map (-inf padding: taps outside the map do not enter the max)
+template <int MODE>
+__device__ __forceinline__ f32x4 sp_read_m(const float *x, int64_t ld, int H, int W, int64_t b, int oh, int ow, int q) {
+    if (MODE == 0) return *reinterpret_cast<const f32x4 *>(x + ((b * H + oh) * W + ow) * ld + q * 4);
+    if (MODE == 1) {
+        const int Hs = H >> 1, Ws = W >> 1;
+        return *reinterpret_cast<const f32x4 *>(x + ((b * Hs + (oh >> 1)) * Ws + (ow >> 1)) * ld + q * 4);
+    }
+    const int Hb = H * 2, Wb = W * 2;
+    const float ninf = -__builtin_inff();
+    f32x4 tap[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int ih = min(max(oh * 2 - 1 + kh, 0), Hb - 1), iw = min(max(ow * 2 - 1 + kw, 0), Wb - 1);
+            tap[kh * 3 + kw] = *reinterpret_cast<const f32x4 *>(x + ((b * Hb + ih) * Wb + iw) * ld + q * 4);
+        }
+    f32x4 m = {ninf, ninf, ninf, ninf};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const bool in = (unsigned)(oh * 2 - 1 + kh) < (unsigned)Hb && (unsigned)(ow * 2 - 1 + kw) < (unsigned)Wb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[j] = in ? fmaxf(m[j], tap[kh * 3 + kw][j]) : m[j];
+        }
+    return m;
+}
+
+// halo of pre(x) for one item -> LDS, HB halo entries per thread in flight.  M1 < 0: single input (no fusion);
+// M2 < 0: two inputs.  Every load is unconditional at clamped coordinates (a branch per load would serialise them);
+// entries outside the image become the depthwise conv's zeros by a select.
+template <int KS, int HB, int M0, int M1, int M2>
+__device__ __forceinline__ void sp_stage_halo(const SpNode &P, float *halo, int ptid, int64_t b, int oy0, int ox0, float w0,
+                                              float w1, float w2) {
+    constexpr int Q = KS;
+    constexpr int NH = (HS * HS * Q + 255) / 256;
+    const int H = P.H, W = P.W;
+#pragma unroll
+    for (int j0 = 0; j0 < NH; j0 += HB) {
+        f32x4 r0[HB], r1[HB], r2[HB];
+        bool inside[HB];
+#pragma unroll
+        for (int u = 0; u < HB; ++u) {
+            const int itc = min(ptid + (j0 + u) * 256, HS * HS * Q - 1);
+            const int hp = itc / Q, q = itc - hp * Q;
+            const int hy = hp / HS, hx = hp - hy * HS;
+            const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+            inside[u] = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+            r0[u] = sp_read_m<M0>(P.in[0], P.ld[0], H, W, b, cy, cx, q);
+            if (M1 >= 0) r1[u] = sp_read_m<(M1 < 0 ? 0 : M1)>(P.in[1], P.ld[1], H, W, b, cy, cx, q);
+            if (M2 >= 0) r2[u] = sp_read_m<(M2 < 0 ? 0 : M2)>(P.in[2], P.ld[2], H, W, b, cy, cx, q);
+        }
+#pragma unroll
+        for (int u = 0; u < HB; ++u) {
+            f32x4 v = r0[u];
+            if (M1 >= 0) {                                    // python sum(): 0 + w0*x0 + w1*x1 (+ w2*x2), then swish
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = w0 * r0[u][e] + w1 * r1[u][e];
+                if (M2 >= 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] + w2 * r2[u][e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] * mydet_sigmoid_fast(v[e]);
+            }
+            if (!inside[u]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int it = ptid + (j0 + u) * 256;
+            if (j0 + u < NH && it < HS * HS * Q) *reinterpret_cast<f32x4 *>(&halo[it * 4]) = v;     // it * 4 == hp * C + q * 4
+        }
+    }
+}
+
+// generic (any mode combination): the branchy reader of the single-phase kernel; not used by the BiFPN / head shapes
+template <int KS>
+__device__ __forceinline__ void sp_stage_halo_any(const SpNode &P, float *halo, int ptid, int64_t b, int oy0, int ox0, float w0,
+                                                  float w1, float w2) {
+    constexpr int Q = KS;
+    const int H = P.H, W = P.W;
+    for (int it = ptid; it < HS * HS * Q; it += 256) {
+        const int hp = it / Q, q = it - hp * Q;
+        const int hy = hp / HS, hx = hp - hy * HS;
+        const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+            const f32x4 v0 = sp_read(P, 0, b, iy, ix, q), v1 = sp_read(P, 1, b, iy, ix, q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = w0 * v0[e] + w1 * v1[e];
+            if (P.n_in > 2) {
+                const f32x4 v2 = sp_read(P, 2, b, iy, ix, q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] + w2 * v2[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] * mydet_sigmoid_fast(v[e]);
+        }
+        *reinterpret_cast<f32x4 *>(&halo[it * 4]) = v;
+    }
+}
+
+// BUDGET: VGPRs of the calling kernel (256: everything of an item in flight; 128: fewer entries per batch)
+template <int KS, int BUDGET = 256>
+__device__ __forceinline__ void sp_stage_item(const SpNode &P, const SpItem &it, float *halo, int ptid) {
+    constexpr int HB1 = BUDGET >= 256 ? 9 : 5, HB2 = BUDGET >= 256 ? 3 : 2;
+    if (P.n_in == 1) {
+        sp_stage_halo<KS, 9, 0, -1, -1>(P, halo, ptid, it.b, it.oy0, it.ox0, 0.f, 0.f, 0.f);
+        return;
+    }
+    float w0 = fmaxf(P.fuse_w[0], 0.0f), w1 = fmaxf(P.fuse_w[1], 0.0f);       // w = relu(weights); w = w / (sum(w) + 0.0001)
+    float w2 = P.n_in > 2 ? fmaxf(P.fuse_w[2], 0.0f) : 0.0f;
+    float sum = w0 + w1;
+    if (P.n_in > 2) sum += w2;
+    sum += 0.0001f;
+    w0 = w0 / sum; w1 = w1 / sum; w2 = w2 / sum;
+    const int kind = P.n_in == 2 ? P.mode[0] * 3 + P.mode[1] : 9 + (P.mode[0] * 3 + P.mode[1]) * 3 + P.mode[2];
+    if (kind == 1) sp_stage_halo<KS, HB1, 0, 1, -1>(P, halo, ptid, it.b, it.oy0, it.ox0, w0, w1, w2);         // same + up2x (top-down)
+    else if (kind == 2) sp_stage_halo<KS, HB2, 0, 2, -1>(P, halo, ptid, it.b, it.oy0, it.ox0, w0, w1, w2);    // same + pool (coarsest out)
+    else if (kind == 9 + 2) sp_stage_halo<KS, HB2, 0, 0, 2>(P, halo, ptid, it.b, it.oy0, it.ox0, w0, w1, w2); // same + same + pool (bottom-up)
+    else sp_stage_halo_any<KS>(P, halo, ptid, it.b, it.oy0, it.ox0, w0, w1, w2);
+}
+
+
 template <int KS>
 __global__ __launch_bounds__(256, 4) void sepconv_kernel(const SpArgs a) {
     constexpr int C = KS * 4, Q = KS, XS = C + 1;
     constexpr int LDS_FLOATS = HS * HS * C > TS * TS * XS ? HS * HS * C : TS * TS * XS;
-    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS + 9 * C];
+    float *swd = lds + LDS_FLOATS;                            // the node's depthwise taps [9][C]
     const int tid = threadIdx.x, bid = blockIdx.x;
     int pi = 0;
     for (int i = 1; i < a.n; ++i)
@@ -151,55 +280,21 @@ __global__ __launch_bounds__(256, 4) void sepconv_kernel(const SpArgs a) {
     const int oy0 = ty * TS, ox0 = tx * TS;
     const int H = P.H, W = P.W;
 
-    // 1. halo of pre(x)
-    float w0 = 0.f, w1 = 0.f, w2 = 0.f;
-    if (P.n_in > 1) {                                         // w = relu(weights); w = w / (sum(w) + 0.0001)
-        w0 = fmaxf(P.fuse_w[0], 0.0f);
-        w1 = fmaxf(P.fuse_w[1], 0.0f);
-        w2 = P.n_in > 2 ? fmaxf(P.fuse_w[2], 0.0f) : 0.0f;
-        float sum = w0 + w1;
-        if (P.n_in > 2) sum += w2;
-        sum += 0.0001f;
-        w0 = w0 / sum; w1 = w1 / sum; w2 = w2 / sum;
+    // 0. everything that does not depend on the halo is requested first: the depthwise taps (-> LDS), the first block's
+    //    weight fragments (registers); their L2 round trip overlaps the halo's
+    const int wave = tid >> 6, lane = tid & 63;
+    float af[KS];
+    {
+        const float *wp = P.wpk + (int64_t)min(nb_begin, P.nb - 1) * KS * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) af[ks] = wp[ks * 64];
     }
-    // three halo items per thread in flight (otherwise a thread waits out one HBM latency per item); the single-input
-    // loads are unconditional at clamped coordinates (a branch per load would serialise them)
-    constexpr int NH = (HS * HS * Q + 255) / 256, HB = 3;
-#pragma unroll
-    for (int j0 = 0; j0 < NH; j0 += HB) {
-        f32x4 hv[HB];
-#pragma unroll
-        for (int u = 0; u < HB; ++u) {
-            const int it = tid + (j0 + u) * 256;
-            const int itc = min(it, HS * HS * Q - 1);
-            const int hp = itc / Q, q = itc - hp * Q;
-            const int hy = hp / HS, hx = hp - hy * HS;
-            const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-            const bool in = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (P.n_in == 1) {
-                const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
-                const f32x4 ld = *reinterpret_cast<const f32x4 *>(P.in[0] + (((int64_t)b * H + cy) * W + cx) * P.ld[0] + q * 4);
-                v = in ? ld : v;
-            } else if (in) {                                  // python sum(): 0 + w0*x0 + w1*x1 (+ w2*x2), then swish
-                const f32x4 v0 = sp_read(P, 0, b, iy, ix, q), v1 = sp_read(P, 1, b, iy, ix, q);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = w0 * v0[j] + w1 * v1[j];
-                if (P.n_in > 2) {
-                    const f32x4 v2 = sp_read(P, 2, b, iy, ix, q);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = v[j] + w2 * v2[j];
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = v[j] * mydet_sigmoid_fast(v[j]);
-            }
-            hv[u] = v;
-        }
-#pragma unroll
-        for (int u = 0; u < HB; ++u) {
-            const int it = tid + (j0 + u) * 256;
-            if (it < HS * HS * Q) *reinterpret_cast<f32x4 *>(&lds[it * 4]) = hv[u];      // it * 4 == hp * C + q * 4
-        }
+    if (tid < 9 * Q) *reinterpret_cast<f32x4 *>(&swd[tid * 4]) = *reinterpret_cast<const f32x4 *>(P.wd + tid * 4);
+    // 1. halo of pre(x): every load unconditional at clamped coordinates, several halo entries per thread in flight
+    {
+        SpItem it;
+        it.pi = pi; it.b = b; it.oy0 = oy0; it.ox0 = ox0; it.nb_begin = nb_begin; it.nb_end = nb_end;
+        sp_stage_item<KS, 128>(P, it, lds, tid);
     }
     __syncthreads();
 
@@ -211,7 +306,7 @@ __global__ __launch_bounds__(256, 4) void sepconv_kernel(const SpArgs a) {
     if (dg < G) {
         f32x4 wv[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) wv[k] = *reinterpret_cast<const f32x4 *>(P.wd + k * C + dq * 4);
+        for (int k = 0; k < 9; ++k) wv[k] = *reinterpret_cast<const f32x4 *>(&swd[k * C + dq * 4]);
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int px = dg + j * G;
@@ -244,7 +339,6 @@ __global__ __launch_bounds__(256, 4) void sepconv_kernel(const SpArgs a) {
     __syncthreads();
 
     // 3. pointwise conv, transposed: D[channel][pixel] = sum_k W[channel][k] * X[pixel][k]
-    const int wave = tid >> 6, lane = tid & 63;
     const int m0 = wave * 16;
     float bf[KS];
 #pragma unroll
@@ -254,37 +348,21 @@ __global__ __launch_bounds__(256, 4) void sepconv_kernel(const SpArgs a) {
     const bool valid = oy < H && ox < W;
     float *yp = P.y + (((int64_t)b * H + oy) * W + ox) * P.ldy;
     const int nsub = (lane >> 4) * 4;
-    auto finish = [&](f32x4 acc, int n) {
-        if (valid && n < P.Cout) {
-            const f32x4 sh = *reinterpret_cast<const f32x4 *>(P.shift + n);
-            if (P.scale) {
-                const f32x4 sc = *reinterpret_cast<const f32x4 *>(P.scale + n);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] = acc[e] * sc[e] + sh[e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] = acc[e] + sh[e];
-            }
-            if (P.act == MYDET_ACT_SWISH) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] = acc[e] * mydet_sigmoid_fast(acc[e]);
-            }
-            *reinterpret_cast<f32x4 *>(yp + n) = acc;
-        }
-    };
-    // one 16-channel block at a time; the NEXT block's weight fragments are in flight under the current block's MFMAs
-    // (same register budget as loading a pair and then computing it, without the exposed L2 latency per pair).  Two
-    // accumulator chains over the even / odd k-steps keep the matrix pipe issuing (40-cycle dependent latency).
-    auto load_block = [&](int nb, float (&f)[KS]) {
-        const float *wp = P.wpk + (int64_t)min(nb, P.nb - 1) * KS * 64 + lane;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) f[ks] = wp[ks * 64];
-    };
-    float af[KS];
-    load_block(nb_begin, af);
+    // one 16-channel block at a time; the NEXT block's weight fragments are in flight under the current block's MFMAs,
+    // the block's own BatchNorm terms are requested at its start (used at its end).  Two accumulator chains over the
+    // even / odd k-steps keep the matrix pipe issuing (40-cycle dependent latency).
     for (int nb = nb_begin; nb < nb_end; ++nb) {
         float an[KS];
-        load_block(nb + 1, an);
+        {
+            const float *wp = P.wpk + (int64_t)min(nb + 1, P.nb - 1) * KS * 64 + lane;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) an[ks] = wp[ks * 64];
+        }
+        const int n = nb * 16 + nsub;
+        const int nc = min(n, P.Cout - 4);
+        const f32x4 sh = *reinterpret_cast<const f32x4 *>(P.shift + nc);
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f};
+        if (P.scale) sc = *reinterpret_cast<const f32x4 *>(P.scale + nc);
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ks += 2) {
@@ -293,11 +371,25 @@ __global__ __launch_bounds__(256, 4) void sepconv_kernel(const SpArgs a) {
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc0[e] = acc0[e] + acc1[e];
-        finish(acc0, nb * 16 + nsub);
+        if (valid && n < P.Cout) {
+            if (P.scale) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc0[e] = acc0[e] * sc[e] + sh[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc0[e] = acc0[e] + sh[e];
+            }
+            if (P.act == MYDET_ACT_SWISH) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc0[e] = acc0[e] * mydet_sigmoid_fast(acc0[e]);
+            }
+            *reinterpret_cast<f32x4 *>(yp + n) = acc0;
+        }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) af[ks] = an[ks];
     }
 }
+
 
 inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 

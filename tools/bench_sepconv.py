@@ -12,6 +12,7 @@ from mydetection_amd import ops                                           # noqa
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=16)
+ap.add_argument('--only', default='', help='run only the cases whose name contains this')
 a = ap.parse_args()
 dev = torch.device('cuda')
 B, C = a.batch, 88
@@ -31,6 +32,8 @@ def node(inputs, modes, cout, act, bn=True):
 
 
 def timeit(name, nodes, flops, nbytes):
+    if a.only and a.only not in name:
+        return
     run = lambda: ops.sepconv_nodes(nodes)                                # noqa: E731
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
@@ -67,3 +70,4 @@ for i, h in enumerate(LEVELS[:-1]):
 for i, h in enumerate(LEVELS[1:], start=1):
     timeit(f'BiFPN bottom-up node {h}x{h} (same + same + pool)', [node([feats[i], feats[i], feats[i - 1]], [0, 0, 2], 88, 0)],
            px[i] * 2 * 88 * 88, (px[i] * 3 + px[i - 1]) * 88 * 4)
+
