@@ -110,7 +110,10 @@ int mydet_conv2d_stem_f32(const float *x, int64_t sxb, int64_t sxc, int64_t sxh,
  * se_partial != NULL: the launch also writes per-image channel sums of y split over S pixel slices,
  * se_partial[B][S+1][C] (slices 0..S-1; slice S is scratch for mydet_se_gate_f32) -- the squeeze of the following squeeze-excite (adaptive_avg_pool2d,
  * external/efficientnet/model.py:81) without another pass over y; deterministic (no atomics).
+ * S must be mydet_dwconv_slices(Ho, Wo, C, K, stride): the number of slices the kernel chosen for the layer writes
+ * (one per 8 x 16 output tile for the LDS-tiled stride-1 kernel, which takes the layers of 32 channels and more).
  */
+int mydet_dwconv_slices(int Ho, int Wo, int C, int K, int stride);
 int mydet_dwconv_f32(const float *x, int64_t ldx, const float *w, const float *scale, const float *shift,
                      float *y, int64_t ldy, int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l,
                      int Ho, int Wo, int act, float *se_partial, int S, void *stream);

@@ -432,13 +432,9 @@ int launch_cfg(int id, const ConvArgs &a, hipStream_t s) {
     }
 }
 
-int forced_cfg() {
-    static int v = -2;
-    if (v == -2) {
-        const char *e = getenv("MYDET_CONV_CFG");
-        v = e ? atoi(e) : -1;
-    }
-    return v;
+int forced_cfg() {      // MYDET_CONV_CFG=<id>: tuning only; read per call so that one process can sweep the configurations
+    const char *e = getenv("MYDET_CONV_CFG");
+    return e && *e ? atoi(e) : -1;
 }
 
 }  // namespace
@@ -489,6 +485,9 @@ extern "C" int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *
     // K = 16/24/40/88... and five 30 KB workgroups fit a CU
     if ((Cin % 32) != 0 && K <= 256) return launch_cfg(6, a, s);
     if (Cout <= 32) return launch_cfg(2, a, s);
+    // short-K, very wide outputs (EfficientNet expand convs at 20^2: 192->1152, 320->1920): the 8-wave 128x128 tile
+    // (tools/sweep_pointwise.py: 79 -> 73 us, 35.7 -> 32.9 us at batch 16)
+    if (KH * KW == 1 && K <= 512 && Cout >= 1024) return launch_cfg(8, a, s);
     if (Cout <= 64) return launch_cfg(KH * KW > 1 ? 6 : 1, a, s);
     // (3x3 layers with K >= 512 and a big grid already prefer the 8-wave tile: 64->128 stride 2 @320^2 +7 %)
     if ((K <= 1024 && !(KH * KW > 1 && K >= 512)) || blocks128 < 1024) return launch_cfg(3, a, s);

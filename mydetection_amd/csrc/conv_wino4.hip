@@ -253,8 +253,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino4_kernel(const W4Args p) 
                 acc[4 * g + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(fu[g & 1][e], fv[g & 1][e], acc[4 * g + e], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // (also after the last stage: the residual loads issued under it are then complete before the epilogue -- leaving
-        // that to the compiler's own vmcnt bookkeeping next to LDS-DMA requests produced wrong residuals)
+        // (also after the last stage: the residual loads issued under it are then complete before the epilogue.  An earlier
+        // arrangement of those loads gave wrong residuals without it; in the present one hipcc's own count is right --
+        // listing in profiles/r03_isa_notes.md -- and the wait is kept because it is free)
         __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): the next stage has landed
         __syncthreads();
     }
@@ -291,9 +292,11 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino4_kernel(const W4Args p) 
                 if (ACT == MYDET_ACT_SWISH) v[e] = v[e] * mydet_sigmoid_fast(v[e]);
             }
             if (RES) v += rv[4 * a + c];
-            // the pixel offset goes into the voffset, NOT the scalar offset: with an SGPR soffset the compiler leaves no
-            // wait state between a 16-byte store and the VALU that next overwrites its data registers, and on gfx950
-            // that store then picked up part of the next pixel's values (tests: test_conv_winograd4_repeatable)
+            // the pixel offset goes into the voffset, NOT the scalar offset: with an SGPR soffset hipcc leaves no wait
+            // state between a 16-byte store and the VALU that next overwrites its data registers (LLVM pads that hazard
+            // only for stores without an SGPR soffset; listing: profiles/r03_isa_notes.md), and on MI355X such a store
+            // picked up part of the next pixel's values about once in eight launches (test_conv_winograd4_repeatable;
+            // tools/check_store_hazard.py proves the pattern absent from the built library)
             const unsigned yo = ybase + (unsigned)((a * p.W + c) * p.ldy * 4);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, orow[a] && ocol[c] ? yo : OOB, 0, 0);
         }

@@ -210,6 +210,129 @@ __global__ __launch_bounds__(256) void dwconv_sum_kernel(const DwArgs p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------ depthwise, LDS-tiled (stride 1)
+// The register-blocked kernels above keep K+1 input rows x (TW+K-1) columns of one channel quad per thread: 183 VGPRs
+// for k = 5 (two waves per SIMD) and one dependent L2 / HBM round trip per input row -- 1.7-2.3 TB/s on the
+// EfficientNet 40^2 / 80^2 layers.  Here a workgroup owns 8 x 16 outputs x 8 channel quads of one image: the
+// (8+K-1) x (16+K-1) input patch is requested in ONE batch (unconditional loads at clamped coordinates, zeros by
+// select), lands in LDS, and every thread then forms a strip of four outputs of one quad from LDS (K+3 column reads per
+// tap row, taps from LDS) in the same (kh, kw) fmaf order as dw_strip.  35 KB of LDS, < 64 VGPRs: four workgroups
+// per CU keep ~30 KB of loads in flight each.  Squeeze sums per (image, tile, channel) in a fixed order.
+struct DwTArgs {
+    const float *x, *w, *scale, *shift;
+    float *y, *partial;
+    int64_t ldx, ldy;
+    int C, H, W, Ho, Wo, pad_t, pad_l, act, S, tiles_x, nchunks;
+};
+
+template <int K, bool SUM>
+__global__ __launch_bounds__(256, 4) void dwconv_tile_kernel(const DwTArgs p) {
+    constexpr int TH = 8, TW = 16, IH = TH + K - 1, IW = TW + K - 1, NPIX = IH * IW, CQ = 8, PS = CQ * 4 + 4;
+    constexpr int NL = (NPIX * CQ + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float tile[NPIX * PS];
+    __shared__ __attribute__((aligned(16))) float wl[K * K * CQ * 4];
+    __shared__ f32x4 red[SUM ? 256 : 1];
+    const int tid = threadIdx.x;
+    const int chunk = blockIdx.x % p.nchunks;          // channel chunks of one tile are neighbours: 128-B runs of one pixel row
+    const int t = blockIdx.x / p.nchunks;
+    const int b = t / p.S, r = t - b * p.S;
+    const int ty = r / p.tiles_x, tx = r - ty * p.tiles_x;
+    const int oh0 = ty * TH, ow0 = tx * TW;
+    const int ih0 = oh0 - p.pad_t, iw0 = ow0 - p.pad_l;
+    const int Q = p.C >> 2, q0 = chunk * CQ;
+    const float *xb = p.x + (int64_t)b * p.H * p.W * p.ldx;
+    // taps of this chunk -> LDS (a quad past the end reads the last quad; its outputs are never stored)
+    if (tid < K * K * CQ) {
+        const int tap = tid / CQ, q = min(q0 + tid % CQ, Q - 1);
+        *reinterpret_cast<f32x4 *>(&wl[tid * 4]) = *reinterpret_cast<const f32x4 *>(p.w + (int64_t)tap * p.C + q * 4);
+    }
+    // input patch -> LDS, one batch
+    f32x4 v[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const int it = min(tid + j * 256, NPIX * CQ - 1);
+        const int q = min(q0 + it % CQ, Q - 1), px = it / CQ;
+        const int py = px / IW, pxx = px - py * IW;
+        const int cy = min(max(ih0 + py, 0), p.H - 1), cx = min(max(iw0 + pxx, 0), p.W - 1);
+        v[j] = *reinterpret_cast<const f32x4 *>(xb + ((int64_t)cy * p.W + cx) * p.ldx + q * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const int it = tid + j * 256;
+        if (it < NPIX * CQ) {
+            const int px = it / CQ, qq = it % CQ;
+            const int py = px / IW, pxx = px - py * IW;
+            const bool in = (unsigned)(ih0 + py) < (unsigned)p.H && (unsigned)(iw0 + pxx) < (unsigned)p.W;
+            *reinterpret_cast<f32x4 *>(&tile[px * PS + qq * 4]) = in ? v[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __syncthreads();
+    // a strip of four outputs of one quad per thread
+    const int qq = tid % CQ, strip = (tid / CQ) % (TW / 4), row = tid / (CQ * (TW / 4));
+    const int q = q0 + qq;
+    f32x4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int kh = 0; kh < K; ++kh) {                   // one tap row at a time: K + 3 columns and its K taps in registers
+        f32x4 col[K + 3];
+#pragma unroll
+        for (int c = 0; c < K + 3; ++c) col[c] = *reinterpret_cast<const f32x4 *>(&tile[((row + kh) * IW + strip * 4 + c) * PS + qq * 4]);
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) {
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(&wl[((kh * K + kw) * CQ + qq) * 4]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[u][e] = fmaf(col[u + kw][e], wv[e], acc[u][e]);
+        }
+    }
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    const int oh = oh0 + row;
+    if (q < Q && oh < p.Ho) {
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (p.scale) {
+            sc = *reinterpret_cast<const f32x4 *>(p.scale + q * 4);
+            sh = *reinterpret_cast<const f32x4 *>(p.shift + q * 4);
+        }
+        float *yp = p.y + (((int64_t)b * p.Ho + oh) * p.Wo + ow0 + strip * 4) * p.ldy + q * 4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (ow0 + strip * 4 + u < p.Wo) {
+                f32x4 o = acc[u];
+                if (p.scale) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = o[e] * sc[e] + sh[e];
+                }
+                if (p.act == MYDET_ACT_SWISH) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = o[e] * mydet_sigmoid_fast(o[e]);
+                } else if (p.act == MYDET_ACT_LEAKY) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : o[e] * 0.1f;
+                }
+                *reinterpret_cast<f32x4 *>(yp + (int64_t)u * p.ldy) = o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sum[e] += o[e];
+            }
+        }
+    }
+    if (SUM) {          // channel sums of the tile: the 32 (row, strip) threads of a quad, added in thread order
+        red[tid] = sum;
+        __syncthreads();
+        if (tid < CQ && q0 + tid < Q) {
+            f32x4 tot = red[tid];
+            for (int k = 1; k < 256 / CQ; ++k) {
+                const f32x4 o = red[tid + k * CQ];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tot[e] += o[e];
+            }
+            *reinterpret_cast<f32x4 *>(p.partial + ((int64_t)b * (p.S + 1) + r) * p.C + (q0 + tid) * 4) = tot;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ SE squeeze + gate
 // standalone stage 1: partial[b][s][c] = sum over pixels of slice s of image b
 __global__ __launch_bounds__(256) void squeeze_partial_kernel(const float *x, int64_t ldx, int C, int HW, int S,
@@ -548,6 +671,15 @@ inline unsigned grid_for(int64_t total) {
 
 inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
+inline bool dw_tiled() {      // MYDET_DW_TILED=0: the register-blocked kernels for stride 1 too (tuning / A-B)
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("MYDET_DW_TILED");
+        v = e ? (atoi(e) != 0) : 1;
+    }
+    return v != 0;
+}
+
 inline bool block2() {       // MYDET_DW_BLOCK2=0: single-row strips everywhere (tuning / A-B)
     static int v = -1;
     if (v < 0) {
@@ -580,6 +712,30 @@ int launch_dw(const DwArgs &p0, int B, hipStream_t stream) {
     return mydet_launch_status();
 }
 
+// number of squeeze slices mydet_dwconv_f32 writes for this layer (the caller sizes se_partial with it)
+extern "C" int mydet_dwconv_slices(int Ho, int Wo, int C, int K, int stride) {
+    if (Ho <= 0 || Wo <= 0) return 0;
+    if (stride == 1 && (K == 3 || K == 5) && dw_tiled() && C >= 32) return ((Ho + 7) / 8) * ((Wo + 15) / 16);      // LDS-tiled kernel: one slice per tile
+    int s = Ho * Wo / 16;
+    s = s > 128 ? 128 : s;
+    return s < 1 ? 1 : s;
+}
+
+template <int K>
+static int launch_dw_tile(const DwArgs &a, int B, hipStream_t stream) {
+    DwTArgs p;
+    p.x = a.x; p.w = a.w; p.scale = a.scale; p.shift = a.shift; p.y = a.y; p.partial = a.partial; p.ldx = a.ldx; p.ldy = a.ldy;
+    p.C = a.C; p.H = a.H; p.W = a.W; p.Ho = a.Ho; p.Wo = a.Wo; p.pad_t = a.pad_t; p.pad_l = a.pad_l; p.act = a.act;
+    p.tiles_x = (a.Wo + 15) / 16;
+    p.S = p.tiles_x * ((a.Ho + 7) / 8);
+    p.nchunks = ((a.C >> 2) + 7) / 8;
+    const int64_t grid = (int64_t)B * p.S * p.nchunks;      // one workgroup per (image, tile, chunk): a persistent form with a
+    if (grid > 0x7fffffff) return MYDET_E_UNSUPP;           // register prefetch of the next tile measured 20 % slower (profiles/r03_mbconv_notes.md)
+    if (a.partial) hipLaunchKernelGGL((dwconv_tile_kernel<K, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((dwconv_tile_kernel<K, false>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    return mydet_launch_status();
+}
+
 extern "C" int mydet_dwconv_f32(const float *x, int64_t ldx, const float *w, const float *scale, const float *shift,
                                 float *y, int64_t ldy, int B, int H, int W, int C, int K, int stride, int pad_t,
                                 int pad_l, int Ho, int Wo, int act, float *se_partial, int S, void *stream) {
@@ -592,6 +748,8 @@ extern "C" int mydet_dwconv_f32(const float *x, int64_t ldx, const float *w, con
     p.x = x; p.w = w; p.scale = scale; p.shift = shift; p.y = y; p.partial = se_partial; p.ldx = ldx; p.ldy = ldy;
     p.C = C; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.pad_t = pad_t; p.pad_l = pad_l; p.act = act; p.S = S; p.total = 0;
     hipStream_t st = (hipStream_t)stream;
+    if (se_partial && S != mydet_dwconv_slices(Ho, Wo, C, K, stride)) return MYDET_E_BADARG;
+    if (stride == 1 && dw_tiled() && C >= 32) return K == 3 ? launch_dw_tile<3>(p, B, st) : launch_dw_tile<5>(p, B, st);
     if (K == 3) return stride == 1 ? launch_dw<3, 1>(p, B, st) : launch_dw<3, 2>(p, B, st);
     return stride == 1 ? launch_dw<5, 1>(p, B, st) : launch_dw<5, 2>(p, B, st);
 }

@@ -294,7 +294,7 @@ def dwconv(x, w_kkc, scale, shift, k, stride, pad, act, squeeze=False):
     out, ldy = empty_nhwc(B, C, Ho, Wo, x.device)
     partial, S = None, 0
     if squeeze:
-        S = se_slices(Ho * Wo)
+        S = _lib.lib().mydet_dwconv_slices(Ho, Wo, C, k, stride)      # what the kernel chosen for this layer writes
         partial = torch.empty((B, S + 1, C), dtype=torch.float32, device=x.device)    # slice S: scratch for the mean
     t0 = TIMER.start() if TIMER else None
     code = _lib.lib().mydet_dwconv_f32(_ptr(x), ldx, _ptr(w_kkc), _ptr(scale), _ptr(shift), _ptr(out), ldy, B, H, W, C,

@@ -284,3 +284,24 @@ def test_graph_cache_policy_and_workspace_refs():
     with __import__('pytest').raises(ValueError):
         ops.check_counts([3, -1, 0])
     assert ops.check_counts([0, 5]) == [0, 5]
+
+
+def test_no_store_data_hazard_in_the_shipped_library():
+    """gfx950 store-data hazard (profiles/r03_isa_notes.md): no 12/16-byte buffer store with an SGPR soffset may be followed
+    directly by a VALU write of its data registers -- hipcc pads that pattern only for stores WITHOUT an SGPR soffset.
+    Checked on the disassembly of every gfx950 code object in libmydet_hip.so (tools/check_store_hazard.py)."""
+    import importlib.util
+    from mydetection_amd import _lib
+    if not os.path.exists('/opt/rocm/lib/llvm/bin/llvm-objdump'):
+        pytest.skip('no llvm-objdump on this machine')
+    spec = importlib.util.spec_from_file_location('check_store_hazard', os.path.join(ROOT, 'tools', 'check_store_hazard.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    stores = hazards = objects = 0
+    for _, text in mod.code_objects(_lib.LIB_PATH):
+        a, _, bad = mod.violations(text)
+        objects += 1
+        stores += a
+        hazards += len(bad)
+    assert objects >= 10 and stores > 100, (objects, stores)
+    assert hazards == 0
