@@ -57,7 +57,8 @@ def parse_args(argv=None):
     ap.add_argument('--size', type=int, default=640)
     ap.add_argument('--config', default='yolov3_80', help='yolov3_80 (headline) | efficientdet-d1 | d1_fcs2_atss')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--graph', action='store_true', help='replay the step from a captured hipGraph')
+    ap.add_argument('--graph', action='store_true', help='(default) replay the step from a captured hipGraph')
+    ap.add_argument('--eager', action='store_true', help='issue every launch of the step from the host instead of replaying a hipGraph')
     ap.add_argument('--verify', action='store_true',
                     help='after the timed region: the gathered records must equal a 1-GPU pass over the same global batch')
     ap.add_argument('--nms-worst', action='store_true', help='isolated NMS worst cases (512 boxes, 1 and 80 classes)')
@@ -175,6 +176,7 @@ def nms_worst_cases(dev, iters=200, warm=20):
 
 def main():
     args = parse_args()
+    args.graph = not args.eager          # the product's default path (api.Detector replays captured graphs, MYDET_GRAPH=1)
     if args.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(self_launch(args))
 
@@ -349,7 +351,11 @@ def main():
                     'note': 'achieved = algorithmic bytes of the family (operands once + result once) / HIP-event time',
                     'step_algorithmic_bytes': round(step_bytes),
                     'step_achieved_GBs': round(step_bytes / (kernel_ms * 1e-3) / 1e9, 1),
-                    'step_frac': round(step_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+                    'step_frac': round(step_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                    # what a maximally fused implementation would still move (block inputs / outputs, weights, residuals;
+                    # not the tensors that live only inside an MBConv block or a separable conv): the stricter yardstick
+                    'fused_min_bytes': round(sum(timer.fused.values()) / args.steps),
+                    'fused_min_frac': round(sum(timer.fused.values()) / args.steps / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
     # HBM/fabric bytes per launch from committed rocprofv3 --pmc passes of this same command (FETCH_SIZE / WRITE_SIZE in
     # separate passes, corrected per kernel as MI355X_MICROARCH.md prescribes); offline because counters need the profiler
     traffic, traffic_src = None, None
@@ -388,7 +394,7 @@ def main():
         'dtype': 'f32',
         'data': 'synthetic',
         'config': {'workload': f'{WORKLOADS.get(args.config, args.config)}, batch {batch}/GPU, {args.size}x{args.size}, '
-                               'random-init calibrated weights' + (', hipGraph replay' if args.graph else ''),
+                               'random-init calibrated weights' + (', hipGraph replay' if args.graph else ', eager launches'),
                    'global_batch': total, 'image_size': args.size, 'parallelism': f'dp{world}',
                    'exchange': f'one all-gather of {parallel.WORDS * 4} B detection records per image' if world > 1 else 'none'},
         'roofline': roofline,

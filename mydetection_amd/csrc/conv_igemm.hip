@@ -397,6 +397,7 @@ int launch(const ConvArgs &a0, int slots, hipStream_t stream) {
     if (splits > nk / 4) splits = nk / 4;
     const size_t need = (size_t)rem * (splits > 0 ? splits : 0) * BM * BN * sizeof(float);
     // only long-K layers: on short ones the two extra launches cost more than the spared round
+    // (shorter K -- 8 or 16 slabs, the 256->128 / 512->256 1x1 layers of YOLOv3 -- measured 1-3 % SLOWER with the tail cut)
     const bool split = rem > 0 && splits >= 2 && a0.ws && need <= a0.ws_bytes &&
                        (small || (nk >= 32 && rounds >= 2 && rem * 2 <= slots));
     a.tile0 = 0; a.splits = 1;

@@ -30,6 +30,10 @@ class KernelTimer:
     def __init__(self, chain=False):
         self.spans = {}
         self.bytes = {}                  # name -> algorithmic bytes (operands read once + result written once)
+        # name -> bytes a maximally fused implementation would still move: tensors that exist only between two layers of a
+        # block the reference itself treats as a unit (the 6x-wide maps inside an MBConv block, the depthwise result
+        # inside a separable conv) are not counted; block inputs / outputs, weights and residuals are
+        self.fused = {}
         # chain=True: the event that closes one launch also opens the next one (every launch of the step is timed and
         # they run back to back on one in-order stream, so "end of launch i" IS "start of launch i+1"): half the
         # event records -- each is a small packet on the GPU's queue -- inside the timed region
@@ -43,12 +47,13 @@ class KernelTimer:
         ev.record()                      # torch's current stream == the stream handed to the C ABI
         return ev
 
-    def stop(self, name, start_ev, work=0.0, nbytes=0.0):
+    def stop(self, name, start_ev, work=0.0, nbytes=0.0, fused=None):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         self._tail = ev
         self.spans.setdefault(name, []).append((start_ev, ev, work))
         self.bytes[name] = self.bytes.get(name, 0.0) + nbytes
+        self.fused[name] = self.fused.get(name, 0.0) + (nbytes if fused is None else fused)
 
     def cut(self):
         """Forget the chain (call where untimed GPU work, a synchronisation or a step boundary intervenes)."""
@@ -196,11 +201,13 @@ def wino4_weights(w_ohwi):
 
 
 def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None, out_ld=None, gate=None, wino=None,
-           wino4=None):
+           wino4=None, interior=None):
     """y = act(conv(x * gate)*scale + shift) + residual.  x logical [B,Cin,H,W]; pad=(top,left,bottom,right);
     gate: optional [B,Cin] per-image channel multipliers (squeeze-excite), 1x1 convs only;
     wino / wino4: optional `wino_weights(w_ohwi)` / `wino4_weights(w_ohwi)`: 3x3 stride-1 pad-1 layers then run a fused
-    Winograd kernel -- F(4x4,3x3) when given and the grid fills the chip (or no F(2x2,3x3) weights are given)."""
+    Winograd kernel -- F(4x4,3x3) when given and the grid fills the chip (or no F(2x2,3x3) weights are given).
+    interior: 'in' / 'out' marks the input / output as a tensor that lives only inside a block (bookkeeping of the
+    fused-minimum byte count of KernelTimer; no effect on the launch)."""
     require_gpu(x, 'conv2d')
     if x.shape[1] % 4:
         raise ValueError(f'conv2d: Cin = {x.shape[1]} is not a multiple of 4 (the implicit-GEMM kernel reads channels in '
@@ -252,8 +259,10 @@ def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None
         B, H, W, Cin, Cout, k, k, stride, pad[0], pad[1], Ho, Wo, act, _stream())
     if t0:
         name = f'conv_igemm {Cin}->{Cout} k{k}s{stride} {H}x{W}' if TIMER_DETAIL else 'conv_igemm'
-        TIMER.stop(name, t0, 2.0 * B * Ho * Wo * Cout * k * k * Cin,
-                   4.0 * (B * H * W * Cin + B * Ho * Wo * Cout * (2 if residual is not None else 1) + k * k * Cin * Cout))
+        b_in, b_out = 4.0 * B * H * W * Cin, 4.0 * B * Ho * Wo * Cout
+        b_rest = 4.0 * (k * k * Cin * Cout) + (b_out if residual is not None else 0.0)
+        TIMER.stop(name, t0, 2.0 * B * Ho * Wo * Cout * k * k * Cin, b_in + b_out + b_rest,
+                   (0.0 if interior == 'in' else b_in) + (0.0 if interior == 'out' else b_out) + b_rest)
     _lib.check(code, 'mydet_conv2d_igemm_f32')
     return out
 
@@ -283,7 +292,7 @@ def se_slices(n_pixels):
     return max(1, min(128, n_pixels // 16))
 
 
-def dwconv(x, w_kkc, scale, shift, k, stride, pad, act, squeeze=False):
+def dwconv(x, w_kkc, scale, shift, k, stride, pad, act, squeeze=False, interior=False):
     """Depthwise k x k conv, y = act(conv*scale + shift); w_kkc [k,k,C]; pad=(top,left,bottom,right).
     squeeze=True also returns the per-slice channel sums [B,S,C] of y (input of `se_gate`)."""
     require_gpu(x, 'dwconv')
@@ -300,7 +309,8 @@ def dwconv(x, w_kkc, scale, shift, k, stride, pad, act, squeeze=False):
     code = _lib.lib().mydet_dwconv_f32(_ptr(x), ldx, _ptr(w_kkc), _ptr(scale), _ptr(shift), _ptr(out), ldy, B, H, W, C,
                                        k, stride, pad[0], pad[1], Ho, Wo, act, _ptr(partial), S, _stream())
     if t0:
-        TIMER.stop(f'dwconv {C} k{k}s{stride} {H}x{W}' if TIMER_DETAIL else 'dwconv', t0, *[4.0 * B * C * (H * W + Ho * Wo)] * 2)
+        TIMER.stop(f'dwconv {C} k{k}s{stride} {H}x{W}' if TIMER_DETAIL else 'dwconv', t0, *[4.0 * B * C * (H * W + Ho * Wo)] * 2,
+                   fused=0.0 if interior is True else (4.0 * B * C * H * W if interior == 'out' else None))
     _lib.check(code, 'mydet_dwconv_f32')
     return (out, partial) if squeeze else out
 
@@ -340,7 +350,7 @@ def mbconv_expand_dw(x, w_expand, shift0, w_dw, shift1, k, stride, pad):
     if t0:      # algorithmic bytes of the two reference layers it replaces: expand (in + out) and depthwise (in + out)
         nb = 4.0 * B * (H * W * (Cin + Cexp) + Cexp * (H * W + Ho * Wo))
         TIMER.stop(f'mbconv_expand_dw {Cin}->{Cexp} k{k}s{stride} {H}x{W}' if TIMER_DETAIL else 'mbconv_expand_dw', t0,
-                   2.0 * B * H * W * Cin * Cexp, nb)
+                   2.0 * B * H * W * Cin * Cexp, nb, fused=4.0 * B * H * W * Cin)
     _lib.check(code, 'mydet_mbconv_expand_dw_f32')
     return out, partial
 
@@ -368,7 +378,7 @@ def se_gate(partial, n_pixels, w1, b1, w2t, b2):
     code = _lib.lib().mydet_se_gate_f32(_ptr(partial), S, B, n_pixels, C, _ptr(w1), _ptr(b1), Cse, _ptr(w2t), _ptr(b2),
                                         _ptr(gate), _stream())
     if t0:
-        TIMER.stop('se_gate', t0, *[4.0 * B * S * C] * 2)
+        TIMER.stop('se_gate', t0, *[4.0 * B * S * C] * 2, fused=0.0)
     _lib.check(code, 'mydet_se_gate_f32')
     return gate
 
@@ -444,7 +454,7 @@ def sepconv_nodes(nodes):
     arr = (_lib.SepconvNode * len(nodes))()
     outs, keep = [], []
     B = C = None
-    work = 0.0
+    work = fused = 0.0
     for i, nd in enumerate(nodes):
         prepared = [to_nhwc(t) for t in nd['inputs']]
         require_gpu(prepared[0][0], 'sepconv_nodes')
@@ -481,10 +491,11 @@ def sepconv_nodes(nodes):
         # algorithmic bytes of the reference layers this node replaces: fusion (n+1 maps), depthwise (2), pointwise (C + Cout)
         px = 4.0 * B * H * W
         work += px * ((C * (n_in + 1) if n_in > 1 else 0) + 2 * C + C + cout)
+        fused += sum(4.0 * t.numel() for t, _ in prepared) + px * cout
     t0 = TIMER.start() if TIMER else None
     code = _lib.lib().mydet_sepconv_nodes_f32(len(nodes), ctypes.cast(arr, ctypes.c_void_p), B, C, _stream())
     if t0:
-        TIMER.stop('sepconv_nodes', t0, work, work)
+        TIMER.stop('sepconv_nodes', t0, work, work, fused=fused)
     _lib.check(code, 'mydet_sepconv_nodes_f32')
     return outs
 

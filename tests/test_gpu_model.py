@@ -437,9 +437,11 @@ def test_effdet_full_size_properties_640(name, batch):
         np.testing.assert_allclose(bp.cpu().numpy(), bb[perm].cpu().numpy(), rtol=1e-5, atol=1e-5)
         assert (cp != ci[perm]).float().mean().item() < 1e-4
         for i in (0, batch - 1):
+            # solo run vs the same image inside the batch: two float32 evaluations whose small-grid layers are cut along K
+            # differently (and, at batch 1, take other tile shapes) -- 3e-5, a third of north_star's tolerance
             b1, c1, s1 = m.forward_candidates(x[i:i + 1])
-            np.testing.assert_allclose(s1[0].cpu().numpy(), sc[i].cpu().numpy(), rtol=1e-5, atol=1e-5)
-            np.testing.assert_allclose(b1[0].cpu().numpy(), bb[i].cpu().numpy(), rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(s1[0].cpu().numpy(), sc[i].cpu().numpy(), rtol=3e-5, atol=1e-5)
+            np.testing.assert_allclose(b1[0].cpu().numpy(), bb[i].cpu().numpy(), rtol=3e-5, atol=1e-5)
     assert bb.shape[1] == (76725 if name == 'efficientdet-d1' else 8525)
     assert torch.isfinite(sc).all() and torch.isfinite(bb).all()
     rec = batched_post_process(bb, ci, sc, conf, thr)

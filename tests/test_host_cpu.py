@@ -305,3 +305,61 @@ def test_no_store_data_hazard_in_the_shipped_library():
         hazards += len(bad)
     assert objects >= 10 and stores > 100, (objects, stores)
     assert hazards == 0
+
+
+def test_pyramid_node_address_audit():
+    """Host-side enumeration of every global address the fused pyramid-node kernel forms (csrc/sepconv.hip:
+    sp_stage_halo / sp_read_m and the epilogue store) over the whole node table of EfficientDet-D1 and D1-FCOS2-ATSS at
+    batch 16 / 32, 640x640 -- all five levels (80^2 ... 5^2), the three fusion kinds, every tile and halo entry:
+    each read must fall inside its input tensor (absent inputs of a single-input node are NEVER dereferenced), each
+    store inside the output.  Round 2 lost a GPU box to an LDS-DMA variant of this kernel that read at
+    0xffffd0ef7000 = -(low 32 bits of a heap pointer): a NULL input pointer of a single-input node had entered 32-bit
+    offset arithmetic; this is the check that was missing."""
+    import numpy as np
+    TS, HS, C = 8, 10, 88
+
+    def halo_coords(H, W):
+        """(iy, ix) of all halo entries of all tiles of an H x W map, clamped as the kernel clamps them."""
+        ty, tx = np.meshgrid(np.arange((H + TS - 1) // TS), np.arange((W + TS - 1) // TS), indexing='ij')
+        hy, hx = np.meshgrid(np.arange(HS), np.arange(HS), indexing='ij')
+        iy = (ty.reshape(-1, 1) * TS - 1 + hy.reshape(1, -1)).reshape(-1)
+        ix = (tx.reshape(-1, 1) * TS - 1 + hx.reshape(1, -1)).reshape(-1)
+        return np.clip(iy, 0, H - 1), np.clip(ix, 0, W - 1)
+
+    def reads(mode, H, W, B, ld):
+        """element offsets (first float of the first / last channel quad) read from an input of `mode` for an H x W node"""
+        cy, cx = halo_coords(H, W)
+        if mode == 0:
+            h, w, py, px = H, W, cy, cx
+        elif mode == 1:
+            h, w, py, px = H // 2, W // 2, cy >> 1, cx >> 1
+        else:
+            h, w = H * 2, W * 2
+            kh, kw = np.meshgrid(np.arange(3), np.arange(3), indexing='ij')
+            py = np.clip(cy.reshape(-1, 1) * 2 - 1 + kh.reshape(1, -1), 0, h - 1).reshape(-1)
+            px = np.clip(cx.reshape(-1, 1) * 2 - 1 + kw.reshape(1, -1), 0, w - 1).reshape(-1)
+        b = np.array([0, B - 1]).reshape(-1, 1)
+        base = ((b * h + py.reshape(1, -1)) * w + px.reshape(1, -1)) * ld
+        return base.min(), base.max() + (C // 4 - 1) * 4 + 3, B * h * w * ld
+
+    kinds = {'tower': (0,), 'top-down': (0, 1), 'bottom-up': (0, 0, 2), 'coarsest out': (0, 2)}
+    checked = 0
+    for B in (16, 32):
+        for hw in (80, 40, 20, 10, 5):
+            for name, modes in kinds.items():
+                if 1 in modes and hw % 2:
+                    continue                              # nearest-2x inputs need an even map (the C ABI rejects the rest)
+                for m in modes:
+                    lo, hi, numel = reads(m, hw, hw, B, C)
+                    assert 0 <= lo and hi < numel, (B, hw, name, m, lo, hi, numel)
+                    checked += 1
+                for cout, ldy in ((88, 88), (720, 756), (36, 756), (4, 84)):
+                    oy = np.arange(hw)
+                    off_max = (((B - 1) * hw + oy.max()) * hw + oy.max()) * ldy + cout - 1
+                    assert off_max < B * hw * hw * ldy
+    assert checked == 2 * (5 * 1 + 4 * 2 + 5 * 3 + 5 * 2)
+    # and the ABI refuses what the kernel could not address: a missing input pointer inside n_in, odd maps under up2x
+    from mydetection_amd import _lib
+    node = _lib.SepconvNode()
+    node.n_in, node.H, node.W, node.Cout, node.ldy = 2, 8, 8, 88, 88
+    assert _lib.lib().mydet_sepconv_nodes_f32(1, ctypes.cast(ctypes.pointer(node), ctypes.c_void_p), 1, 88, None) == -1
