@@ -428,6 +428,7 @@ int launch_cfg(int id, const ConvArgs &a, hipStream_t s) {
         case 2: return launch<128, 32, 4, 1, 32>(a, 3 * cus, s);
         case 3: return launch<64, 64, 2, 2, 32>(a, 4 * cus, s);
         case 6: return launch<128, 64, 2, 2, 16>(a, 5 * cus, s);
+        case 9: return launch<128, 96, 4, 1, 32>(a, 2 * cus, s);       // Cout in (64, 96]: 80 / 88 channels
         case 8: return launch<128, 128, 2, 4, 32>(a, 2 * cus, s);     // 8 waves, wave tile 64x32
         default: return MYDET_E_BADARG;
     }
@@ -486,6 +487,9 @@ extern "C" int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *
     // K = 16/24/40/88... and five 30 KB workgroups fit a CU
     if ((Cin % 32) != 0 && K <= 256) return launch_cfg(6, a, s);
     if (Cout <= 32) return launch_cfg(2, a, s);
+    // 80 / 88 output channels behind a long K (480->80 project convs): a 96-wide tile instead of two 64-wide ones
+    // (tools/sweep_pointwise.py, batch 32: 67 -> 57 us)
+    if (KH * KW == 1 && Cout > 64 && Cout <= 96 && K >= 384) return launch_cfg(9, a, s);
     // short-K, very wide outputs (EfficientNet expand convs at 20^2: 192->1152, 320->1920): the 8-wave 128x128 tile
     // (tools/sweep_pointwise.py: 79 -> 73 us, 35.7 -> 32.9 us at batch 16)
     if (KH * KW == 1 && K <= 512 && Cout >= 1024) return launch_cfg(8, a, s);
