@@ -417,6 +417,10 @@ extern "C" int mydet_sepconv_nodes_f32(int n, const mydet_sepconv_node *nodes, i
                     return MYDET_E_BADARG;
                 if (s.mode[k] == 1 && ((s.H & 1) || (s.W & 1))) return MYDET_E_BADARG;
                 if (s.n_in == 1 && s.mode[k] != 0) return MYDET_E_BADARG;
+            } else {
+                // a slot beyond n_in is never read; give it input 0's address all the same, so that no address
+                // arithmetic in the kernel can ever start from a null pointer (the cause of round 2's fault)
+                p.in[k] = s.in[0]; p.ld[k] = s.ld[0]; p.mode[k] = 0;
             }
         }
         p.n_in = s.n_in; p.fuse_w = s.fuse_weights; p.wd = s.w_dw; p.wpk = s.w_pw_packed; p.scale = s.scale;
