@@ -224,9 +224,11 @@ def main():
         from mydetection_amd.graph import GraphedPath
         graphed = GraphedPath(model, x, conf, nms)
 
-    def local_records(inp=None):
+    def local_records(inp=None, pricing=False):
         if graphed is not None and inp is None:
             return graphed()
+        if graphed is not None and not pricing:
+            return {k: v.clone() for k, v in graphed.eager(inp).items()}      # the replayed decomposition, host-issued
         with torch.no_grad():
             bb, ci, sc = model.forward_candidates(x if inp is None else inp)
             return batched_post_process(bb, ci, sc, conf, nms)
@@ -258,7 +260,7 @@ def main():
     if timer is None:        # graph replay hides the launches from the event timer: price the kernels eagerly, after
         ops.TIMER = ops.KernelTimer()
         for _ in range(args.steps):
-            local_records(x)
+            local_records(x, pricing=True)
         torch.cuda.synchronize()
         timer, ops.TIMER = ops.TIMER, None
 
@@ -394,8 +396,9 @@ def main():
         'dtype': 'f32',
         'data': 'synthetic',
         'config': {'workload': f'{WORKLOADS.get(args.config, args.config)}, batch {batch}/GPU, {args.size}x{args.size}, '
-                               'random-init calibrated weights' + (', hipGraph replay' if args.graph else ', eager launches'),
+                               'random-init calibrated weights' + (f', hipGraph replay ({graphed.lanes} batch lane{"s" if graphed.lanes > 1 else ""} per GPU)' if args.graph else ', eager launches'),
                    'global_batch': total, 'image_size': args.size, 'parallelism': f'dp{world}',
+                   'batch_lanes': graphed.lanes if graphed is not None else 1,
                    'exchange': f'one all-gather of {parallel.WORDS * 4} B detection records per image' if world > 1 else 'none'},
         'roofline': roofline,
         'stages': stages,

@@ -19,6 +19,7 @@ handed to another tensor.  A graph captured before a parameter change would stil
 OLD parameters; `stale()` tells (the model's `weights_epoch` moves on `load_state_dict` / `.to()`),
 and `GraphCache` / `api.Detector` drop such graphs instead of replaying them.
 """
+import os
 from collections import OrderedDict
 
 import torch
@@ -40,30 +41,104 @@ def prepared_tensors(model):
 
 
 class GraphedPath:
-    """Captured `images -> detection records` for one (batch, H, W) and one (conf, nms) setting."""
+    """Captured `images -> detection records` for one (batch, H, W) and one (conf, nms) setting.
 
-    def __init__(self, model, example, conf_thres, nms_thres, warmup=2):
+    `lanes`: the images of a batch are independent, so the batch can be cut into equal parts that run the whole path on
+    streams of their own (fork / join inside the capture -> parallel branches of the hipGraph).  The hardware
+    dispatcher then fills the CUs that one lane's launch leaves idle -- its ramp, its tail, the small grids of the
+    coarse pyramid levels -- with the other lane's workgroups.  Measured (profiles/r03_lanes.md): two lanes are +5 % on
+    the EfficientDet-family configs (~140 launches of 10-150 us per step) and -5 % on YOLOv3 (launches of 0.3-1 ms that
+    fill the chip on their own), so the default `'auto'` (env MYDET_LANES) captures the path with one and with two
+    lanes, times a few replays of each and keeps the faster graph.  Each lane has its own scratch (`ops.lane`).
+    A lane's launches see a batch of B / lanes images, so float results can differ from a full-batch eager pass in the
+    last bits (grid-size dependent K cuts, exactly as a solo image differs from the same image in a batch);
+    `eager()` runs the same decomposition without the graph and is bit-identical to a replay."""
+
+    def __init__(self, model, example, conf_thres, nms_thres, warmup=2, lanes=None):
         assert example.is_cuda and example.dim() == 4
         self.model = model
         self.static_in = example.clone()
         self.conf, self.nms = float(conf_thres), float(nms_thres)
         self.epoch = getattr(model, 'weights_epoch', 0)
+        if lanes is None:
+            lanes = os.environ.get('MYDET_LANES', 'auto')
+        B = example.shape[0]
+        if lanes == 'auto':
+            tries = [1, 2] if B >= 2 and B % 2 == 0 else [1]
+        else:
+            tries = [int(lanes) if int(lanes) > 1 and B % int(lanes) == 0 else 1]
+        best = None
+        for n in tries:
+            cap = self._capture(n, warmup)
+            if len(tries) > 1:
+                cap['ms'] = self._time_replays(cap['graph'])
+                if best is not None and cap['ms'] >= best['ms']:
+                    del cap
+                    continue
+            best = cap
+        self.lanes, self._streams = best['lanes'], best['streams']
+        self.graph, self._cand, self.records = best['graph'], best['cand'], best['records']
+        self.tuned_ms = best.get('ms')
+        # the warm-up sized every scratch buffer and prepared every parameter (a growth during capture raises), so what
+        # exists now is exactly what the graph recorded
+        self._held = (ops.live_workspaces(example.device), prepared_tensors(model))
+
+    def _capture(self, lanes, warmup):
+        self.lanes = lanes
+        self._streams = [torch.cuda.Stream() for _ in range(lanes)] if lanes > 1 else []
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(warmup):                       # first launches set function attributes, fill caches
                 self._run_eager()
         torch.cuda.current_stream().wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
-            self.cand, self.records = self._run_eager()
-        # the warm-up sized every scratch buffer and prepared every parameter (a growth during capture raises), so what
-        # exists now is exactly what the graph recorded
-        self._held = (ops.live_workspaces(example.device), prepared_tensors(model))
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph), torch.no_grad():
+            cand, records = self._run_eager()
+        return dict(lanes=lanes, streams=self._streams, graph=graph, cand=cand, records=records)
+
+    @staticmethod
+    def _time_replays(graph, n=5):
+        graph.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            graph.replay()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / n
 
     def _run_eager(self):
-        bb, ci, sc = self.model.forward_candidates(self.static_in)
-        return (bb, ci, sc), batched_post_process(bb, ci, sc, self.conf, self.nms)
+        if self.lanes == 1:
+            bb, ci, sc = self.model.forward_candidates(self.static_in)
+            return (bb, ci, sc), batched_post_process(bb, ci, sc, self.conf, self.nms)
+        main = torch.cuda.current_stream()
+        parts = self.static_in.chunk(self.lanes)
+        outs = []
+        for i, (st, part) in enumerate(zip(self._streams, parts)):
+            st.wait_stream(main)
+            with torch.cuda.stream(st), ops.lane(i):
+                bb, ci, sc = self.model.forward_candidates(part)
+                outs.append(((bb, ci, sc), batched_post_process(bb, ci, sc, self.conf, self.nms)))
+        for st in self._streams:
+            main.wait_stream(st)
+        # only the records (16 400 B per image) are joined inside the graph; the candidates stay per lane
+        return [o[0] for o in outs], ops.record_views(torch.cat([o[1]['records'] for o in outs]))
+
+    def eager(self, x=None):
+        """The captured launch sequence issued from the host (same lanes, same streams): what a replay computes, bit for
+        bit, in fresh tensors."""
+        if x is not None and x.data_ptr() != self.static_in.data_ptr():
+            self.static_in.copy_(x, non_blocking=True)
+        with torch.no_grad():
+            return self._run_eager()[1]
+
+    @property
+    def cand(self):
+        """(bbox, class_idx, score) of the last replay, before post-processing (joined on demand when lanes > 1)."""
+        if self.lanes == 1:
+            return self._cand
+        return tuple(torch.cat([c[j] for c in self._cand]) for j in range(3))
 
     def stale(self):
         """True when the model's parameters were replaced after the capture (the graph would compute with the old ones)."""

@@ -113,11 +113,28 @@ def empty_nhwc(B, C, H, W, device, ld=None):
 
 _WORKSPACE = {}
 WORKSPACE_BYTES = 64 << 20
+_LANE = 0
+
+
+class lane:
+    """`with ops.lane(i):` -- launches issued inside use lane i's scratch buffers.  Scratch is reused in stream order,
+    so two launch sequences that run on different streams at the same time (graph.GraphedPath's batch lanes) must not
+    share it; everything outside a `with` is lane 0."""
+    def __init__(self, index):
+        self.index = int(index)
+
+    def __enter__(self):
+        global _LANE
+        self.prev, _LANE = _LANE, self.index
+
+    def __exit__(self, *exc):
+        global _LANE
+        _LANE = self.prev
 
 
 def conv_workspace(device):
-    """Per-device scratch for the split-K tail of conv2d (stream-ordered reuse; one stream per process)."""
-    key = (device.type, device.index)
+    """Per-device, per-lane scratch for the split-K tail of conv2d (stream-ordered reuse; one stream per lane)."""
+    key = (device.type, device.index, _LANE)
     if key not in _WORKSPACE:
         _WORKSPACE[key] = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
     return _WORKSPACE[key]
@@ -127,12 +144,12 @@ _WINO4_WS = {}
 
 
 def wino4_workspace(device, nbytes):
-    """Per-device scratch for the transform-domain input of the F(4x4,3x3) kernel: grows to the largest layer seen
-    (stream-ordered reuse; one stream per process).  A hipGraph must be captured after an eager pass has sized it.
+    """Per-device, per-lane scratch for the transform-domain input of the F(4x4,3x3) kernel: grows to the largest layer
+    seen (stream-ordered reuse; one stream per lane).  A hipGraph must be captured after an eager pass has sized it.
     Growth REPLACES the buffer: whoever recorded its address (a captured hipGraph) keeps the superseded tensor alive
     through `live_workspaces` -- graph.GraphedPath does -- so a replay never writes into memory the caching allocator
     has handed to someone else."""
-    key = (device.type, device.index)
+    key = (device.type, device.index, _LANE)
     ws = _WINO4_WS.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         if device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
@@ -145,7 +162,7 @@ def live_workspaces(device):
     """The scratch tensors launches on `device` are currently handed (split-K workspace, F(4x4) transform-domain
     input).  A captured launch sequence holds on to this list for as long as it can be replayed."""
     key = (device.type, device.index)
-    return [t for t in (_WORKSPACE.get(key), _WINO4_WS.get(key)) if t is not None]
+    return [t for d in (_WORKSPACE, _WINO4_WS) for k, t in d.items() if k[:2] == key]
 
 
 def conv_out_size(n, k, stride, pad_lo, pad_hi):

@@ -445,7 +445,7 @@ def test_effdet_full_size_properties_640(name, batch):
     assert bb.shape[1] == (76725 if name == 'efficientdet-d1' else 8525)
     assert torch.isfinite(sc).all() and torch.isfinite(bb).all()
     rec = batched_post_process(bb, ci, sc, conf, thr)
-    graphed = GraphedPath(m, x, conf, thr)
+    graphed = GraphedPath(m, x, conf, thr, lanes=1)
     rg = graphed(x)
     for k in ('count', 'index', 'class_idx', 'score', 'bbox'):
         assert torch.equal(rg[k], rec[k]), k
@@ -526,7 +526,8 @@ def test_graph_survives_workspace_growth_and_weight_reload(model, monkeypatch):
     m, cfg = model
     monkeypatch.setattr(ops, 'WINO4_MIN_ITEMS', 1)            # every 3x3 layer with Cin >= 64 on the F(4x4) pair -> uses the workspace
     dev = torch.device('cuda', torch.cuda.current_device())
-    ops._WINO4_WS.pop((dev.type, dev.index), None)            # start from no workspace: the small shape sizes it
+    for k in [k for k in ops._WINO4_WS if k[:2] == (dev.type, dev.index)]:
+        ops._WINO4_WS.pop(k)                                  # start from no workspace: the small shape sizes it
     det = Detector(model_and_cfg=(m, cfg))
     conf, nms = 0.005, 0.45
     small = synth.make_images(1, 128, seed=5).cuda()
@@ -538,13 +539,13 @@ def test_graph_survives_workspace_growth_and_weight_reload(model, monkeypatch):
     first = det._records(small, conf, nms)                     # captured + replayed
     assert len(det._graphs.graphs) == 1
     g = next(iter(det._graphs.graphs.values()))
-    ws_small = ops.live_workspaces(dev)[-1]
+    ws_small = ops._WINO4_WS[(dev.type, dev.index, 0)]
     assert any(t.data_ptr() == ws_small.data_ptr() for t in g._held[0])
     for k in ('count', 'bbox', 'score', 'class_idx', 'index'):
         assert torch.equal(first[k], eager_small[k]), k
     with torch.no_grad():                                      # a larger input, eagerly: the workspace is replaced
         m.forward_candidates(large)
-    ws_large = ops.live_workspaces(dev)[-1]
+    ws_large = ops._WINO4_WS[(dev.type, dev.index, 0)]
     assert ws_large.numel() > ws_small.numel() and ws_large.data_ptr() != ws_small.data_ptr()
     ptr_small, n_small = ws_small.data_ptr(), ws_small.numel()
     del ws_small
@@ -675,7 +676,7 @@ def test_hipgraph_replay_equals_eager(model):
     m, cfg = model
     x0 = synth.make_images(4, 320, seed=21).cuda()
     x1 = synth.make_images(4, 320, seed=22).cuda()
-    run = GraphedPath(m, x0, 0.005, 0.45)
+    run = GraphedPath(m, x0, 0.005, 0.45, lanes=1)
     for x in (x0, x1, x0):
         rec = {k: v.clone() for k, v in run(x).items()}
         with torch.no_grad():
@@ -683,6 +684,48 @@ def test_hipgraph_replay_equals_eager(model):
         assert int(ref['count'].sum()) > 0
         for k in ('count', 'index', 'class_idx', 'score', 'bbox'):
             assert torch.equal(rec[k], ref[k]), k
+
+
+@pytest.mark.parametrize('name', ['yolov3_80', 'efficientdet-d1'])
+def test_hipgraph_batch_lanes(name):
+    """Batch lanes (GraphedPath(lanes=2): the two halves of the batch as parallel branches of one hipGraph, each with
+    its own scratch): a replay equals the same decomposition issued from the host bit for bit -- also after a replay
+    with other images, i.e. no lane reads the other's scratch --, equals the two half batches run one after the other
+    on the default stream, and stays within the solo-vs-batch float tolerance of the full-batch pass.  'auto' times
+    both captures and keeps one of them."""
+    from mydetection_amd import synth
+    from mydetection_amd.graph import GraphedPath
+    from mydetection_amd.models.general import name_to_model
+    from mydetection_amd.utils.structures import batched_post_process
+    m, cfg = name_to_model(name)
+    m.load_state_dict(synth.make_state_dict(m.state_dict(), name), strict=True)
+    m = m.eval().cuda()
+    conf, thr = cfg['test.ap_conf_thres'], cfg['test.nms_thres']
+    mk = synth.make_normalized_images if name == 'efficientdet-d1' else synth.make_images
+    x0, x1 = mk(4, 384, seed=31).cuda(), mk(4, 384, seed=32).cuda()
+    run = GraphedPath(m, x0, conf, thr, lanes=2)
+    assert run.lanes == 2
+    for x in (x0, x1, x0):
+        rec = {k: v.clone() for k, v in run(x).items()}
+        cand = run.cand
+        ref = {k: v.clone() for k, v in run.eager(x).items()}
+        with torch.no_grad():
+            halves = [batched_post_process(*m.forward_candidates(h), conf, thr) for h in x.chunk(2)]
+            full = m.forward_candidates(x)
+        assert int(ref['count'].sum()) > 0
+        for k in ('count', 'index', 'class_idx', 'score', 'bbox'):
+            assert torch.equal(rec[k], ref[k]), k
+            assert torch.equal(rec[k], torch.cat([h[k] for h in halves])), k
+        np.testing.assert_allclose(cand[2].cpu().numpy(), full[2].cpu().numpy(), rtol=3e-5, atol=1e-5)
+        np.testing.assert_allclose(cand[0].cpu().numpy(), full[0].cpu().numpy(), rtol=3e-5, atol=1e-5)
+    auto = GraphedPath(m, x0, conf, thr, lanes='auto')
+    assert auto.lanes in (1, 2) and auto.tuned_ms > 0
+    a = auto(x1)
+    b = auto.eager(x1)
+    for k in ('count', 'index', 'class_idx', 'score', 'bbox'):
+        assert torch.equal(a[k], b[k]), k
+    odd = GraphedPath(m, x0[:3].contiguous(), conf, thr, lanes='auto')
+    assert odd.lanes == 1
 
 
 def test_device_preprocessing_vs_reference_golden(model, golden):

@@ -272,7 +272,8 @@ def test_graph_cache_policy_and_workspace_refs():
     del gb
 
     dev = torch.device('cpu')
-    ops._WINO4_WS.pop((dev.type, dev.index), None)
+    for k in [k for k in ops._WINO4_WS if k[:2] == (dev.type, dev.index)]:
+        ops._WINO4_WS.pop(k)
     ws1 = ops.wino4_workspace(dev, 1024)
     held = ops.live_workspaces(dev)
     p1 = ws1.data_ptr()
@@ -280,7 +281,18 @@ def test_graph_cache_policy_and_workspace_refs():
     ws2 = ops.wino4_workspace(dev, 1 << 20)
     assert ws2.data_ptr() != p1 and any(t.data_ptr() == p1 for t in held)       # the old block is still owned by `held`
     assert ops.wino4_workspace(dev, 4096) is ws2                                 # no shrink, no churn
-    ops._WINO4_WS.pop((dev.type, dev.index), None)
+    # batch lanes (graph.GraphedPath): a lane has scratch of its own, and a graph holds every lane's
+    with ops.lane(1):
+        wl = ops.wino4_workspace(dev, 4096)
+        cl = ops.conv_workspace(dev)
+        with ops.lane(0):
+            assert ops.wino4_workspace(dev, 4096) is ws2
+        assert ops.wino4_workspace(dev, 16) is wl
+    assert wl is not ws2 and cl is not ops.conv_workspace(dev) and ops.wino4_workspace(dev, 16) is ws2
+    live = ops.live_workspaces(dev)
+    assert all(any(t is w for t in live) for w in (ws2, wl, cl, ops.conv_workspace(dev)))
+    for k in [k for k in ops._WINO4_WS if k[:2] == (dev.type, dev.index)]:
+        ops._WINO4_WS.pop(k)
     with __import__('pytest').raises(ValueError):
         ops.check_counts([3, -1, 0])
     assert ops.check_counts([0, 5]) == [0, 5]
