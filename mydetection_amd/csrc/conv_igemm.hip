@@ -439,6 +439,11 @@ int forced_cfg() {      // MYDET_CONV_CFG=<id>: tuning only; read per call so th
     return e && *e ? atoi(e) : -1;
 }
 
+bool pw_skinny_on() {   // MYDET_PW_SKINNY=0: tuning only (A/B against the tiled kernel)
+    const char *e = getenv("MYDET_PW_SKINNY");
+    return !(e && *e == '0');
+}
+
 }  // namespace
 
 extern "C" int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *w, const float *scale,
@@ -477,6 +482,12 @@ extern "C" int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *
     a.ws_bytes = workspace_bytes > 0 ? (size_t)workspace_bytes : 0;
     hipStream_t s = (hipStream_t)stream;
     if (forced_cfg() >= 0) return launch_cfg(forced_cfg(), a, s);
+    // few output channels behind a big map (MBConv project convs of the high-resolution stages): the LDS-free skinny
+    // kernel of pointwise.hip (tools/sweep_pointwise.py)
+    if (KH * KW == 1 && stride == 1 && Ho == H && Wo == W && Cout <= 48 && M64 >= 65536 && pw_skinny_on()) {
+        const int rc = mydet_pw_skinny(x, ldx, w, scale, shift, residual, ldr, a_gate, y, ldy, B, H * W, Cin, Cout, act, stream);
+        if (rc != MYDET_E_UNSUPP) return rc;
+    }
     // Tile choice, from the per-shape sweep in profiles/ (tools/sweep_conv_cfg.sh):
     //   narrow outputs take a narrow N tile; short-K layers (1x1 convs, prologue/epilogue-bound) and
     //   grids under ~4 blocks per CU do best with 64x64 tiles at 4 workgroups/CU; the long-K 3x3

@@ -460,6 +460,47 @@ def test_se_gate_and_gated_conv(dev):
         assert (y.cpu().double() - ref).abs().max() < 3e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize('Cin,Cout,H,W,gated,res,act', [
+    (16, 16, 192, 192, True, True, 0), (32, 16, 181, 183, True, False, 0), (96, 24, 192, 176, True, False, 0),
+    (144, 24, 181, 183, True, True, 0), (144, 40, 192, 176, True, False, 0), (240, 40, 181, 183, True, True, 0),
+    (32, 44, 192, 176, False, True, 2), (16, 8, 200, 168, False, False, 1), (144, 48, 181, 183, False, False, 0)])
+def test_pointwise_skinny(dev, monkeypatch, Cin, Cout, H, W, gated, res, act):
+    """The LDS-free skinny 1x1 kernel (csrc/pointwise.hip; mydet_conv2d_igemm_f32 routes Cout <= 48, Cin in
+    {16, 32, 96, 144, 240}, >= 65 536 pixels to it): against a float64 conv, with the SE gate on x, BatchNorm terms,
+    activation, residual, ragged pixel counts (a last workgroup past the end, pixel blocks that straddle the two images)
+    and padded leading dimensions; and against the tiled kernel (MYDET_PW_SKINNY=0) to float32 rounding."""
+    from mydetection_amd import ops
+    g = torch.Generator().manual_seed(Cin * 100 + Cout)
+    B = 2
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    gate = torch.rand(B, Cin, generator=g) if gated else None
+    r = torch.randn(B, Cout, H, W, generator=g) if res else None
+    xin = x.double() * gate.double().view(B, Cin, 1, 1) if gated else x.double()
+    ref = F.conv2d(xin, w.double()) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    if act == 1:
+        ref = torch.where(ref > 0, ref, ref * 0.1)
+    if act == 2:
+        ref = ref * torch.sigmoid(ref)
+    if res:
+        ref = ref + r.double()
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last)
+    args = (xd, w.permute(0, 2, 3, 1).contiguous().to(dev), scale.to(dev), shift.to(dev), 1, 1, (0, 0, 0, 0), act)
+    kw = dict(residual=r.to(dev).contiguous(memory_format=torch.channels_last) if res else None,
+              gate=gate.to(dev) if gated else None)
+    y = ops.conv2d(*args, **kw)
+    tol = 2e-5 * max(1.0, ref.abs().max().item())
+    assert (y.cpu().double() - ref).abs().max() < tol
+    y_pad = ops.conv2d(*args, out_ld=Cout + 8, **kw)                  # a leading dimension wider than Cout
+    assert torch.equal(y_pad.contiguous(), y.contiguous())
+    monkeypatch.setenv('MYDET_PW_SKINNY', '0')
+    y_tiled = ops.conv2d(*args, **kw)
+    monkeypatch.delenv('MYDET_PW_SKINNY')
+    assert (y_tiled.cpu().double() - ref).abs().max() < tol
+    assert not torch.equal(y_tiled, y) or Cin == 16       # two kernels, two summation orders (K = 16 can coincide)
+
+
 def test_maxpool_and_bifpn_fuse(dev):
     from mydetection_amd import ops
     g = torch.Generator().manual_seed(5)

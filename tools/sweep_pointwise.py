@@ -13,6 +13,7 @@ from mydetection_amd import ops                                           # noqa
 ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=16)
 ap.add_argument('--cfgs', default='0,1,2,3,6,8')
+ap.add_argument('--first', type=int, default=0, help='only the first N shapes (7 = the ones the skinny kernel of pointwise.hip takes)')
 a = ap.parse_args()
 dev = torch.device('cuda')
 B = a.batch
@@ -47,7 +48,7 @@ def timeit(run):
 
 cfgs = [int(c) for c in a.cfgs.split(',')]
 print(f'{"shape":28s} {"default":>9s} ' + ' '.join(f'cfg{c:>2d}    ' for c in cfgs))
-for cin, cout, hw, act, gate, res in SHAPES:
+for cin, cout, hw, act, gate, res in (SHAPES[:a.first] if a.first else SHAPES):
     x = torch.randn(B, hw, hw, cin, device=dev).permute(0, 3, 1, 2)
     w = (torch.randn(cout, 1, 1, cin, device=dev) / cin ** 0.5).contiguous()
     sc, sh = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev) * 0.1
