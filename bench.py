@@ -312,9 +312,14 @@ def main():
     stages['postprocess']['p50_note'] = ('p50/p95: 100 back-to-back launches on the step\'s candidates after the timed region, own start/stop '
                                          'events per launch; in_step_p50_ms: the launch inside the timed steps (chained events)')
     stages['postprocess']['mean_detections_per_image'] = round(float(rec['count'].float().mean()), 1)
-    dec_ms, dec_bytes = summ['decode'][1], summ['decode'][2]
-    stages['decode']['achieved_GBs'] = round(dec_bytes / (dec_ms * 1e-3) / 1e9, 1)
-    stages['decode']['frac_hbm_peak'] = round(dec_bytes / (dec_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+    if 'decode' in summ:
+        dec_ms, dec_bytes = summ['decode'][1], summ['decode'][2]
+        stages['decode']['achieved_GBs'] = round(dec_bytes / (dec_ms * 1e-3) / 1e9, 1)
+        stages['decode']['frac_hbm_peak'] = round(dec_bytes / (dec_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+    if 'sepconv_decode' in summ:
+        stages['sepconv_decode']['note'] = ('the towers\' last separable convs with the RetinaNet decode in their epilogue: class logits '
+                                            'never reach memory; algorithmic_GBs prices it with the bytes of the three reference layers '
+                                            '(depthwise, pointwise, decode)')
     for k, v in summ.items():                                    # algorithmic bytes / time per family
         if timer.bytes.get(k):
             stages[k]['algorithmic_GBs'] = round(timer.bytes[k] / (v[1] * 1e-3) / 1e9, 1)

@@ -333,6 +333,29 @@ typedef struct {
 } mydet_sepconv_node;
 int mydet_sepconv_nodes_f32(int n, const mydet_sepconv_node *nodes, int B, int C, void *stream);
 
+/* The LAST layers of the EfDetHead towers with RetinaLayer's decode in their epilogue: replaces the last
+ * SeparableConv2d of class_nets / bbox_nets (models/rpns.py:121-197) + RetinaLayer.forward
+ * (models/detlayers/retinanet.py:63-82) + the level concatenation of models/general.py:74-76, i.e.
+ * mydet_sepconv_nodes_f32 + mydet_decode_levels_f32(MYDET_DECODE_RETINA) without the A*n_cls class logits per pixel ever
+ * reaching memory.  Same results as that pair (same arithmetic, candidate order (a, y, x), first maximum on ties).
+ *   kind 0 (class tower): node.Cout = A * cpad, cpad = 16 * ceil(n_cls / 16): w_pw_packed / shift hold anchor a's n_cls
+ *           rows at [a * cpad, a * cpad + n_cls), zero rows after them; writes score (sigmoid of the anchor's largest
+ *           logit) and class_idx.  n_cls in 65..96.
+ *   kind 1 (box tower):   node.Cout = 4 * A (tx, ty, tw, th per anchor); anchors_wh = HOST pointer to A (w, h) pairs in
+ *           pixels; writes bbox (cx, cy, w, h clamped to [1, max(img_h, img_w)]).
+ * node.y / node.ldy are ignored, node.n_in == 1, node.act == MYDET_ACT_NONE.  n_off = first candidate of the node's
+ * level inside [0, N).  bbox [B,N,4] f32, class_idx [B,N] i64, score [B,N] f32.  C == 88, A <= 12. */
+typedef struct {
+    mydet_sepconv_node node;
+    int kind;
+    float stride;
+    const float *anchors_wh;
+    int64_t n_off;
+} mydet_sepconv_decode_node;
+int mydet_sepconv_decode_retina_f32(int n, const mydet_sepconv_decode_node *nodes, int B, int C, int A, int n_cls,
+                                    int img_h, int img_w, float *bbox, int64_t *class_idx, float *score, int64_t N,
+                                    void *stream);
+
 /* Pairwise IoU [Na,Nb]; utils/bbox_ops.py:6-49 (xyxy != 0: corner format, else cxcywh). */
 int mydet_bboxes_iou_f32(const float *a, int Na, const float *b, int Nb, int xyxy,
                          float *iou, void *stream);

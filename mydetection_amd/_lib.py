@@ -46,6 +46,7 @@ SIGNATURES = {
     'mydet_mbconv_tiles': [c_int, c_int, c_int],
     'mydet_mbconv_expand_dw_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64] + [c_int] * 11 + [c_ptr, c_int, c_ptr],
     'mydet_sepconv_nodes_f32': [c_int, c_ptr, c_int, c_int, c_ptr],
+    'mydet_sepconv_decode_retina_f32': [c_int, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_i64, c_ptr],
     'mydet_bboxes_iou_f32': [c_ptr, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr],
     'mydet_bboxes_to_original_batched_f32': [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr],
     'mydet_detections_to_json_f64': [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr],
@@ -78,6 +79,11 @@ class SepconvNode(ctypes.Structure):
     _fields_ = [('inp', c_ptr * 3), ('ld', c_i64 * 3), ('mode', c_int * 3), ('n_in', c_int), ('fuse_weights', c_ptr),
                 ('w_dw', c_ptr), ('w_pw_packed', c_ptr), ('scale', c_ptr), ('shift', c_ptr), ('y', c_ptr), ('ldy', c_i64),
                 ('H', c_int), ('W', c_int), ('Cout', c_int), ('act', c_int)]
+
+
+class SepconvDecodeNode(ctypes.Structure):
+    """mydet_sepconv_decode_node (include/mydet.h)."""
+    _fields_ = [('node', SepconvNode), ('kind', c_int), ('stride', c_f32), ('anchors_wh', c_ptr), ('n_off', c_i64)]
 
 
 SEPCONV_MAX_NODES = 10

@@ -73,7 +73,7 @@ __device__ __forceinline__ int mydet_xcd_remap(int bid, int nblk) {
     return base + (bid >> 3);
 }
 
-// pointwise.hip: skinny 1x1 conv (Cout <= 48, Cin in {16, 32, 96, 144, 240}); MYDET_E_UNSUPP otherwise.  Library-internal.
+// pointwise.hip: LDS-free-x 1x1 conv (Cin <= 240, Cout % 4 == 0); MYDET_E_UNSUPP otherwise.  Library-internal.
 int mydet_pw_skinny(const float *x, int64_t ldx, const float *w, const float *scale, const float *shift,
                     const float *residual, int64_t ldr, const float *gate, float *y, int64_t ldy, int B, int HW, int Cin,
                     int Cout, int act, void *stream);

@@ -439,6 +439,11 @@ int forced_cfg() {      // MYDET_CONV_CFG=<id>: tuning only; read per call so th
     return e && *e ? atoi(e) : -1;
 }
 
+bool pw_wide_on() {     // MYDET_PW_WIDE=1: every 1x1 conv with Cin <= 240 goes to pointwise.hip (tuning only)
+    const char *e = getenv("MYDET_PW_WIDE");
+    return e && *e == '1';
+}
+
 bool pw_skinny_on() {   // MYDET_PW_SKINNY=0: tuning only (A/B against the tiled kernel)
     const char *e = getenv("MYDET_PW_SKINNY");
     return !(e && *e == '0');
@@ -484,7 +489,8 @@ extern "C" int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *
     if (forced_cfg() >= 0) return launch_cfg(forced_cfg(), a, s);
     // few output channels behind a big map (MBConv project convs of the high-resolution stages): the LDS-free skinny
     // kernel of pointwise.hip (tools/sweep_pointwise.py)
-    if (KH * KW == 1 && stride == 1 && Ho == H && Wo == W && Cout <= 48 && M64 >= 65536 && pw_skinny_on()) {
+    if (KH * KW == 1 && stride == 1 && Ho == H && Wo == W && pw_skinny_on() &&
+        ((Cout <= 48 && M64 >= 65536) || pw_wide_on())) {
         const int rc = mydet_pw_skinny(x, ldx, w, scale, shift, residual, ldr, a_gate, y, ldy, B, H * W, Cin, Cout, act, stream);
         if (rc != MYDET_E_UNSUPP) return rc;
     }

@@ -34,10 +34,12 @@ constexpr int PW_WAVES = 4;
 
 template <int KC, int NB, int PB, int DEPTH, bool GATE>
 __global__ __launch_bounds__(PW_WAVES * 64) void pw_skinny_kernel(const PwArgs p) {
-    constexpr int K = KC * 16;
+    constexpr int KP = KC * 16;                    // K rounded up to whole chunks
     constexpr int WG_PIX = PW_WAVES * PB * 16;
     __shared__ __attribute__((aligned(16))) float wl[NB * KC * 64 * 4];
-    __shared__ __attribute__((aligned(16))) float gl[GATE ? 2 * K : 4];
+    __shared__ __attribute__((aligned(16))) float gl[GATE ? 2 * KP : 4];
+    const int K = p.K;                             // (KC - 1) * 16 < K <= KC * 16, K % 4 == 0
+    const int n0 = blockIdx.y * (NB * 16);         // this workgroup's slab of output channels
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int j = lane & 15, kk = lane >> 4;
     const int64_t m_wg = (int64_t)blockIdx.x * WG_PIX;
@@ -45,14 +47,20 @@ __global__ __launch_bounds__(PW_WAVES * 64) void pw_skinny_kernel(const PwArgs p
 
     // pixel rows: unconditional loads at clamped pixel indices (a ragged last workgroup re-reads the last pixel)
     f32x4 a[DEPTH][KC];
-    const float *xbase = p.x + kk * 4;
+    // the last chunk of a K that is not a multiple of 16: lanes whose four k lie beyond K load the row's last four
+    // channels instead and are zeroed (the matching weights are zero as well)
+    const int k_tail = (KC - 1) * 16 + kk * 4;
+    const bool tail_ok = k_tail < K;
+    const float *xbase = p.x + kk * 4, *xtail = p.x + (tail_ok ? k_tail : K - 4);
     const int64_t ldx = p.ldx, m_last = (int64_t)p.M - 1;
 #define PW_LOAD_BLOCK(pb_, dst_)                                                              \
     {                                                                                         \
         int64_t m_ = m_wave + (pb_) * 16 + j;                                                 \
         m_ = m_ < m_last ? m_ : m_last;                                                       \
         const float *xp_ = xbase + m_ * ldx;                                                  \
-        _Pragma("unroll") for (int i_ = 0; i_ < KC; ++i_)(dst_)[i_] = *reinterpret_cast<const f32x4 *>(xp_ + i_ * 16); \
+        _Pragma("unroll") for (int i_ = 0; i_ < KC - 1; ++i_)(dst_)[i_] = *reinterpret_cast<const f32x4 *>(xp_ + i_ * 16); \
+        (dst_)[KC - 1] = *reinterpret_cast<const f32x4 *>(xtail + m_ * ldx);                  \
+        if (!tail_ok) (dst_)[KC - 1] = f32x4{0.f, 0.f, 0.f, 0.f};                             \
     }
 #pragma unroll
     for (int d = 0; d < DEPTH - 1 && d < PB; ++d) PW_LOAD_BLOCK(d, a[d])
@@ -68,9 +76,9 @@ __global__ __launch_bounds__(PW_WAVES * 64) void pw_skinny_kernel(const PwArgs p
     for (int it = 0; it < WIT; ++it) {
         const int idx = min(tid + it * PW_WAVES * 64, NB * KC * 64 - 1);
         const int l = idx & 63, t = idx >> 6, i = t % KC, nb = t / KC;
-        const int c = nb * 16 + (l & 15);
-        wt[it] = *reinterpret_cast<const f32x4 *>(p.w + (int64_t)min(c, p.Cout - 1) * K + i * 16 + (l >> 4) * 4);
-        if (c >= p.Cout) wt[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int c = n0 + nb * 16 + (l & 15), k = i * 16 + (l >> 4) * 4;
+        wt[it] = *reinterpret_cast<const f32x4 *>(p.w + (int64_t)min(c, p.Cout - 1) * K + min(k, K - 4));
+        if (c >= p.Cout || k >= K) wt[it] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int it = 0; it < WIT; ++it) {
@@ -80,10 +88,11 @@ __global__ __launch_bounds__(PW_WAVES * 64) void pw_skinny_kernel(const PwArgs p
     const int b0 = (int)(m_wg / p.HW);
     if (GATE) {
         const int nimg = (p.M + p.HW - 1) / p.HW;
-        for (int idx = tid; idx < 2 * K / 4; idx += PW_WAVES * 64) {
-            const int which = idx / (K / 4), q = idx - which * (K / 4);
+        for (int idx = tid; idx < 2 * KP / 4; idx += PW_WAVES * 64) {
+            const int which = idx / (KP / 4), q = idx - which * (KP / 4);
             const int b = min(b0 + which, nimg - 1);
-            *reinterpret_cast<f32x4 *>(&gl[which * K + q * 4]) = *reinterpret_cast<const f32x4 *>(p.gate + (int64_t)b * K + q * 4);
+            *reinterpret_cast<f32x4 *>(&gl[which * KP + q * 4]) =
+                *reinterpret_cast<const f32x4 *>(p.gate + (int64_t)b * K + min(q * 4, K - 4));       // beyond K: x is zero there
         }
     }
     mydet_lds_barrier();              // orders the LDS copies only: the pixel loads stay in flight across it
@@ -97,7 +106,7 @@ __global__ __launch_bounds__(PW_WAVES * 64) void pw_skinny_kernel(const PwArgs p
         const int64_t m = m_wave + pb * 16 + j;
         if (GATE) {
             // the workgroup's pixels lie in image b0 or b0 + 1 (HW >= WG_PIX is checked on the host)
-            const float *gp = gl + (m >= (int64_t)(b0 + 1) * p.HW ? K : 0) + kk * 4;
+            const float *gp = gl + (m >= (int64_t)(b0 + 1) * p.HW ? KP : 0) + kk * 4;
 #pragma unroll
             for (int i = 0; i < KC; ++i) {
                 const f32x4 g = *reinterpret_cast<const f32x4 *>(gp + i * 16);
@@ -125,7 +134,7 @@ __global__ __launch_bounds__(PW_WAVES * 64) void pw_skinny_kernel(const PwArgs p
             const float *rp = p.res ? p.res + m * p.ldr : nullptr;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const int n = nb * 16 + kk * 4;
+                const int n = n0 + nb * 16 + kk * 4;
                 if (n < p.Cout) {
                     f32x4 v;
 #pragma unroll
@@ -147,22 +156,37 @@ __global__ __launch_bounds__(PW_WAVES * 64) void pw_skinny_kernel(const PwArgs p
 }
 
 template <int KC, int NB, int PB, int DEPTH>
-int pw_launch(const PwArgs &a, hipStream_t s) {
+int pw_launch(const PwArgs &a, int slabs, hipStream_t s) {
     constexpr int WG_PIX = PW_WAVES * PB * 16;
-    const unsigned grid = (unsigned)(((int64_t)a.M + WG_PIX - 1) / WG_PIX);
-    if (a.gate)
-        hipLaunchKernelGGL((pw_skinny_kernel<KC, NB, PB, DEPTH, true>), dim3(grid), dim3(PW_WAVES * 64), 0, s, a);
-    else
-        hipLaunchKernelGGL((pw_skinny_kernel<KC, NB, PB, DEPTH, false>), dim3(grid), dim3(PW_WAVES * 64), 0, s, a);
+    const dim3 grid((unsigned)(((int64_t)a.M + WG_PIX - 1) / WG_PIX), (unsigned)slabs);
+    if constexpr (NB <= 3) {
+        if (a.gate) {
+            hipLaunchKernelGGL((pw_skinny_kernel<KC, NB, PB, DEPTH, true>), grid, dim3(PW_WAVES * 64), 0, s, a);
+            return mydet_launch_status();
+        }
+    }
+    if (a.gate) return MYDET_E_UNSUPP;
+    hipLaunchKernelGGL((pw_skinny_kernel<KC, NB, PB, DEPTH, false>), grid, dim3(PW_WAVES * 64), 0, s, a);
     return mydet_launch_status();
 }
 
+// Output channels are cut into slabs of NB 16-channel blocks (grid.y): a slab's weights (NB * KC KB in operand order)
+// must fit LDS several times per CU, and a wave's accumulators its registers.  x is re-read once per slab, from L2.
 template <int KC, int PB, int DEPTH>
 int pw_launch_nb(const PwArgs &a, hipStream_t s) {
-    const int nb = (a.Cout + 15) / 16;
-    if (nb == 1) return pw_launch<KC, 1, PB, DEPTH>(a, s);
-    if (nb == 2) return pw_launch<KC, 2, PB, DEPTH>(a, s);
-    return pw_launch<KC, 3, PB, DEPTH>(a, s);
+    constexpr int CAP = KC >= 16 ? 2 : KC >= 12 ? 4 : KC >= 10 ? 4 : KC >= 8 ? 5 : 6;
+    const int nblocks = (a.Cout + 15) / 16;
+    const int slabs = (nblocks + CAP - 1) / CAP;
+    const int nb = (nblocks + slabs - 1) / slabs;
+    switch (nb) {
+        case 1: return pw_launch<KC, 1, PB, DEPTH>(a, slabs, s);
+        case 2: return pw_launch<KC, 2, PB, DEPTH>(a, slabs, s);
+        case 3: return pw_launch<KC, 3, PB, DEPTH>(a, slabs, s);
+        case 4: return pw_launch<KC, 4, PB, DEPTH>(a, slabs, s);
+        case 5: if constexpr (CAP >= 5) return pw_launch<KC, 5, PB, DEPTH>(a, slabs, s);
+        case 6: if constexpr (CAP >= 6) return pw_launch<KC, 6, PB, DEPTH>(a, slabs, s);
+        default: return MYDET_E_UNSUPP;
+    }
 }
 
 }  // namespace
@@ -173,18 +197,25 @@ int mydet_pw_skinny(const float *x, int64_t ldx, const float *w, const float *sc
                     const float *residual, int64_t ldr, const float *gate, float *y, int64_t ldy, int B, int HW, int Cin,
                     int Cout, int act, void *stream) {
     const int64_t M = (int64_t)B * HW;
-    if (Cout > 48 || (Cout & 3) || (Cin & 15) || M >= ((int64_t)1 << 31)) return MYDET_E_UNSUPP;
+    if ((Cout & 3) || (Cin & 3) || Cin < 4 || Cin > 240 || M >= ((int64_t)1 << 31)) return MYDET_E_UNSUPP;
     // a workgroup covers at most 512 consecutive pixels: two images at most when a map has that many
-    if (gate && HW < 512) return MYDET_E_UNSUPP;
+    if (gate && (HW < 512 || Cout > 48)) return MYDET_E_UNSUPP;
     PwArgs a;
     a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.res = residual; a.gate = gate; a.y = y;
     a.ldx = ldx; a.ldr = ldr; a.ldy = ldy; a.M = (int)M; a.HW = HW; a.K = Cin; a.Cout = Cout; a.act = act;
     hipStream_t s = (hipStream_t)stream;
-    switch (Cin / 16) {
+    switch ((Cin + 15) / 16) {
         case 1: return pw_launch_nb<1, 8, 8>(a, s);
         case 2: return pw_launch_nb<2, 8, 4>(a, s);
+        case 3: return pw_launch_nb<3, 4, 2>(a, s);
+        case 4: return pw_launch_nb<4, 4, 2>(a, s);
+        case 5: return pw_launch_nb<5, 4, 2>(a, s);
         case 6: return pw_launch_nb<6, 4, 2>(a, s);
+        case 7: return pw_launch_nb<7, 4, 2>(a, s);
+        case 8: return pw_launch_nb<8, 4, 2>(a, s);
         case 9: return pw_launch_nb<9, 4, 2>(a, s);
+        case 10: return pw_launch_nb<10, 4, 2>(a, s);
+        case 12: return pw_launch_nb<12, 4, 2>(a, s);
         case 15: return pw_launch_nb<15, 4, 2>(a, s);
         default: return MYDET_E_UNSUPP;
     }

@@ -259,33 +259,17 @@ __device__ __forceinline__ void sp_stage_item(const SpNode &P, const SpItem &it,
 }
 
 
+// Phases 0-2 of a work item, shared by the node kernel and the decoding node kernel: on return the 64 x C operand tile of
+// the pointwise conv lies in `lds` ([64 px][C + 1]) and `af` holds the weight fragments of channel block `nb_first`.
 template <int KS>
-__global__ __launch_bounds__(256, 4) void sepconv_kernel(const SpArgs a) {
+__device__ __forceinline__ void sp_front(const SpNode &P, float *lds, float *swd, int tid, int b, int oy0, int ox0,
+                                         int nb_first, float (&af)[KS]) {
     constexpr int C = KS * 4, Q = KS, XS = C + 1;
-    constexpr int LDS_FLOATS = HS * HS * C > TS * TS * XS ? HS * HS * C : TS * TS * XS;
-    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS + 9 * C];
-    float *swd = lds + LDS_FLOATS;                            // the node's depthwise taps [9][C]
-    const int tid = threadIdx.x, bid = blockIdx.x;
-    int pi = 0;
-    for (int i = 1; i < a.n; ++i)
-        if (bid >= a.p[i].tile_begin) pi = i;                 // uniform
-    const SpNode &P = a.p[pi];
-    // work item = (tile, slice of the output-channel blocks): small maps are cut along the channels as well, so a
-    // 5x5 level does not leave 240 CUs idle while 16 workgroups walk all of Cout
-    const int t0 = bid - P.tile_begin;
-    const int t = t0 / P.nsplit, ns = t0 - t * P.nsplit;
-    const int nb_begin = ns * P.nb_per, nb_end = min(P.nb, nb_begin + P.nb_per);
-    const int b = t / P.tiles_per_img, r = t - b * P.tiles_per_img;
-    const int ty = r / P.tiles_x, tx = r - ty * P.tiles_x;
-    const int oy0 = ty * TS, ox0 = tx * TS;
-    const int H = P.H, W = P.W;
-
     // 0. everything that does not depend on the halo is requested first: the depthwise taps (-> LDS), the first block's
     //    weight fragments (registers); their L2 round trip overlaps the halo's
-    const int wave = tid >> 6, lane = tid & 63;
-    float af[KS];
+    const int lane = tid & 63;
     {
-        const float *wp = P.wpk + (int64_t)min(nb_begin, P.nb - 1) * KS * 64 + lane;
+        const float *wp = P.wpk + (int64_t)min(nb_first, P.nb - 1) * KS * 64 + lane;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) af[ks] = wp[ks * 64];
     }
@@ -293,7 +277,7 @@ __global__ __launch_bounds__(256, 4) void sepconv_kernel(const SpArgs a) {
     // 1. halo of pre(x): every load unconditional at clamped coordinates, several halo entries per thread in flight
     {
         SpItem it;
-        it.pi = pi; it.b = b; it.oy0 = oy0; it.ox0 = ox0; it.nb_begin = nb_begin; it.nb_end = nb_end;
+        it.pi = 0; it.b = b; it.oy0 = oy0; it.ox0 = ox0; it.nb_begin = 0; it.nb_end = 0;
         sp_stage_item<KS, 128>(P, it, lds, tid);
     }
     __syncthreads();
@@ -337,6 +321,31 @@ __global__ __launch_bounds__(256, 4) void sepconv_kernel(const SpArgs a) {
         }
     }
     __syncthreads();
+}
+
+template <int KS>
+__global__ __launch_bounds__(256, 4) void sepconv_kernel(const SpArgs a) {
+    constexpr int C = KS * 4, XS = C + 1;
+    constexpr int LDS_FLOATS = HS * HS * C > TS * TS * XS ? HS * HS * C : TS * TS * XS;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS + 9 * C];
+    float *swd = lds + LDS_FLOATS;                            // the node's depthwise taps [9][C]
+    const int tid = threadIdx.x, bid = blockIdx.x;
+    int pi = 0;
+    for (int i = 1; i < a.n; ++i)
+        if (bid >= a.p[i].tile_begin) pi = i;                 // uniform
+    const SpNode &P = a.p[pi];
+    // work item = (tile, slice of the output-channel blocks): small maps are cut along the channels as well, so a
+    // 5x5 level does not leave 240 CUs idle while 16 workgroups walk all of Cout
+    const int t0 = bid - P.tile_begin;
+    const int t = t0 / P.nsplit, ns = t0 - t * P.nsplit;
+    const int nb_begin = ns * P.nb_per, nb_end = min(P.nb, nb_begin + P.nb_per);
+    const int b = t / P.tiles_per_img, r = t - b * P.tiles_per_img;
+    const int ty = r / P.tiles_x, tx = r - ty * P.tiles_x;
+    const int oy0 = ty * TS, ox0 = tx * TS;
+    const int H = P.H, W = P.W;
+    const int wave = tid >> 6, lane = tid & 63;
+    float af[KS];
+    sp_front<KS>(P, lds, swd, tid, b, oy0, ox0, nb_begin, af);
 
     // 3. pointwise conv, transposed: D[channel][pixel] = sum_k W[channel][k] * X[pixel][k]
     const int m0 = wave * 16;
@@ -388,6 +397,166 @@ __global__ __launch_bounds__(256, 4) void sepconv_kernel(const SpArgs a) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) af[ks] = an[ks];
     }
+}
+
+
+// ------------------------------------------------------------------------------------------- decoding head nodes
+// The LAST layer of an EfDetHead tower with RetinaLayer's decode in its epilogue (models/rpns.py:121-197 ->
+// models/detlayers/retinanet.py:63-82): the class tower's 9 x 90 logits per pixel (442 MB per 16 images at 640^2)
+// are never written -- a lane holds 4 consecutive classes of one pixel, keeps the running maximum / first argmax of the
+// current anchor over the anchor's channel blocks, the four lanes of a pixel are merged by lane exchange, and
+// score = sigmoid(max logit), class index go straight to the candidate arrays; the box tower's 4 logits per anchor are
+// exactly one lane's 4 channels and leave as a decoded box.  Same arithmetic as decode_kernel (decode.hip), same
+// candidate order (a, y, x).
+constexpr int DEC_MAX_A = 12;
+struct SpDecNode {
+    int kind;                       // 0 class tower, 1 box tower
+    float stride;
+    int64_t n_off;
+    float aw[DEC_MAX_A], ah[DEC_MAX_A];
+};
+struct SpDecArgs {
+    int n, B, A, n_cls, img_h, img_w;
+    int64_t N;
+    float *bbox, *score;
+    int64_t *cidx;
+    SpNode p[SP_MAX];
+    SpDecNode d[SP_MAX];
+};
+
+// first maximum of sigmoid(x) over increasing k.  Below 5 the logits are compared (sigmoid is monotone; decode_kernel does
+// the same); from 5 up float32 sigmoids of different logits coincide more and more (all of them from 17.4), so there
+// the sigmoid values decide and an equal value keeps the earlier class -- what torch.max over the sigmoids returns.
+__device__ __forceinline__ void dec_update(float &best, int &bi, float x, int k) {
+    if (x > best) {
+        if (x < 5.0f || mydet_sigmoid(x) > mydet_sigmoid(best)) {
+            best = x;
+            bi = k;
+        }
+    }
+}
+
+template <int KS, int NBA>
+__global__ __launch_bounds__(256, 4) void sepconv_decode_kernel(const SpDecArgs a) {
+    constexpr int C = KS * 4, XS = C + 1;
+    constexpr int LDS_FLOATS = HS * HS * C > TS * TS * XS ? HS * HS * C : TS * TS * XS;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS + 9 * C];
+    __shared__ float s_aw[DEC_MAX_A], s_ah[DEC_MAX_A];
+    float *swd = lds + LDS_FLOATS;
+    const int tid = threadIdx.x, bid = blockIdx.x;
+    int pi = 0;
+    for (int i = 1; i < a.n; ++i)
+        if (bid >= a.p[i].tile_begin) pi = i;                 // uniform
+    const SpNode &P = a.p[pi];
+    const int kind = a.d[pi].kind;
+    const float st = a.d[pi].stride;
+    const int64_t n_off = a.d[pi].n_off;
+    if (tid < DEC_MAX_A) { s_aw[tid] = a.d[pi].aw[tid]; s_ah[tid] = a.d[pi].ah[tid]; }
+    const int t0 = bid - P.tile_begin;
+    const int t = t0 / P.nsplit, ns = t0 - t * P.nsplit;
+    const int nb_begin = ns * P.nb_per, nb_end = min(P.nb, nb_begin + P.nb_per);       // class nodes: whole anchors
+    const int b = t / P.tiles_per_img, r = t - b * P.tiles_per_img;
+    const int ty = r / P.tiles_x, tx = r - ty * P.tiles_x;
+    const int oy0 = ty * TS, ox0 = tx * TS;
+    const int H = P.H, W = P.W;
+    const int wave = tid >> 6, lane = tid & 63;
+    float af[KS];
+    sp_front<KS>(P, lds, swd, tid, b, oy0, ox0, nb_begin, af);
+
+    const int m0 = wave * 16;
+    float bf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) bf[ks] = lds[(m0 + (lane & 15)) * XS + ks * 4 + (lane >> 4)];
+    const int px = m0 + (lane & 15);
+    const int oy = oy0 + (px >> 3), ox = ox0 + (px & 7);
+    const bool valid = oy < H && ox < W;
+    const int kk = lane >> 4, nsub = kk * 4;
+    const int64_t cand0 = (int64_t)b * a.N + n_off + (int64_t)oy * W + ox;               // + a * H * W
+    const int64_t hw = (int64_t)H * W;
+
+    // one 16-channel block: acc = W[nb] . X^T + shift (the NEXT block's fragments are requested first, as in sepconv_kernel)
+#define SP_DEC_BLOCK(nb_, v_)                                                                         \
+    {                                                                                                 \
+        float an_[KS];                                                                                \
+        const float *wp_ = P.wpk + (int64_t)min((nb_) + 1, P.nb - 1) * KS * 64 + lane;                \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) an_[ks] = wp_[ks * 64];                     \
+        const f32x4 sh_ = *reinterpret_cast<const f32x4 *>(P.shift + (nb_) * 16 + nsub);              \
+        f32x4 sc_ = {1.f, 1.f, 1.f, 1.f};                                                             \
+        if (P.scale) sc_ = *reinterpret_cast<const f32x4 *>(P.scale + (nb_) * 16 + nsub);             \
+        f32x4 acc0_ = {0.f, 0.f, 0.f, 0.f}, acc1_ = {0.f, 0.f, 0.f, 0.f};                             \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ks += 2) {                                        \
+            acc0_ = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks], bf[ks], acc0_, 0, 0, 0);             \
+            acc1_ = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks + 1], bf[ks + 1], acc1_, 0, 0, 0);     \
+        }                                                                                             \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) acc0_[e] = acc0_[e] + acc1_[e];                 \
+        if (P.scale) {                                                                                \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) acc0_[e] = acc0_[e] * sc_[e] + sh_[e];      \
+        } else {                                                                                      \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) acc0_[e] = acc0_[e] + sh_[e];               \
+        }                                                                                             \
+        (v_) = acc0_;                                                                                 \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) af[ks] = an_[ks];                           \
+    }
+
+    if (kind == 0) {
+        const float ninf = -__builtin_inff();
+        for (int an = nb_begin / NBA; an < nb_end / NBA; ++an) {
+            float best = ninf;
+            int bi = 0;
+#pragma unroll
+            for (int blk = 0; blk < NBA; ++blk) {
+                f32x4 v;
+                SP_DEC_BLOCK(an * NBA + blk, v)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = blk * 16 + nsub + e;
+                    if (k < a.n_cls) dec_update(best, bi, v[e], k);
+                }
+            }
+            // the pixel's four lanes hold interleaved class subsets: the larger value wins, an equal one only with the
+            // lower class index (= the first maximum of the sequential scan)
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) {
+                const float ob = __shfl_xor(best, off);
+                const int obi = __shfl_xor(bi, off);
+                bool gt = ob > best, eq = ob == best;
+                if (fmaxf(ob, best) >= 5.0f) {
+                    const float so = mydet_sigmoid(ob), sb = mydet_sigmoid(best);
+                    gt = so > sb;
+                    eq = so == sb;
+                }
+                const bool take = gt || (eq && obi < bi);
+                best = take ? ob : best;
+                bi = take ? obi : bi;
+            }
+            if (kk == 0 && valid) {
+                const int64_t n = cand0 + (int64_t)an * hw;
+                a.score[n] = mydet_sigmoid(best);
+                a.cidx[n] = (int64_t)bi;
+            }
+        }
+    } else {
+        const float fmaxhw = (float)(a.img_h > a.img_w ? a.img_h : a.img_w);
+        for (int nb = nb_begin; nb < nb_end; ++nb) {
+            f32x4 v;
+            SP_DEC_BLOCK(nb, v)
+            const int an = nb * 4 + kk;                         // a lane's 4 channels are one anchor's (tx, ty, tw, th)
+            if (valid && an < a.A) {
+                const float aw = s_aw[an], ah = s_ah[an];
+                const float acx = st * 0.5f + (float)ox * st;
+                const float acy = st * 0.5f + (float)oy * st;
+                f32x4 o;
+                o[0] = acx + v[0] * aw;
+                o[1] = acy + v[1] * ah;
+                o[2] = expf(v[2]) * aw;
+                o[3] = expf(v[3]) * ah;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = fminf(fmaxf(o[j], 1.0f), fmaxhw);
+                *reinterpret_cast<f32x4 *>(a.bbox + (cand0 + (int64_t)an * hw) * 4) = o;
+            }
+        }
+    }
+#undef SP_DEC_BLOCK
 }
 
 
@@ -449,5 +618,64 @@ extern "C" int mydet_sepconv_nodes_f32(int n, const mydet_sepconv_node *nodes, i
     }
     a.total = (int)tiles;
     hipLaunchKernelGGL((sepconv_kernel<22>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
+    return mydet_launch_status();
+}
+
+extern "C" int mydet_sepconv_decode_retina_f32(int n, const mydet_sepconv_decode_node *nodes, int B, int C, int A, int n_cls,
+                                               int img_h, int img_w, float *bbox, int64_t *class_idx, float *score,
+                                               int64_t N, void *stream) {
+    if (n <= 0 || n > SP_MAX || !nodes || B <= 0 || A <= 0 || n_cls <= 0 || N <= 0 || !bbox || !class_idx || !score)
+        return MYDET_E_BADARG;
+    if (C != 88 || A > DEC_MAX_A) return MYDET_E_UNSUPP;
+    const int nba = (n_cls + 15) / 16;                       // channel blocks per anchor of a class node
+    if (nba != 5 && nba != 6) return MYDET_E_UNSUPP;         // 65..96 classes (COCO's 80 / 90 / 91)
+    if (!al16(bbox)) return MYDET_E_BADARG;
+    SpDecArgs a;
+    a.n = n; a.B = B; a.A = A; a.n_cls = n_cls; a.img_h = img_h; a.img_w = img_w; a.N = N;
+    a.bbox = bbox; a.score = score; a.cidx = class_idx;
+    int64_t tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        const mydet_sepconv_node &s = nodes[i].node;
+        SpNode &p = a.p[i];
+        SpDecNode &d = a.d[i];
+        if (nodes[i].kind != 0 && nodes[i].kind != 1) return MYDET_E_BADARG;
+        if (s.n_in != 1 || s.mode[0] != 0 || s.H <= 0 || s.W <= 0 || s.act != MYDET_ACT_NONE) return MYDET_E_BADARG;
+        if (s.Cout != (nodes[i].kind == 0 ? A * nba * 16 : A * 4)) return MYDET_E_BADARG;
+        if (!s.in[0] || !al16(s.in[0]) || (s.ld[0] & 3) || s.ld[0] < C || !s.w_dw || !s.w_pw_packed || !s.shift ||
+            !al16(s.w_dw) || !al16(s.w_pw_packed) || !al16(s.shift) || (s.scale && !al16(s.scale)))
+            return MYDET_E_BADARG;
+        if (nodes[i].kind == 1 && !nodes[i].anchors_wh) return MYDET_E_BADARG;
+        if (nodes[i].n_off < 0 || nodes[i].n_off + (int64_t)A * s.H * s.W > N) return MYDET_E_BADARG;
+        for (int k = 0; k < 3; ++k) { p.in[k] = s.in[0]; p.ld[k] = s.ld[0]; p.mode[k] = 0; }
+        p.n_in = 1; p.fuse_w = nullptr; p.wd = s.w_dw; p.wpk = s.w_pw_packed; p.scale = s.scale; p.shift = s.shift;
+        p.y = nullptr; p.ldy = 0; p.H = s.H; p.W = s.W; p.Cout = s.Cout; p.act = MYDET_ACT_NONE;
+        p.nb = (s.Cout + 15) / 16;
+        p.tiles_x = (s.W + TS - 1) / TS;
+        p.tiles_per_img = p.tiles_x * ((s.H + TS - 1) / TS);
+        d.kind = nodes[i].kind; d.stride = nodes[i].stride; d.n_off = nodes[i].n_off;
+        for (int k = 0; k < DEC_MAX_A; ++k) {
+            d.aw[k] = nodes[i].kind == 1 && k < A ? nodes[i].anchors_wh[2 * k] : 0.0f;
+            d.ah[k] = nodes[i].kind == 1 && k < A ? nodes[i].anchors_wh[2 * k + 1] : 0.0f;
+        }
+        tiles += (int64_t)p.tiles_per_img * B;
+        if (tiles > 0x7fffffff) return MYDET_E_UNSUPP;
+    }
+    // small launches cut the class nodes along the anchors
+    const int64_t base_tiles = tiles;
+    tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        SpNode &p = a.p[i];
+        int split = 1;
+        if (a.d[i].kind == 0 && base_tiles < 2 * mydet_cu_count()) split = (int)((3 * mydet_cu_count() + base_tiles - 1) / base_tiles);
+        if (split > A) split = A;
+        p.nb_per = a.d[i].kind == 0 ? nba * ((A + split - 1) / split) : p.nb;
+        p.nsplit = (p.nb + p.nb_per - 1) / p.nb_per;
+        p.tile_begin = (int)tiles;
+        tiles += (int64_t)p.tiles_per_img * B * p.nsplit;
+    }
+    if (nba == 5)
+        hipLaunchKernelGGL((sepconv_decode_kernel<22, 5>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((sepconv_decode_kernel<22, 6>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
     return mydet_launch_status();
 }

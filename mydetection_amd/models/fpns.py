@@ -3,7 +3,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .modules import ConvBn, ConvBnLeaky, SpconvBn
+from .modules import ConvBn, ConvBnLeaky, SpconvBn, prepare_conv
 
 
 class YOLOv3FPN(nn.Module):
@@ -111,6 +111,26 @@ def _identity(x):
     return x
 
 
+def conv1x1_bn_pair(a, b, x):
+    """Two conv1x1_bn modules that read the SAME feature (BiFPN's p4in_m / p4in_out, p5in_m / p5in_out,
+    reference: models/fpns.py:366-372) as one launch: their prepared weights and BatchNorm terms are concatenated along
+    the output channels (cached; rebuilt when either module's parameters change) and the two results are channel
+    ranges of one pixel-major tensor, which the pyramid-node kernel reads in place through its leading dimension."""
+    if a is _identity:
+        return x, x
+    pa, pb = prepare_conv(a, 'main', a[0], a[1]), prepare_conv(b, 'main', b[0], b[1])
+    cache = a.__dict__.setdefault('_prep_cache', {})
+    hit = cache.get('pair')
+    if hit is None or hit[0][0] is not pa[0] or hit[0][1] is not pb[0]:
+        with torch.no_grad():
+            hit = ((pa[0], pb[0]), tuple(torch.cat([u, v]).contiguous() for u, v in zip(pa, pb)))
+        cache['pair'] = hit
+    w, scale, shift = hit[1]
+    y = ops.conv2d(x, w, scale, shift, 1, 1, (0, 0, 0, 0), ops.ACT_NONE)
+    na = pa[0].shape[0]
+    return y[:, :na], y[:, na:]
+
+
 class BiFPN3(nn.Module):
     '''
     One bidirectional pyramid layer over P3..P5 for three-level backbones (reference: models/fpns.py:315-354):
@@ -140,10 +160,12 @@ class BiFPN3(nn.Module):
         P3in, P4in, P5in = features
         assert P3in.shape[2] == P4in.shape[2] * 2 == P5in.shape[2] * 4
         up, down = ops.FUSE_UP2X, ops.FUSE_POOL
-        P4m = self.fuse_4m(self.p4in_m(P4in), (self.p5in_4m(P5in), up))
+        p5_4m, p5_out = conv1x1_bn_pair(self.p5in_4m, self.p5in_out, P5in)
+        p4_m, p4_out = conv1x1_bn_pair(self.p4in_m, self.p4in_out, P4in)
+        P4m = self.fuse_4m(p4_m, (p5_4m, up))
         P3out = self.fuse_3out(self.p3in_out(P3in), (P4m, up))
-        P4out = self.fuse_4out(self.p4in_out(P4in), P4m, (P3out, down))
-        P5out = self.fuse_5out(self.p5in_out(P5in), (P4out, down))
+        P4out = self.fuse_4out(p4_out, P4m, (P3out, down))
+        P5out = self.fuse_5out(p5_out, (P4out, down))
         return [P3out, P4out, P5out]
 
 
@@ -180,12 +202,14 @@ class BiFPN5(nn.Module):
         P3in, P4in, P5in, P6in, P7in = features
         assert P3in.shape[2] == P4in.shape[2] * 2 == P5in.shape[2] * 4 == P6in.shape[2] * 8 == P7in.shape[2] * 16
         up, down = ops.FUSE_UP2X, ops.FUSE_POOL
+        p5_m, p5_out = conv1x1_bn_pair(self.p5in_m, self.p5in_out, P5in)
+        p4_m, p4_out = conv1x1_bn_pair(self.p4in_m, self.p4in_out, P4in)
         P6m = self.fuse_6m(P6in, (P7in, up))
-        P5m = self.fuse_5m(self.p5in_m(P5in), (P6m, up))
-        P4m = self.fuse_4m(self.p4in_m(P4in), (P5m, up))
+        P5m = self.fuse_5m(p5_m, (P6m, up))
+        P4m = self.fuse_4m(p4_m, (P5m, up))
         P3out = self.fuse_3out(self.p3in_out(P3in), (P4m, up))
-        P4out = self.fuse_4out(self.p4in_out(P4in), P4m, (P3out, down))
-        P5out = self.fuse_5out(self.p5in_out(P5in), P5m, (P4out, down))
+        P4out = self.fuse_4out(p4_out, P4m, (P3out, down))
+        P5out = self.fuse_5out(p5_out, P5m, (P4out, down))
         P6out = self.fuse_6out(P6in, P6m, (P5out, down))
         P7out = self.fuse_7out(P7in, (P6out, down))
         return [P3out, P4out, P5out, P6out, P7out]

@@ -79,6 +79,15 @@ class OneStageBBox(torch.nn.Module):
         self.img_size = x.shape[2:4]
         features = self.backbone(x)
         features = self.fpn(features)
+        if getattr(self.rpn, 'can_decode_retina', None) is not None and self.rpn.can_decode_retina(self.det_layers):
+            # EfDetHead + RetinaLayer: decode in the epilogue of the towers' last layers (no class logits in memory)
+            nB = x.shape[0]
+            n_total = sum(d.num_anchors * f.shape[2] * f.shape[3] for d, f in zip(self.det_layers, features))
+            bbs = torch.empty((nB, n_total, 4), dtype=torch.float32, device=x.device)
+            cls_idx = torch.empty((nB, n_total), dtype=torch.int64, device=x.device)
+            scores = torch.empty((nB, n_total), dtype=torch.float32, device=x.device)
+            self.rpn.decode_retina(features, self.det_layers, self.img_size, bbs, cls_idx, scores)
+            return bbs, cls_idx, scores
         all_branch_preds = self.rpn(features)
 
         counts = []

@@ -146,6 +146,19 @@ class SeparableConv2d(nn.Module):
         return dict(inputs=list(inputs), modes=modes, fuse_weights=fuse_weights, w_dw=wd, w_pw=hit[1], scale=scale,
                     shift=shift, cout=self.pointwise.out_channels, act=act, out=out)
 
+    def node_per_anchor(self, inputs, A, n_cls):
+        """Descriptor of this layer as the class tower's last layer for `ops.sepconv_decode_retina`: the pointwise
+        weights / bias with every anchor's n_cls rows padded to whole 16-channel blocks (cached)."""
+        nd = self.node(inputs)
+        wp, _, shift = prepare_conv(self, ('pw', id(None)), self.pointwise, None)
+        cache = self.__dict__.setdefault('_prep_cache', {})
+        hit = cache.get(('pwk_anchor', A, n_cls))
+        if hit is None or hit[0] is not wp:
+            hit = (wp, ops.pack_pointwise_per_anchor(wp, shift, A, n_cls))
+            cache[('pwk_anchor', A, n_cls)] = hit
+        nd['w_pw'], nd['shift'] = hit[1]
+        return nd
+
     def forward(self, x, bn=None, act=ops.ACT_NONE):
         if self.training:
             raise NotImplementedError('mydetection_amd implements the inference path only; call model.eval()')

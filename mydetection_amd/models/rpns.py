@@ -142,6 +142,50 @@ class EfDetHead(nn.Module):
         self.bb_param = bb_param
         self.enable_conf = enable_conf
 
+    def _tower_layers(self, features):
+        """The repeat x (sepconv -> BN -> swish) layers of both towers of every level: layers of equal depth share one
+        launch.  Returns (class features, box features) per level."""
+        n = len(features)
+        cls_t, box_t = list(features), list(features)
+        depth = len(self.class_nets[0]) - 1
+        for r in range(depth):
+            outs = ops.sepconv_nodes([self.class_nets[i][r].node([cls_t[i]]) for i in range(n)]
+                                     + [self.bbox_nets[i][r].node([box_t[i]]) for i in range(n)])
+            cls_t, box_t = outs[:n], outs[n:]
+        return cls_t, box_t
+
+    def can_decode_retina(self, det_layers):
+        """True when `decode_retina` covers this head with these decode layers."""
+        from .detlayers.retinanet import RetinaLayer
+        mods = [m for net in list(self.class_nets) + list(self.bbox_nets) for m in net]
+        return (ops.FUSED_DECODE and not self.enable_conf and self.bb_param == 4 and 2 * len(self.class_nets) <= ops._lib.SEPCONV_MAX_NODES
+                and len(det_layers) == len(self.class_nets) and all(m.fusable() for m in mods)
+                and all(isinstance(net[-1], SeparableConv2d) for net in list(self.class_nets) + list(self.bbox_nets))
+                and all(type(d) is RetinaLayer and d.num_anchors == self.n_anch and d.n_cls == self.n_cls for d in det_layers)
+                and 65 <= self.n_cls <= 96 and self.n_anch <= 12)
+
+    def decode_retina(self, features, det_layers, img_size, bbox, class_idx, score):
+        """forward() + RetinaLayer.forward of every level + the level concatenation, with the decode in the epilogue of
+        the towers' last layers (ops.sepconv_decode_retina): the class logits are never written.  Candidates of level i
+        go to [n_off_i, n_off_i + A*H_i*W_i) of bbox / class_idx / score."""
+        cls_t, box_t = self._tower_layers(features)
+        depth = len(self.class_nets[0]) - 1
+        nodes, n_off = [], 0
+        offs = []
+        for i, f in enumerate(features):
+            offs.append(n_off)
+            n_off += self.n_anch * f.shape[2] * f.shape[3]
+        assert n_off == bbox.shape[1]
+        for i in range(len(features)):
+            nd = self.class_nets[i][depth].node_per_anchor([cls_t[i]], self.n_anch, self.n_cls)
+            nd.update(kind=0, stride=det_layers[i].stride, anchors_wh=None, n_off=offs[i])
+            nodes.append(nd)
+        for i in range(len(features)):
+            nd = self.bbox_nets[i][depth].node([box_t[i]])
+            nd.update(kind=1, stride=det_layers[i].stride, anchors_wh=det_layers[i].anchor_wh.numpy(), n_off=offs[i])
+            nodes.append(nd)
+        ops.sepconv_decode_retina(nodes, self.n_anch, self.n_cls, img_size, bbox, class_idx, score)
+
     def _towers(self, features):
         """Class and box predictions of every level.  When the fused node kernel covers the tower layers, the layers of
         equal depth of all levels and both towers share ONE launch (10 nodes), so the 5x5 ... 80x80 maps of a depth

@@ -517,6 +517,73 @@ def sepconv_nodes(nodes):
     return outs
 
 
+# MYDET_FUSED_DECODE=0: the EfDetHead + RetinaLayer path writes its class logits and decodes them in a second launch
+FUSED_DECODE = os.environ.get('MYDET_FUSED_DECODE', '1') != '0'
+
+
+def pack_pointwise_per_anchor(w, shift, A, n_cls):
+    """Class-tower weights [A * n_cls, C] / shifts [A * n_cls] with every anchor's rows padded to whole 16-channel blocks
+    (zero rows / zero shifts), in `pack_pointwise` order: what `sepconv_decode_retina` reads (include/mydet.h)."""
+    w = w.reshape(w.shape[0], -1).float()
+    C = w.shape[1]
+    cpad = (n_cls + 15) // 16 * 16
+    wp = w.new_zeros((A, cpad, C))
+    wp[:, :n_cls] = w.view(A, n_cls, C)
+    sp = shift.new_zeros((A, cpad))
+    sp[:, :n_cls] = shift.float().view(A, n_cls)
+    return pack_pointwise(wp.view(A * cpad, C)), sp.view(-1).contiguous()
+
+
+def sepconv_decode_retina(nodes, A, n_cls, img_hw, bbox, class_idx, score):
+    """The last sepconv of every EfDetHead tower with RetinaLayer's decode in its epilogue, one launch.
+    nodes: dicts with keys inputs ([tensor [B,C,h,w]]), w_dw, w_pw, shift, scale (or None), kind (0 class tower: w_pw /
+    shift from `pack_pointwise_per_anchor`; 1 box tower: plain `pack_pointwise`), stride, anchors_wh ([A,2], box
+    towers), n_off.  Writes bbox [B,N,4], class_idx [B,N] i64, score [B,N] at the nodes' candidate ranges."""
+    assert 1 <= len(nodes) <= _lib.SEPCONV_MAX_NODES
+    require_gpu(bbox, 'sepconv_decode_retina')
+    arr = (_lib.SepconvDecodeNode * len(nodes))()
+    keep = []
+    B = C = None
+    work = fused = 0.0
+    cpad = (n_cls + 15) // 16 * 16
+    for i, nd in enumerate(nodes):
+        x, ld = to_nhwc(nd['inputs'][0])
+        b, c, H, W = x.shape
+        B, C = (b, c) if B is None else (B, C)
+        assert (b, c) == (B, C), 'all nodes of a launch share batch and channels'
+        node = arr[i].node
+        for k in range(3):
+            node.inp[k] = x.data_ptr() if k == 0 else None
+            node.ld[k] = ld if k == 0 else 0
+            node.mode[k] = 0
+        node.n_in = 1
+        node.fuse_weights = None
+        node.w_dw, node.w_pw_packed = nd['w_dw'].data_ptr(), nd['w_pw'].data_ptr()
+        node.scale = nd['scale'].data_ptr() if nd.get('scale') is not None else None
+        node.shift = nd['shift'].data_ptr()
+        node.y, node.ldy, node.H, node.W, node.act = None, 0, H, W, ACT_NONE
+        node.Cout = A * cpad if nd['kind'] == 0 else A * 4
+        arr[i].kind, arr[i].stride, arr[i].n_off = int(nd['kind']), float(nd['stride']), int(nd['n_off'])
+        anch = None
+        if nd['kind'] == 1:
+            anch = np.ascontiguousarray(np.asarray(nd['anchors_wh'], dtype=np.float32).reshape(-1))
+            assert anch.size == 2 * A
+        arr[i].anchors_wh = anch.ctypes.data if anch is not None else None
+        keep.append((x, anch))
+        # reference-layer bytes: depthwise (2 maps), pointwise (C in, Cout out), decode (Cout in, 28 B per candidate out)
+        px = 4.0 * B * H * W
+        cout = A * n_cls if nd['kind'] == 0 else A * 4
+        work += px * (2 * C + C + cout + cout) + (12.0 if nd['kind'] == 0 else 16.0) * B * A * H * W
+        fused += px * C + (12.0 if nd['kind'] == 0 else 16.0) * B * A * H * W
+    t0 = TIMER.start() if TIMER else None
+    code = _lib.lib().mydet_sepconv_decode_retina_f32(len(nodes), ctypes.cast(arr, ctypes.c_void_p), B, C, A, n_cls,
+                                                      int(img_hw[0]), int(img_hw[1]), _ptr(bbox), _ptr(class_idx),
+                                                      _ptr(score), bbox.shape[1], _stream())
+    if t0:
+        TIMER.stop('sepconv_decode', t0, work, work, fused=fused)
+    _lib.check(code, 'mydet_sepconv_decode_retina_f32')
+
+
 def upsample_concat(a, size, b=None):
     """cat((nearest_resize(a, size), b), dim=1) in one pass."""
     require_gpu(a, 'upsample_concat')

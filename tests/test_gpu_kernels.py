@@ -463,7 +463,11 @@ def test_se_gate_and_gated_conv(dev):
 @pytest.mark.parametrize('Cin,Cout,H,W,gated,res,act', [
     (16, 16, 192, 192, True, True, 0), (32, 16, 181, 183, True, False, 0), (96, 24, 192, 176, True, False, 0),
     (144, 24, 181, 183, True, True, 0), (144, 40, 192, 176, True, False, 0), (240, 40, 181, 183, True, True, 0),
-    (32, 44, 192, 176, False, True, 2), (16, 8, 200, 168, False, False, 1), (144, 48, 181, 183, False, False, 0)])
+    (32, 44, 192, 176, False, True, 2), (16, 8, 200, 168, False, False, 1), (144, 48, 181, 183, False, False, 0),
+    # K not a multiple of 16 (masked last chunk) and output channels cut into slabs
+    (40, 240, 81, 83, False, False, 2), (112, 672, 41, 39, False, False, 2), (80, 480, 40, 40, False, True, 2),
+    (192, 1152, 20, 20, False, False, 2), (88, 88, 37, 41, False, False, 0), (24, 144, 90, 77, False, False, 1),
+    (40, 40, 181, 183, True, True, 0), (4, 12, 64, 64, False, False, 0), (236, 100, 33, 31, False, True, 0)])
 def test_pointwise_skinny(dev, monkeypatch, Cin, Cout, H, W, gated, res, act):
     """The LDS-free skinny 1x1 kernel (csrc/pointwise.hip; mydet_conv2d_igemm_f32 routes Cout <= 48, Cin in
     {16, 32, 96, 144, 240}, >= 65 536 pixels to it): against a float64 conv, with the SE gate on x, BatchNorm terms,
@@ -489,6 +493,7 @@ def test_pointwise_skinny(dev, monkeypatch, Cin, Cout, H, W, gated, res, act):
     args = (xd, w.permute(0, 2, 3, 1).contiguous().to(dev), scale.to(dev), shift.to(dev), 1, 1, (0, 0, 0, 0), act)
     kw = dict(residual=r.to(dev).contiguous(memory_format=torch.channels_last) if res else None,
               gate=gate.to(dev) if gated else None)
+    monkeypatch.setenv('MYDET_PW_WIDE', '1')              # every shape of this test through pointwise.hip
     y = ops.conv2d(*args, **kw)
     tol = 2e-5 * max(1.0, ref.abs().max().item())
     assert (y.cpu().double() - ref).abs().max() < tol

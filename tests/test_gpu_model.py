@@ -686,6 +686,52 @@ def test_hipgraph_replay_equals_eager(model):
             assert torch.equal(rec[k], ref[k]), k
 
 
+@pytest.mark.parametrize('variant', ['plain', 'saturated_and_tied'])
+def test_fused_retina_decode_equals_two_launch_path(monkeypatch, variant):
+    """EfDetHead + RetinaLayer: the decode in the epilogue of the towers' last layers (ops.sepconv_decode_retina: no class
+    logits in memory) gives the candidates of the two-launch path (last sepconv writes logits, decode kernel reads
+    them) bit for bit -- boxes, scores, class indices -- also with logits in the saturated range of the float32
+    sigmoid (>= 5: sigmoid values decide; >= 17.4: all equal 1.0, the first class wins) and with exactly tied classes."""
+    from mydetection_amd import ops, synth
+    from mydetection_amd.models.general import name_to_model
+    m, cfg = name_to_model('efficientdet-d1')
+    sd = synth.make_state_dict(m.state_dict(), 'efficientdet-d1')
+    if variant == 'saturated_and_tied':
+        for lvl in range(5):
+            wk, bk = f'rpn.class_nets.{lvl}.3.pointwise.weight', f'rpn.class_nets.{lvl}.3.pointwise.bias'
+            w, b = sd[wk].clone(), sd[bk].clone()
+            A, C = 9, cfg['general.num_class']
+            w, b = w.view(A, C, -1), b.view(A, C)
+            w[0, 7], b[0, 7] = w[0, 3], b[0, 3]            # anchor 0: classes 3 and 7 are the same function
+            b[0, 3] += 3.0
+            b[0, 7] += 3.0                                  # ... and usually the maximum
+            b[1, 70:80] += 9.0                              # anchor 1: several classes above 5
+            b[2, 5] += 30.0
+            b[2, 60] += 31.0                                # anchor 2: two classes at sigmoid == 1.0: class 5 wins
+            w[3, 70], b[3, 70] = w[3, 20], b[3, 20]         # anchor 3: a tie between lanes (classes 20 and 70)
+            b[3, 20] += 12.0
+            b[3, 70] += 12.0
+            sd[wk], sd[bk] = w.view(A * C, -1, 1, 1), b.view(-1)
+    m.load_state_dict(sd, strict=True)
+    m = m.eval().cuda()
+    x = synth.make_normalized_images(3, 384, seed=77).cuda()
+    assert m.rpn.can_decode_retina(m.det_layers)
+    with torch.no_grad():
+        bb, ci, sc = m.forward_candidates(x)
+        monkeypatch.setattr(ops, 'FUSED_DECODE', False)
+        assert not m.rpn.can_decode_retina(m.det_layers)
+        bb2, ci2, sc2 = m.forward_candidates(x)
+    assert bb.shape == bb2.shape == (3, 9 * (48 * 48 + 24 * 24 + 12 * 12 + 6 * 6 + 3 * 3), 4)
+    assert torch.equal(sc, sc2) and torch.equal(ci, ci2) and torch.equal(bb, bb2)
+    if variant == 'saturated_and_tied':
+        n3 = 48 * 48                                        # level 0, anchors 0..3
+        a0, a1, a2, a3 = (ci[:, k * n3:(k + 1) * n3] for k in range(4))
+        assert (a0 == 3).float().mean() > 0.2 and not (a0 == 7).any()
+        assert ((a1 >= 70) & (a1 < 80)).all()
+        assert (a2 == 5).all() and bool((sc[:, 2 * n3:3 * n3] == 1.0).all())
+        assert (a3 == 20).float().mean() > 0.5 and not (a3 == 70).any()
+
+
 @pytest.mark.parametrize('name', ['yolov3_80', 'efficientdet-d1'])
 def test_hipgraph_batch_lanes(name):
     """Batch lanes (GraphedPath(lanes=2): the two halves of the batch as parallel branches of one hipGraph, each with

@@ -47,7 +47,7 @@ def timeit(run):
 
 
 cfgs = [int(c) for c in a.cfgs.split(',')]
-print(f'{"shape":28s} {"default":>9s} ' + ' '.join(f'cfg{c:>2d}    ' for c in cfgs))
+print(f'{"shape":28s} {"default":>9s} {"pw.hip":>9s} ' + ' '.join(f'cfg{c:>2d}    ' for c in cfgs))
 for cin, cout, hw, act, gate, res in (SHAPES[:a.first] if a.first else SHAPES):
     x = torch.randn(B, hw, hw, cin, device=dev).permute(0, 3, 1, 2)
     w = (torch.randn(cout, 1, 1, cin, device=dev) / cin ** 0.5).contiguous()
@@ -57,6 +57,9 @@ for cin, cout, hw, act, gate, res in (SHAPES[:a.first] if a.first else SHAPES):
     run = lambda: ops.conv2d(x, w, sc, sh, 1, 1, (0, 0, 0, 0), act, residual=r, gate=g)      # noqa: E731
     os.environ.pop('MYDET_CONV_CFG', None)
     t0 = timeit(run)
+    os.environ['MYDET_PW_WIDE'] = '1'
+    tw = timeit(run)
+    os.environ.pop('MYDET_PW_WIDE')
     row = []
     for c in cfgs:
         os.environ['MYDET_CONV_CFG'] = str(c)
@@ -66,4 +69,4 @@ for cin, cout, hw, act, gate, res in (SHAPES[:a.first] if a.first else SHAPES):
             row.append(float('nan'))
     os.environ.pop('MYDET_CONV_CFG', None)
     best = min(row)
-    print(f'{cin:5d}->{cout:<5d}@{hw:<3d} g{gate} r{res} a{act}   {t0:8.1f}  ' + ' '.join(f'{t:8.1f}{"*" if t == best else " "}' for t in row))
+    print(f'{cin:5d}->{cout:<5d}@{hw:<3d} g{gate} r{res} a{act}   {t0:8.1f}  {tw:8.1f}  ' + ' '.join(f'{t:8.1f}{"*" if t == best else " "}' for t in row))
