@@ -66,14 +66,14 @@ __device__ __forceinline__ void tile_load(const DecodeArgs &p, const Level &L, i
         unsigned i = threadIdx.x + 256u * j;
         i = i < ncls4 ? i : ncls4 - 1;
         const unsigned r = (i * p.mc) >> 20, c4 = i - r * p.qc;
-        v[j] = *reinterpret_cast<const f32x4 *>(cls + (int64_t)r * L.ldcls + c4 * 4);
+        v[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(cls + (int64_t)r * L.ldcls + c4 * 4));      // read once
     }
 #pragma unroll
     for (int j = 0; j < NVB; ++j) {
         unsigned i = threadIdx.x + 256u * j;
         i = i < nbox4 ? i : nbox4 - 1;
         const unsigned r = (i * p.mb) >> 20, c4 = i - r * p.qb;
-        vb[j] = *reinterpret_cast<const f32x4 *>(box + (int64_t)r * L.ldbox + c4 * 4);
+        vb[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(box + (int64_t)r * L.ldbox + c4 * 4));
     }
 }
 

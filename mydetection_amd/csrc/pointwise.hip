@@ -59,7 +59,10 @@ __global__ __launch_bounds__(PW_WAVES * 64) void pw_skinny_kernel(const PwArgs p
         m_ = m_ < m_last ? m_ : m_last;                                                       \
         const float *xp_ = xbase + m_ * ldx;                                                  \
         _Pragma("unroll") for (int i_ = 0; i_ < KC - 1; ++i_)(dst_)[i_] = *reinterpret_cast<const f32x4 *>(xp_ + i_ * 16); \
-        (dst_)[KC - 1] = *reinterpret_cast<const f32x4 *>(xtail + m_ * ldx);                  \
+        /* K <= 16: a wave's load covers whole lines that nobody reads again -> streaming load (16->16 @320^2: 61 -> 53 us); */ \
+        /* with more chunks a line is shared by two load instructions and the hint costs a refetch (96->24: 41 -> 52 us)   */ \
+        if (KC == 1) (dst_)[0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(xtail + m_ * ldx)); \
+        else (dst_)[KC - 1] = *reinterpret_cast<const f32x4 *>(xtail + m_ * ldx);             \
         if (!tail_ok) (dst_)[KC - 1] = f32x4{0.f, 0.f, 0.f, 0.f};                             \
     }
 #pragma unroll
