@@ -312,8 +312,9 @@ int mydet_mbconv_expand_dw_f32(const float *x, int64_t ldx, const float *w_expan
  * Replaces mydet_bifpn_fuse_f32 + mydet_dwconv_f32 + mydet_conv2d_igemm_f32 for these nodes (SeparableConv2d,
  * models/modules.py:5-21, with the following BatchNorm folded into scale/shift).
  * in[i]: logical [B,C,h,w] channels-last, pixel stride ld[i].  w_dw [3][3][C].  w_pw_packed: the pointwise weight
- * W[Cout][C] in MFMA fragment order, ceil(Cout/16) x (C/4) x 64 floats:
- *     packed[nb][ks][lane] = W[16*nb + (lane & 15)][4*ks + (lane >> 4)]   (rows >= Cout are zero).
+ * W[Cout][C] in MFMA operand order with four k-steps of a lane side by side, ceil(Cout/16) x ceil(C/16) x 64 x 4 floats:
+ *     packed[nb][kq][lane][e] = W[16*nb + (lane & 15)][4*(4*kq + e) + (lane >> 4)]   (rows >= Cout and k >= C are zero):
+ *     a workgroup copies a block to LDS with 16-byte loads and every wave reads its operands from there.
  * scale may be NULL (no BatchNorm: y = conv + shift).  Cout % 4 == 0.  act: MYDET_ACT_NONE | MYDET_ACT_SWISH.
  * `nodes` is a HOST array of n (<= MYDET_SEPCONV_MAX_NODES) descriptors; all nodes share B and C (C == 88). */
 #define MYDET_SEPCONV_MAX_NODES 10

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libmydet_hip.so')
+# MYDET_LIB_PATH: a differently built copy of the library (kernel experiments: tools/ablate_sepconv.sh); default = the in-tree build
+LIB_PATH = os.environ.get('MYDET_LIB_PATH') or os.path.join(_HERE, 'lib', 'libmydet_hip.so')
 
 c_int, c_i64, c_f32, c_f64, c_ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
 

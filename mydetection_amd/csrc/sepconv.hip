@@ -80,36 +80,6 @@ __device__ __forceinline__ f32x4 sp_read(const SpNode &P, int i, int64_t b, int 
     return m;
 }
 
-template <int KS>
-__device__ __forceinline__ void sp_load_pair(const SpNode &P, int nb, int lane, float (&f0)[KS], float (&f1)[KS]) {
-    const float *wp0 = P.wpk + (int64_t)min(nb, P.nb - 1) * KS * 64 + lane;
-    const float *wp1 = P.wpk + (int64_t)min(nb + 1, P.nb - 1) * KS * 64 + lane;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        f0[ks] = wp0[ks * 64];
-        f1[ks] = wp1[ks * 64];
-    }
-}
-
-__device__ __forceinline__ void sp_finish(const SpNode &P, f32x4 acc, int n, bool valid, float *yp) {
-    if (valid && n < P.Cout) {
-        const f32x4 sh = *reinterpret_cast<const f32x4 *>(P.shift + n);
-        if (P.scale) {
-            const f32x4 sc = *reinterpret_cast<const f32x4 *>(P.scale + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = acc[e] * sc[e] + sh[e];
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = acc[e] + sh[e];
-        }
-        if (P.act == MYDET_ACT_SWISH) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = acc[e] * mydet_sigmoid_fast(acc[e]);
-        }
-        *reinterpret_cast<f32x4 *>(yp + n) = acc;
-    }
-}
-
 struct SpItem {
     int pi, b, oy0, ox0, nb_begin, nb_end;
 };
@@ -259,20 +229,45 @@ __device__ __forceinline__ void sp_stage_item(const SpNode &P, const SpItem &it,
 }
 
 
+// The pointwise weights of one 16-channel block, KQ * 64 float4 in MFMA operand order (include/mydet.h).  The four waves
+// of a workgroup need the SAME fragments, so the block is fetched once per workgroup -- 1.5 coalesced 16-byte loads per
+// thread -- into a two-slot LDS ring behind the operand tile and read from there (one ds_read_b128 per four MFMAs).
+// (Each wave loading its own fragments, 22 dword loads per block and wave, kept the vector-memory pipe busier than the
+// matrix pipe: with those loads removed the 720-channel class node ran in 0.20 instead of 0.36 ms.)
+template <int KS>
+struct SpW {
+    static constexpr int KQ = (KS + 3) / 4;
+    static constexpr int F4 = KQ * 64;               // float4 per block
+    static constexpr int SECOND = F4 - 256;          // threads that carry a second float4
+    f32x4 g0, g1;
+    __device__ __forceinline__ void load(const SpNode &P, int nb, int tid) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(P.wpk) + (int64_t)min(nb, P.nb - 1) * F4;
+        g0 = src[tid];
+        g1 = src[min(tid + 256, F4 - 1)];
+    }
+    __device__ __forceinline__ void store(float *slot, int tid) const {
+        reinterpret_cast<f32x4 *>(slot)[tid] = g0;
+        if (tid < SECOND) reinterpret_cast<f32x4 *>(slot)[tid + 256] = g1;
+    }
+    static __device__ __forceinline__ void fragments(const float *slot, int lane, float (&af)[KQ * 4]) {
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const f32x4 v = reinterpret_cast<const f32x4 *>(slot)[q * 64 + lane];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) af[q * 4 + e] = v[e];
+        }
+    }
+};
+
 // Phases 0-2 of a work item, shared by the node kernel and the decoding node kernel: on return the 64 x C operand tile of
-// the pointwise conv lies in `lds` ([64 px][C + 1]) and `af` holds the weight fragments of channel block `nb_first`.
+// the pointwise conv lies in `lds` ([64 px][C + 1]) and `w0` holds (in registers) the weights of channel block `nb_first`.
 template <int KS>
 __device__ __forceinline__ void sp_front(const SpNode &P, float *lds, float *swd, int tid, int b, int oy0, int ox0,
-                                         int nb_first, float (&af)[KS]) {
+                                         int nb_first, SpW<KS> &w0) {
     constexpr int C = KS * 4, Q = KS, XS = C + 1;
     // 0. everything that does not depend on the halo is requested first: the depthwise taps (-> LDS), the first block's
-    //    weight fragments (registers); their L2 round trip overlaps the halo's
-    const int lane = tid & 63;
-    {
-        const float *wp = P.wpk + (int64_t)min(nb_first, P.nb - 1) * KS * 64 + lane;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) af[ks] = wp[ks * 64];
-    }
+    //    weights (registers); their L2 round trip overlaps the halo's
+    w0.load(P, nb_first, tid);
     if (tid < 9 * Q) *reinterpret_cast<f32x4 *>(&swd[tid * 4]) = *reinterpret_cast<const f32x4 *>(P.wd + tid * 4);
     // 1. halo of pre(x): every load unconditional at clamped coordinates, several halo entries per thread in flight
     {
@@ -344,8 +339,12 @@ __global__ __launch_bounds__(256, 4) void sepconv_kernel(const SpArgs a) {
     const int oy0 = ty * TS, ox0 = tx * TS;
     const int H = P.H, W = P.W;
     const int wave = tid >> 6, lane = tid & 63;
-    float af[KS];
-    sp_front<KS>(P, lds, swd, tid, b, oy0, ox0, nb_begin, af);
+    SpW<KS> wreg;
+    sp_front<KS>(P, lds, swd, tid, b, oy0, ox0, nb_begin, wreg);
+    float *ring = lds + TS * TS * XS;                         // two weight slots behind the operand tile
+    constexpr int WSLOT = SpW<KS>::F4 * 4;
+    wreg.store(ring, tid);
+    __syncthreads();
 
     // 3. pointwise conv, transposed: D[channel][pixel] = sum_k W[channel][k] * X[pixel][k]
     const int m0 = wave * 16;
@@ -357,16 +356,15 @@ __global__ __launch_bounds__(256, 4) void sepconv_kernel(const SpArgs a) {
     const bool valid = oy < H && ox < W;
     float *yp = P.y + (((int64_t)b * H + oy) * W + ox) * P.ldy;
     const int nsub = (lane >> 4) * 4;
-    // one 16-channel block at a time; the NEXT block's weight fragments are in flight under the current block's MFMAs,
-    // the block's own BatchNorm terms are requested at its start (used at its end).  Two accumulator chains over the
-    // even / odd k-steps keep the matrix pipe issuing (40-cycle dependent latency).
+    const int act = P.act;
+    // one 16-channel block at a time; the NEXT block's weights are in flight (registers) under the current block's
+    // MFMAs and land in the other ring slot at the end of the iteration.  Two accumulator chains over the even / odd
+    // k-steps keep the matrix pipe issuing (40-cycle dependent latency).
     for (int nb = nb_begin; nb < nb_end; ++nb) {
-        float an[KS];
-        {
-            const float *wp = P.wpk + (int64_t)min(nb + 1, P.nb - 1) * KS * 64 + lane;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) an[ks] = wp[ks * 64];
-        }
+        const int cur = (nb - nb_begin) & 1;
+        wreg.load(P, nb + 1, tid);
+        float af[SpW<KS>::KQ * 4];
+        SpW<KS>::fragments(ring + cur * WSLOT, lane, af);
         const int n = nb * 16 + nsub;
         const int nc = min(n, P.Cout - 4);
         const f32x4 sh = *reinterpret_cast<const f32x4 *>(P.shift + nc);
@@ -388,17 +386,16 @@ __global__ __launch_bounds__(256, 4) void sepconv_kernel(const SpArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc0[e] = acc0[e] + sh[e];
             }
-            if (P.act == MYDET_ACT_SWISH) {
+            if (act == MYDET_ACT_SWISH) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc0[e] = acc0[e] * mydet_sigmoid_fast(acc0[e]);
             }
             *reinterpret_cast<f32x4 *>(yp + n) = acc0;
         }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) af[ks] = an[ks];
+        wreg.store(ring + (cur ^ 1) * WSLOT, tid);
+        __syncthreads();
     }
 }
-
 
 // ------------------------------------------------------------------------------------------- decoding head nodes
 // The LAST layer of an EfDetHead tower with RetinaLayer's decode in its epilogue (models/rpns.py:121-197 ->
@@ -460,8 +457,13 @@ __global__ __launch_bounds__(256, 4) void sepconv_decode_kernel(const SpDecArgs 
     const int oy0 = ty * TS, ox0 = tx * TS;
     const int H = P.H, W = P.W;
     const int wave = tid >> 6, lane = tid & 63;
-    float af[KS];
-    sp_front<KS>(P, lds, swd, tid, b, oy0, ox0, nb_begin, af);
+    SpW<KS> wreg;
+    sp_front<KS>(P, lds, swd, tid, b, oy0, ox0, nb_begin, wreg);
+    float *ring = lds + TS * TS * XS;
+    constexpr int WSLOT = SpW<KS>::F4 * 4;
+    wreg.store(ring, tid);
+    __syncthreads();
+    int cur = 0;
 
     const int m0 = wave * 16;
     float bf[KS];
@@ -474,12 +476,13 @@ __global__ __launch_bounds__(256, 4) void sepconv_decode_kernel(const SpDecArgs 
     const int64_t cand0 = (int64_t)b * a.N + n_off + (int64_t)oy * W + ox;               // + a * H * W
     const int64_t hw = (int64_t)H * W;
 
-    // one 16-channel block: acc = W[nb] . X^T + shift (the NEXT block's fragments are requested first, as in sepconv_kernel)
+    // one 16-channel block: acc = W[nb] . X^T + shift (the NEXT block's weights are requested first and land in the other
+    // ring slot at the end, as in sepconv_kernel)
 #define SP_DEC_BLOCK(nb_, v_)                                                                         \
     {                                                                                                 \
-        float an_[KS];                                                                                \
-        const float *wp_ = P.wpk + (int64_t)min((nb_) + 1, P.nb - 1) * KS * 64 + lane;                \
-        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) an_[ks] = wp_[ks * 64];                     \
+        wreg.load(P, (nb_) + 1, tid);                                                                 \
+        float af[SpW<KS>::KQ * 4];                                                                    \
+        SpW<KS>::fragments(ring + cur * WSLOT, lane, af);                                             \
         const f32x4 sh_ = *reinterpret_cast<const f32x4 *>(P.shift + (nb_) * 16 + nsub);              \
         f32x4 sc_ = {1.f, 1.f, 1.f, 1.f};                                                             \
         if (P.scale) sc_ = *reinterpret_cast<const f32x4 *>(P.scale + (nb_) * 16 + nsub);             \
@@ -495,7 +498,9 @@ __global__ __launch_bounds__(256, 4) void sepconv_decode_kernel(const SpDecArgs 
             _Pragma("unroll") for (int e = 0; e < 4; ++e) acc0_[e] = acc0_[e] + sh_[e];               \
         }                                                                                             \
         (v_) = acc0_;                                                                                 \
-        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) af[ks] = an_[ks];                           \
+        wreg.store(ring + (cur ^ 1) * WSLOT, tid);                                                    \
+        __syncthreads();                                                                              \
+        cur ^= 1;                                                                                     \
     }
 
     if (kind == 0) {

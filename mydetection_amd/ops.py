@@ -446,15 +446,19 @@ def bifpn_fuse(inputs, modes, weights):
 
 
 def pack_pointwise(w):
-    """Pointwise weight [Cout, C] (or OHWI [Cout,1,1,C]) in the MFMA fragment order `sepconv_nodes` reads:
-    packed[nb][ks][lane] = W[16*nb + (lane & 15)][4*ks + (lane >> 4)], rows >= Cout zero (include/mydet.h)."""
+    """Pointwise weight [Cout, C] (or OHWI [Cout,1,1,C]) in the MFMA operand order `sepconv_nodes` reads, four k-steps of
+    a lane side by side (one 16-byte load / LDS read per four MFMAs; include/mydet.h):
+        packed[nb][kq][lane][e] = W[16*nb + (lane & 15)][4*(4*kq + e) + (lane >> 4)],   kq < ceil(C/16),
+    zero for rows >= Cout and k >= C."""
     w = w.reshape(w.shape[0], -1).float()
     Cout, C = w.shape
     assert C % 4 == 0
-    nb = (Cout + 15) // 16
-    wp = w.new_zeros((nb * 16, C))
-    wp[:Cout] = w
-    return wp.view(nb, 16, C // 4, 4).permute(0, 2, 3, 1).contiguous()
+    nb, ks = (Cout + 15) // 16, C // 4
+    kq = (ks + 3) // 4
+    wp = w.new_zeros((nb * 16, kq * 4, 4))                 # [row][k-step][k within the step]
+    wp[:Cout, :ks] = w.view(Cout, ks, 4)
+    # [nb][16 rows][kq][e][4 kk] -> [nb][kq][kk][16 rows][e]: lane = kk * 16 + row
+    return wp.view(nb, 16, kq, 4, 4).permute(0, 2, 4, 1, 3).contiguous().view(nb, kq, 64, 4)
 
 
 SEPCONV_CHANNELS = (88,)        # instantiated channel counts of the fused node kernel
