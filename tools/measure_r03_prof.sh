@@ -8,7 +8,8 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03; mkdir -p $O
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/stats_$TAG $O/fetch_$TAG $O/write_$TAG
-timeout -k 5 $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$TAG -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --eager "$@" > $O/stats_$TAG.log 2>&1
+# kernel stats of the DEFAULT command (hipGraph replay); the PMC passes run --eager (one dispatch record per launch)
+timeout -k 5 $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$TAG -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > $O/stats_$TAG.log 2>&1
 cp $(find $O/stats_$TAG -name '*kernel_stats.csv' | head -1) $O/r03_kernel_stats_$TAG.csv
 tail -1 $O/stats_$TAG.log | cut -c1-200
 timeout -k 5 $T rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch_$TAG -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager "$@" > $O/fetch_$TAG.log 2>&1
