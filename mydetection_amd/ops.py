@@ -384,20 +384,12 @@ def channel_sums(x):
     return partial
 
 
-_ABL_GATES = {}
-
-
 def se_gate(partial, n_pixels, w1, b1, w2t, b2):
     """gate [B,C] = sigmoid(W2 . swish(W1 . mean + b1) + b2) from per-slice sums [B,S+1,C]; w2t = W2 transposed [Cse,C]."""
     require_gpu(partial, 'se_gate')
     B, S, C = partial.shape
     S -= 1
     Cse = w1.shape[0]
-    if os.environ.get('MYDET_ABL_SE'):        # TEMPORARY measurement knob: no SE launch, a constant gate
-        key = (B, C)
-        if key not in _ABL_GATES:
-            _ABL_GATES[key] = torch.full((B, C), 0.5, dtype=torch.float32, device=partial.device)
-        return _ABL_GATES[key]
     gate = torch.empty((B, C), dtype=torch.float32, device=partial.device)
     t0 = TIMER.start() if TIMER else None
     code = _lib.lib().mydet_se_gate_f32(_ptr(partial), S, B, n_pixels, C, _ptr(w1), _ptr(b1), Cse, _ptr(w2t), _ptr(b2),

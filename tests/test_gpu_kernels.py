@@ -460,6 +460,30 @@ def test_se_gate_and_gated_conv(dev):
         assert (y.cpu().double() - ref).abs().max() < 3e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize('C,Cse,S', [(96, 4, 800), (32, 8, 800), (144, 6, 200), (1920, 80, 6), (1152, 48, 15), (672, 28, 15),
+                                      (240, 10, 50), (16, 4, 128), (480, 20, 1), (4100, 80, 3)])
+def test_se_tail_from_slice_sums(dev, C, Cse, S):
+    """The one-launch squeeze-excite tail (mean over S slice sums -> reduce conv + swish -> expand conv + sigmoid) on the
+    slice counts / channel widths the EfficientNet blocks produce (S up to 800 tiles, C up to 1920; C = 4100 takes the
+    two-launch fallback), against float64; twice: bit-identical (fixed summation order); the mean lands in slice S."""
+    from mydetection_amd import ops
+    g = torch.Generator().manual_seed(C + S)
+    B, HW = 3, 16 * S
+    partial = torch.randn(B, S + 1, C, generator=g) * 4
+    w1, b1 = torch.randn(Cse, C, generator=g) / C ** 0.5, torch.randn(Cse, generator=g) * 0.1
+    w2, b2 = torch.randn(C, Cse, generator=g) * 0.3, torch.randn(C, generator=g) * 0.1
+    m = partial[:, :S].double().sum(dim=1) / HW
+    h = m @ w1.double().t() + b1.double()
+    h = h * torch.sigmoid(h)
+    ref = torch.sigmoid(h @ w2.double().t() + b2.double())
+    args = (HW, w1.to(dev), b1.to(dev), w2.t().contiguous().to(dev), b2.to(dev))
+    pd = partial.to(dev)
+    gate = ops.se_gate(pd, *args)
+    assert (gate.cpu().double() - ref).abs().max() < 2e-6
+    assert (pd[:, S].cpu().double() - m).abs().max() < 1e-5 * max(1.0, m.abs().max().item())
+    assert torch.equal(ops.se_gate(partial.to(dev), *args), gate)
+
+
 @pytest.mark.parametrize('Cin,Cout,H,W,gated,res,act', [
     (16, 16, 192, 192, True, True, 0), (32, 16, 181, 183, True, False, 0), (96, 24, 192, 176, True, False, 0),
     (144, 24, 181, 183, True, True, 0), (144, 40, 192, 176, True, False, 0), (240, 40, 181, 183, True, True, 0),
