@@ -375,3 +375,57 @@ def test_pyramid_node_address_audit():
     node = _lib.SepconvNode()
     node.n_in, node.H, node.W, node.Cout, node.ldy = 2, 8, 8, 88, 88
     assert _lib.lib().mydet_sepconv_nodes_f32(1, ctypes.cast(ctypes.pointer(node), ctypes.c_void_p), 1, 88, None) == -1
+
+
+def test_pointwise_operand_packing():
+    """ops.pack_pointwise / pack_pointwise_per_anchor (pure tensor code): the documented operand order of include/mydet.h --
+    packed[nb][kq][lane][e] = W[16 nb + (lane & 15)][4 (4 kq + e) + (lane >> 4)], zeros beyond Cout and C; per anchor
+    every anchor's n_cls rows start a fresh run of whole 16-channel blocks (what mydet_sepconv_decode_retina_f32 walks)."""
+    from mydetection_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for cout, C in ((88, 88), (36, 88), (720, 88), (20, 24)):
+        w = torch.randn(cout, C, generator=g)
+        p = ops.pack_pointwise(w)
+        nb, kq = (cout + 15) // 16, (C // 4 + 3) // 4
+        assert p.shape == (nb, kq, 64, 4) and p.is_contiguous()
+        for b_, q_, lane, e in ((0, 0, 0, 0), (nb - 1, kq - 1, 63, 3), (nb // 2, kq // 2, 37, 2), (0, kq - 1, 16, 1)):
+            row, k = 16 * b_ + (lane & 15), 4 * (4 * q_ + e) + (lane >> 4)
+            want = float(w[row, k]) if row < cout and k < C else 0.0
+            assert float(p[b_, q_, lane, e]) == want, (cout, C, b_, q_, lane, e)
+        assert abs(float(p.double().abs().sum()) - float(w.double().abs().sum())) < 1e-9      # nothing lost, nothing duplicated
+    A, n_cls, C = 9, 80, 88
+    w, sh = torch.randn(A * n_cls, C, generator=g), torch.randn(A * n_cls, generator=g)
+    p, s = ops.pack_pointwise_per_anchor(w, sh, A, n_cls)
+    assert p.shape == (A * 5, 6, 64, 4) and s.shape == (A * 80,)
+    A, n_cls = 3, 90                                                    # 90 classes: 96-row runs, 6 zero rows per anchor
+    w, sh = torch.randn(A * n_cls, C, generator=g), torch.randn(A * n_cls, generator=g)
+    p, s = ops.pack_pointwise_per_anchor(w, sh, A, n_cls)
+    assert p.shape == (A * 6, 6, 64, 4) and s.shape == (A * 96,)
+    for a in range(A):
+        assert torch.equal(s[a * 96:a * 96 + 90], sh[a * 90:(a + 1) * 90]) and float(s[a * 96 + 90:(a + 1) * 96].abs().sum()) == 0
+        blk = p[a * 6 + 5]                                              # the anchor's last block: rows 80..95, 10 real ones
+        for lane in (0, 9, 10, 15, 31, 63):
+            row = 80 + (lane & 15)
+            want = float(w[a * 90 + row, 4 * (4 * 1 + 2) + (lane >> 4)]) if row < 90 else 0.0
+            assert float(blk[1, lane, 2]) == want
+
+
+def test_decode_node_abi_and_argument_checks():
+    """mydet_sepconv_decode_node mirrors the C struct (size / offsets), and the entry point refuses what the kernel does not
+    cover before any launch: class counts outside 65..96, channel counts other than 88, inconsistent Cout, null pointers."""
+    from mydetection_amd import _lib
+    assert ctypes.sizeof(_lib.SepconvNode) == 136 and ctypes.sizeof(_lib.SepconvDecodeNode) == 160
+    assert _lib.SepconvDecodeNode.kind.offset == 136 and _lib.SepconvDecodeNode.anchors_wh.offset == 144
+    lib = _lib.lib()
+    arr = (_lib.SepconvDecodeNode * 1)()
+    ptr = ctypes.cast(arr, ctypes.c_void_p)
+    fake = ctypes.c_void_p(16)
+    f = lib.mydet_sepconv_decode_retina_f32
+    assert f(1, ptr, 1, 88, 9, 80, 64, 64, None, None, None, 100, None) == -1          # null outputs
+    assert f(1, ptr, 1, 64, 9, 80, 64, 64, fake, fake, fake, 100, None) == -2           # C != 88
+    assert f(1, ptr, 1, 88, 9, 20, 64, 64, fake, fake, fake, 100, None) == -2           # n_cls outside 65..96
+    assert f(1, ptr, 1, 88, 13, 80, 64, 64, fake, fake, fake, 100, None) == -2          # more anchors than the table holds
+    arr[0].node.n_in, arr[0].node.H, arr[0].node.W, arr[0].node.Cout, arr[0].kind = 1, 8, 8, 123, 0
+    assert f(1, ptr, 1, 88, 9, 80, 64, 64, fake, fake, fake, 9 * 64, None) == -1        # Cout != A * 16 * ceil(n_cls / 16)
+    arr[0].node.Cout = 9 * 80
+    assert f(1, ptr, 1, 88, 9, 80, 64, 64, fake, fake, fake, 9 * 64, None) == -1        # null input / weights
