@@ -505,11 +505,13 @@ extern "C" int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *
     if ((Cin % 32) != 0 && K <= 256) return launch_cfg(6, a, s);
     if (Cout <= 32) return launch_cfg(2, a, s);
     // 80 / 88 output channels behind a long K (480->80 project convs): a 96-wide tile instead of two 64-wide ones
-    // (tools/sweep_pointwise.py, batch 32: 67 -> 57 us)
-    if (KH * KW == 1 && Cout > 64 && Cout <= 96 && K >= 384) return launch_cfg(9, a, s);
+    // (tools/sweep_pointwise.py, batch 32: 67 -> 57 us; a tie at batch 16 and a loss at batch 8 -- 12 800 rows:
+    // 36 vs 24 us -- where the 64 x 64 tiles with the split-K tail fill the chip better)
+    if (KH * KW == 1 && Cout > 64 && Cout <= 96 && K >= 384 && M64 >= 40000) return launch_cfg(9, a, s);
     // short-K, very wide outputs (EfficientNet expand convs at 20^2: 192->1152, 320->1920): the 8-wave 128x128 tile
-    // (tools/sweep_pointwise.py: 79 -> 73 us, 35.7 -> 32.9 us at batch 16)
-    if (KH * KW == 1 && K <= 512 && Cout >= 1024) return launch_cfg(8, a, s);
+    // (tools/sweep_pointwise.py: 79 -> 73 us, 35.7 -> 32.9 us at batch 16; under 4 800 rows -- batch 8 at 20^2 -- the
+    // 64 x 64 tiles are ahead again: 320->1920 47 -> 44 us)
+    if (KH * KW == 1 && K <= 512 && Cout >= 1024 && (M64 >= 4800 || K <= 256)) return launch_cfg(8, a, s);
     if (Cout <= 64) return launch_cfg(KH * KW > 1 ? 6 : 1, a, s);
     // (3x3 layers with K >= 512 and a big grid already prefer the 8-wave tile: 64->128 stride 2 @320^2 +7 %)
     if ((K <= 1024 && !(KH * KW > 1 && K >= 512)) || blocks128 < 1024) return launch_cfg(3, a, s);
