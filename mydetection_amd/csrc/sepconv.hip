@@ -12,7 +12,7 @@
 // 5x5 / 10x10 levels do not pay a launch each.
 //
 // One 256-thread workgroup owns an 8x8 output tile of one image, all channels:
-//   0. requests that do not depend on the halo go out first (depthwise taps -> LDS, first weight fragments -> registers)
+//   0. requests that do not depend on the halo go out first (depthwise taps -> LDS, the first weight block -> registers)
 //   1. the 10x10 halo of pre(x) -> LDS (float4 per thread, inputs read once; out-of-image pixels are the conv's zeros);
 //      every load is unconditional at clamped coordinates and specialised by the node's input modes, so that a batch of
 //      halo entries is in flight at once (a run-time mode switch around each load made hipcc wait for every single one)
@@ -20,8 +20,9 @@
 //      over the halo as the [64 px][C+1] operand tile (odd stride: conflict-free fragment reads)
 //   3. pointwise conv on FP32 MFMA, computed transposed (A = weights, B = pixels: v_mfma_f32_16x16x4_f32), so a lane
 //      ends up with 4 consecutive output channels of one pixel = one 16-byte store after the BN/act epilogue.  A wave
-//      owns 16 pixels; the weights come pre-packed in fragment order (one coalesced 256-B load per k-step).
-// LDS 35 KB -> 4 workgroups per CU: the halo loads of one overlap the MFMAs of another.
+//      owns 16 pixels; the weights come pre-packed in operand order, one 16-channel block at a time through a two-slot
+//      LDS ring shared by the workgroup's four waves (SpW below).
+// LDS 38 KB -> 4 workgroups per CU: the halo loads of one overlap the MFMAs of another.
 // Built with -ffp-contract=off: the fusion arithmetic rounds like the reference's separate mul / add ops.
 #include <cstdlib>
 
@@ -83,26 +84,6 @@ __device__ __forceinline__ f32x4 sp_read(const SpNode &P, int i, int64_t b, int 
 struct SpItem {
     int pi, b, oy0, ox0, nb_begin, nb_end;
 };
-
-// work item = (tile, slice of the output-channel blocks)
-__device__ __forceinline__ SpItem sp_decode(const SpArgs &a, int item) {
-    int pi = 0;
-    for (int i = 1; i < a.n; ++i)
-        if (item >= a.p[i].tile_begin) pi = i;                 // uniform
-    const SpNode &P = a.p[pi];
-    const int t0 = item - P.tile_begin;
-    const int t = t0 / P.nsplit, ns = t0 - t * P.nsplit;
-    SpItem it;
-    it.pi = pi;
-    it.nb_begin = ns * P.nb_per;
-    it.nb_end = min(P.nb, it.nb_begin + P.nb_per);
-    it.b = t / P.tiles_per_img;
-    const int r = t - it.b * P.tiles_per_img;
-    const int ty = r / P.tiles_x;
-    it.oy0 = ty * TS;
-    it.ox0 = (r - ty * P.tiles_x) * TS;
-    return it;
-}
 
 // one fused input at in-image (clamped) coordinates, branch-free: MODE 0 same size, 1 nearest-2x of the half-size map,
 // 2 3x3/2 max pool of the double-size map (-inf padding: taps outside the map do not enter the max)

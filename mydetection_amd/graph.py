@@ -66,7 +66,7 @@ class GraphedPath:
         if lanes == 'auto':
             tries = [1, 2] if B >= 2 and B % 2 == 0 else [1]
         else:
-            tries = [int(lanes) if int(lanes) > 1 and B % int(lanes) == 0 else 1]
+            tries = [int(lanes) if 1 < int(lanes) <= B else 1]         # a forced count may cut unevenly (tensor_split)
         best = None
         for n in tries:
             cap = self._capture(n, warmup)
@@ -113,7 +113,7 @@ class GraphedPath:
             bb, ci, sc = self.model.forward_candidates(self.static_in)
             return (bb, ci, sc), batched_post_process(bb, ci, sc, self.conf, self.nms)
         main = torch.cuda.current_stream()
-        parts = self.static_in.chunk(self.lanes)
+        parts = self.static_in.tensor_split(self.lanes)
         outs = []
         for i, (st, part) in enumerate(zip(self._streams, parts)):
             st.wait_stream(main)
