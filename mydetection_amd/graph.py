@@ -114,16 +114,19 @@ class GraphedPath:
             return (bb, ci, sc), batched_post_process(bb, ci, sc, self.conf, self.nms)
         main = torch.cuda.current_stream()
         parts = self.static_in.tensor_split(self.lanes)
-        outs = []
+        # every lane writes its rows of ONE record buffer (allocated on the joining stream); the candidates stay per lane
+        records = torch.empty((self.static_in.shape[0], ops._lib.REC_WORDS), dtype=torch.int32, device=self.static_in.device)
+        cands, lo = [], 0
         for i, (st, part) in enumerate(zip(self._streams, parts)):
             st.wait_stream(main)
             with torch.cuda.stream(st), ops.lane(i):
                 bb, ci, sc = self.model.forward_candidates(part)
-                outs.append(((bb, ci, sc), batched_post_process(bb, ci, sc, self.conf, self.nms)))
+                batched_post_process(bb, ci, sc, self.conf, self.nms, records=records[lo:lo + part.shape[0]])
+                cands.append((bb, ci, sc))
+            lo += part.shape[0]
         for st in self._streams:
             main.wait_stream(st)
-        # only the records (16 400 B per image) are joined inside the graph; the candidates stay per lane
-        return [o[0] for o in outs], ops.record_views(torch.cat([o[1]['records'] for o in outs]))
+        return cands, ops.record_views(records)
 
     def eager(self, x=None):
         """The captured launch sequence issued from the host (same lanes, same streams): what a replay computes, bit for

@@ -706,7 +706,7 @@ def record_views(records):
             'records': records}
 
 
-def postprocess(bbox, class_idx, score, conf_thres, nms_thres, topk=TOPK):
+def postprocess(bbox, class_idx, score, conf_thres, nms_thres, topk=TOPK, records=None):
     """Batched filter/top-k/class-aware NMS.  bbox [B,N,4], class_idx [B,N] i64, score [B,N].
 
     Returns dict of device tensors: count [B] i32, bbox [B,512,4], class_idx [B,512] i64, score [B,512],
@@ -720,7 +720,9 @@ def postprocess(bbox, class_idx, score, conf_thres, nms_thres, topk=TOPK):
     bbox, class_idx, score = bbox.contiguous(), class_idx.contiguous(), score.contiguous()
     B, N = score.shape
     dev = bbox.device
-    records = torch.empty((B, _lib.REC_WORDS), dtype=torch.int32, device=dev)
+    if records is None:
+        records = torch.empty((B, _lib.REC_WORDS), dtype=torch.int32, device=dev)
+    assert records.dtype == torch.int32 and tuple(records.shape) == (B, _lib.REC_WORDS) and records.is_contiguous()
     scratch = torch.empty((B, max(N, 1)), dtype=torch.int64, device=dev)
     t0 = TIMER.start() if TIMER else None
     code = _lib.lib().mydet_postprocess_records_f32(_ptr(bbox), _ptr(class_idx), _ptr(score), B, N, float(conf_thres),

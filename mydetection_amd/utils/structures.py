@@ -234,10 +234,11 @@ def batched_to_json(rec, img_ids, eval_type='x1y1wh', catIdx2id=None) -> list:
     return out
 
 
-def batched_post_process(bboxes, cats, scores, conf_thres, nms_thres):
+def batched_post_process(bboxes, cats, scores, conf_thres, nms_thres, records=None):
     '''
     The batched form of `for d in dts: d.post_process(...)` (examples/train.py:229-232):
     bboxes [B,N,4], cats [B,N], scores [B,N] on the device -> fixed-size records
     {count [B], bbox [B,512,4], class_idx [B,512], score [B,512], index [B,512]}, no host sync.
+    records: optional int32 [B, REC_WORDS] buffer to write (rows of a larger batch's record buffer).
     '''
-    return ops.postprocess(bboxes, cats, scores, conf_thres, nms_thres, TOPK)
+    return ops.postprocess(bboxes, cats, scores, conf_thres, nms_thres, TOPK, records=records)
