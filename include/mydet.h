@@ -303,6 +303,18 @@ int mydet_mbconv_expand_dw_f32(const float *x, int64_t ldx, const float *w_expan
                                float *y, int64_t ldy, int B, int H, int W, int Cin, int Cexp, int K, int stride,
                                int pad_t, int pad_l, int Ho, int Wo, float *se_partial, int S, void *stream);
 
+/* EfficientNet stem fused with the depthwise conv of the first MBConv block (which has expand_ratio 1):
+ *     y = swish(BN1(depthwise3x3_s1_pad1( swish(BN0(conv3x3_s2(image))) )))      + per-tile channel sums of y
+ * Replaces _conv_stem -> _bn0 -> swish (external/efficientnet/model.py:133-140) and _depthwise_conv -> _bn1 -> swish +
+ * the adaptive_avg_pool2d of block 0 (:76-80); the 32-channel stem output never reaches memory.
+ * x: the image, logical [B,3,H,W], strides sxb/sxc/sxh/sxw in floats (as mydet_conv2d_stem_f32).  w_stem: OHWI [32][3][3][3]
+ * with BN0's scale folded in, shift0 [32]; w_dw [3][3][32] with BN1's scale folded in, shift1 [32].  pad_t / pad_l: the
+ * stem's "SAME" padding (top / left; bottom / right follow from Hs, Ws).  y [B,Hs,Ws,ldy].  se_partial (optional):
+ * [B][S+1][32] with S == mydet_mbconv_tiles(Hs, Ws, 1).  C must be 32 (MYDET_E_UNSUPP otherwise). */
+int mydet_stem_dw_f32(const float *x, int64_t sxb, int64_t sxc, int64_t sxh, int64_t sxw, const float *w_stem,
+                      const float *shift0, const float *w_dw, const float *shift1, float *y, int64_t ldy, int B, int H, int W,
+                      int C, int pad_t, int pad_l, int Hs, int Ws, float *se_partial, int S, void *stream);
+
 /* Fused separable-conv node of the 88-channel BiFPN / EfDetHead pyramid, several nodes per launch:
  *     y = act( pointwise1x1( depthwise3x3_pad1( pre(in...) ) ) * scale + shift )
  *   n_in == 1: pre = identity                 spconv3x3_bn_swish / last sepconv of a head tower, models/rpns.py:121-205

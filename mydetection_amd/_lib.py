@@ -47,6 +47,8 @@ SIGNATURES = {
     'mydet_mbconv_tiles': [c_int, c_int, c_int],
     'mydet_mbconv_expand_dw_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64] + [c_int] * 11 + [c_ptr, c_int, c_ptr],
     'mydet_sepconv_nodes_f32': [c_int, c_ptr, c_int, c_int, c_ptr],
+    'mydet_stem_dw_f32': [c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int,
+                          c_int, c_int, c_int, c_int, c_ptr, c_int, c_ptr],
     'mydet_sepconv_decode_retina_f32': [c_int, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_i64, c_ptr],
     'mydet_bboxes_iou_f32': [c_ptr, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr],
     'mydet_bboxes_to_original_batched_f32': [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr],

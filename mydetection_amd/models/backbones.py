@@ -133,9 +133,14 @@ class EfNetBackbone(nn.Module):
         self.enable_dropout = cfg['model.efficientnet.enable_dropout']     # drop-connect: identity at inference
 
     def forward(self, x):
-        x = self.model.stem(x)
+        blocks = list(self.model._blocks)
+        if self.model.stem_fusable():           # stem + block 0's depthwise conv in one launch (block 0 keeps the resolution)
+            x = self.model.stem_block0(x)
+            blocks = blocks[1:]
+        else:
+            x = self.model.stem(x)
         features = []
-        for block in self.model._blocks:
+        for block in blocks:
             y = block(x)
             if y.shape[-1] != x.shape[-1]:
                 features.append(x)

@@ -372,6 +372,34 @@ def mbconv_expand_dw(x, w_expand, shift0, w_dw, shift1, k, stride, pad):
     return out, partial
 
 
+# MYDET_FUSED_STEM=0 keeps the EfficientNet stem and block 0's depthwise conv as two launches
+FUSED_STEM_DW = os.environ.get('MYDET_FUSED_STEM', '1') != '0'
+
+
+def stem_dw(x, w_stem, shift0, w_dw, shift1, pad):
+    """swish(BN1(depthwise3x3(swish(BN0(conv3x3_s2(image)))))) and the per-tile channel sums of the result in one launch
+    (EfficientNet stem + block 0's depthwise conv).  x [B,3,H,W] in any strides; w_stem OHWI [32,3,3,3] and w_dw
+    [3,3,32] carry the BatchNorm scales (`fold_scale`); pad = the stem's (top, left, bottom, right).
+    Returns (y [B,32,Hs,Ws], partial [B,S+1,32])."""
+    require_gpu(x, 'stem_dw')
+    assert x.dtype == torch.float32 and x.shape[1] == 3
+    B, _, H, W = x.shape
+    C = w_stem.shape[0]
+    Hs = conv_out_size(H, 3, 2, pad[0], pad[2])
+    Ws = conv_out_size(W, 3, 2, pad[1], pad[3])
+    out, ldy = empty_nhwc(B, C, Hs, Ws, x.device)
+    S = _lib.lib().mydet_mbconv_tiles(Hs, Ws, 1)
+    partial = torch.empty((B, S + 1, C), dtype=torch.float32, device=x.device)
+    sb, sc, sh, sw = x.stride()
+    t0 = TIMER.start() if TIMER else None
+    code = _lib.lib().mydet_stem_dw_f32(_ptr(x), sb, sc, sh, sw, _ptr(w_stem), _ptr(shift0), _ptr(w_dw), _ptr(shift1), _ptr(out),
+                                        ldy, B, H, W, C, pad[0], pad[1], Hs, Ws, _ptr(partial), S, _stream())
+    if t0:      # reference-layer bytes: stem (image in, map out) + depthwise (map in, map out)
+        TIMER.stop('stem_dw', t0, 0.0, 4.0 * B * (3 * H * W + 3 * C * Hs * Ws), fused=4.0 * B * (3 * H * W + C * Hs * Ws))
+    _lib.check(code, 'mydet_stem_dw_f32')
+    return out, partial
+
+
 def channel_sums(x):
     """Per-slice channel sums [B,S,C] of x [B,C,H,W] (standalone squeeze)."""
     require_gpu(x, 'channel_sums')

@@ -460,6 +460,40 @@ def test_se_gate_and_gated_conv(dev):
         assert (y.cpu().double() - ref).abs().max() < 3e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize('B,H,W,chlast', [(2, 64, 64, False), (3, 100, 76, False), (1, 61, 95, True), (2, 640, 640, False)])
+def test_stem_dw_fused(dev, B, H, W, chlast):
+    """EfficientNet stem + block 0's depthwise conv as one launch (csrc/stem_dw.hip; the 32-channel stem map stays in LDS):
+    against float64 (static SAME padding of a stride-2 3x3 conv on even and odd sizes, ragged tiles, both image
+    layouts), against the two-launch path, and its per-tile channel sums against the map it wrote."""
+    from mydetection_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    x = torch.rand(B, 3, H, W, generator=g) * 2 - 1
+    ws = torch.randn(32, 3, 3, 3, generator=g) * 0.3
+    wd = torch.randn(32, 1, 3, 3, generator=g) * 0.3
+    sc0, sh0 = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.2
+    sc1, sh1 = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.2
+    pt, pl = (1, 1) if H % 2 else (0, 0), (1, 1) if W % 2 else (0, 0)             # TF "SAME" for k3 s2: total 1 (even) / 2 (odd)
+    pad = (pt[0] if H % 2 else 0, pl[0] if W % 2 else 0, 1, 1)
+    xp = F.pad(x.double(), (pad[1], pad[3], pad[0], pad[2]))
+    t = F.conv2d(xp, ws.double(), stride=2) * sc0.double().view(1, -1, 1, 1) + sh0.double().view(1, -1, 1, 1)
+    t = t * torch.sigmoid(t)
+    ref = F.conv2d(t, wd.double(), padding=1, groups=32) * sc1.double().view(1, -1, 1, 1) + sh1.double().view(1, -1, 1, 1)
+    ref = ref * torch.sigmoid(ref)
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last) if chlast else x.to(dev)
+    ws_o = ws.permute(0, 2, 3, 1).contiguous().to(dev)                            # OHWI
+    wd_k = wd.permute(2, 3, 0, 1).reshape(3, 3, 32).contiguous().to(dev)          # [k,k,C]
+    y, partial = ops.stem_dw(xd, ops.fold_scale(ws_o, sc0.to(dev)), sh0.to(dev), ops.fold_scale(wd_k, sc1.to(dev)), sh1.to(dev), pad)
+    assert y.shape == ref.shape
+    tol = 3e-5 * max(1.0, ref.abs().max().item())
+    assert (y.cpu().double() - ref).abs().max() < tol
+    np.testing.assert_allclose(partial[:, :-1].sum(dim=1).cpu().double().numpy(), y.cpu().double().sum(dim=(2, 3)).numpy(), rtol=1e-5, atol=1e-3)
+    s = ops.conv2d_stem(xd, ws_o, sc0.to(dev), sh0.to(dev), 2, pad, ops.ACT_SWISH)
+    y2 = ops.dwconv(s, wd_k, sc1.to(dev), sh1.to(dev), 3, 1, (1, 1, 1, 1), ops.ACT_SWISH)
+    assert (y2 - y).abs().max().item() < tol
+    y3, _ = ops.stem_dw(xd, ops.fold_scale(ws_o, sc0.to(dev)), sh0.to(dev), ops.fold_scale(wd_k, sc1.to(dev)), sh1.to(dev), pad)
+    assert torch.equal(y3, y)
+
+
 @pytest.mark.parametrize('C,Cse,S', [(96, 4, 800), (32, 8, 800), (144, 6, 200), (1920, 80, 6), (1152, 48, 15), (672, 28, 15),
                                       (240, 10, 50), (16, 4, 128), (480, 20, 1), (4100, 80, 3)])
 def test_se_tail_from_slice_sums(dev, C, Cse, S):
