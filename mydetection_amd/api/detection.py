@@ -201,13 +201,35 @@ class Detector():
             g = cache.lookup(key)                                    # LRU; drops a graph captured before a weight change
             if g is None and cache.should_capture(key):
                 from ..graph import GraphedPath
-                g = cache.insert(key, GraphedPath(self.model, x, conf_thres, nms_thres))   # each graph owns its activations
+                # each graph owns its activations; the lane count is the detector's (below), not a timing decision
+                g = cache.insert(key, GraphedPath(self.model, x, conf_thres, nms_thres, lanes=self.batch_lanes(x.shape[0])))
             if g is not None:
                 return {k: v.clone() for k, v in g(x).items()}       # the graph's own record buffers are overwritten by the next replay
             cache.note_eager(key)
         with torch.no_grad():
-            bb, ci, sc = self.model.forward_candidates(x)
-            return batched_post_process(bb, ci, sc, conf_thres, nms_thres)
+            lanes = self.batch_lanes(x.shape[0])
+            if lanes == 1:
+                bb, ci, sc = self.model.forward_candidates(x)
+                return batched_post_process(bb, ci, sc, conf_thres, nms_thres)
+            # the eager form of a laned graph: the same parts of the batch, one after the other -- bit-identical to the replay
+            records = torch.empty((x.shape[0], ops._lib.REC_WORDS), dtype=torch.int32, device=x.device)
+            lo = 0
+            for part in x.tensor_split(lanes):
+                bb, ci, sc = self.model.forward_candidates(part)
+                batched_post_process(bb, ci, sc, conf_thres, nms_thres, records=records[lo:lo + part.shape[0]])
+                lo += part.shape[0]
+            return ops.record_views(records)
+
+    def batch_lanes(self, batch):
+        """How many parts a batch of this size is evaluated in (graph.GraphedPath: parallel graph branches).  A fixed rule
+        -- MYDET_LANES when it is a number, else the model's `batch_lanes_hint` (2 for the EfficientNet-based models,
+        whose step is many short launches; 1 for Darknet-53) for even batches -- so that the eager calls that precede a
+        capture and the replays that follow it give the same bits."""
+        env = os.environ.get('MYDET_LANES', 'auto')
+        want = int(env) if env.isdigit() else int(getattr(self.model, 'batch_lanes_hint', 1))
+        if want <= 1 or batch < 2:
+            return 1
+        return min(want, batch) if env.isdigit() else (want if batch % want == 0 else 1)
 
     def predict_batch(self, pil_imgs, **kwargs):
         """Batched form of detect_one (the reference loops image by image, api/detection.py:67-74): images that share a

@@ -61,6 +61,10 @@ class OneStageBBox(torch.nn.Module):
         self.bb_format = cfg.get('general.pred_bbox_format', 'cxcywh')
         self.input_format = cfg['general.input_format']
         self.weights_epoch = 0
+        # how many parts api.Detector evaluates an even batch in (graph.GraphedPath batch lanes): the EfficientNet-based
+        # models are ~130 launches of 10-150 us per step and gain 5 % from two lanes, Darknet-53's launches fill the chip
+        # alone and lose 5 % (profiles/r03_lanes.md)
+        self.batch_lanes_hint = 2 if 'efficientnet' in str(cfg.get('model.backbone.name', '')).lower() else 1
 
     # captured hipGraphs (graph.GraphedPath) record the addresses of the kernel-ready parameter copies; the epoch tells
     # them that the parameters were replaced (in-place edits of single tensors are seen by the eager path through the

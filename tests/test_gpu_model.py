@@ -686,6 +686,32 @@ def test_hipgraph_replay_equals_eager(model):
             assert torch.equal(rec[k], ref[k]), k
 
 
+def test_detector_lanes_same_bits_before_and_after_capture(monkeypatch):
+    """api.Detector on an EfficientNet-based model evaluates an even batch as two half batches (batch lanes): the eager calls
+    that precede the capture run the halves one after the other, the replays run them as parallel graph branches -- the
+    detections of the first (eager), second (captured) and later (replayed) calls are bit-identical."""
+    import PIL.Image
+    from mydetection_amd import synth
+    from mydetection_amd.api import Detector
+    from mydetection_amd.models.general import name_to_model
+    monkeypatch.delenv('MYDET_LANES', raising=False)           # the rule under test is the default one
+    m, cfg = name_to_model('efficientdet-d1')
+    m.load_state_dict(synth.make_state_dict(m.state_dict(), 'efficientdet-d1'), strict=True)
+    m = m.eval().cuda()
+    assert m.batch_lanes_hint == 2
+    det = Detector(model_and_cfg=(m, cfg))
+    assert det.batch_lanes(4) == 2 and det.batch_lanes(3) == 1 and det.batch_lanes(1) == 1
+    imgs = [PIL.Image.fromarray((synth.make_images(1, (256, 256), seed=60 + i)[0].permute(1, 2, 0).numpy() * 255).astype(np.uint8))
+            for i in range(4)]
+    kw = dict(preprocessing='resize_pad_square', input_size=256, conf_thres=0.005)
+    runs = [det.predict_batch(imgs, **kw) for _ in range(4)]
+    assert det.use_graph and len(det._graphs.graphs) == 1 and next(iter(det._graphs.graphs.values())).lanes == 2
+    assert all(len(d) > 0 for d in runs[0])
+    for later in runs[1:]:
+        for d, e in zip(runs[0], later):
+            assert torch.equal(d.cats, e.cats) and torch.equal(d.scores, e.scores) and torch.equal(d.bboxes, e.bboxes)
+
+
 @pytest.mark.parametrize('variant', ['plain', 'saturated_and_tied'])
 def test_fused_retina_decode_equals_two_launch_path(monkeypatch, variant):
     """EfDetHead + RetinaLayer: the decode in the epilogue of the towers' last layers (ops.sepconv_decode_retina: no class
