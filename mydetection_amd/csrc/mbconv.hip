@@ -226,9 +226,10 @@ struct DwTArgs {
     int C, H, W, Ho, Wo, pad_t, pad_l, act, S, tiles_x, nchunks;
 };
 
-template <int K, bool SUM>
+// CQ channel quads per workgroup: 8 (tile 8 x 16) for C >= 32, 4 (tile 8 x 32) for the 16-channel layer
+template <int K, bool SUM, int CQ = 8>
 __global__ __launch_bounds__(256, 4) void dwconv_tile_kernel(const DwTArgs p) {
-    constexpr int TH = 8, TW = 16, IH = TH + K - 1, IW = TW + K - 1, NPIX = IH * IW, CQ = 8, PS = CQ * 4 + 4;
+    constexpr int TH = 8, TW = 128 / CQ, IH = TH + K - 1, IW = TW + K - 1, NPIX = IH * IW, PS = CQ * 4 + 4;
     constexpr int NL = (NPIX * CQ + 255) / 256;
     __shared__ __attribute__((aligned(16))) float tile[NPIX * PS];
     __shared__ __attribute__((aligned(16))) float wl[K * K * CQ * 4];
@@ -715,7 +716,8 @@ int launch_dw(const DwArgs &p0, int B, hipStream_t stream) {
 // number of squeeze slices mydet_dwconv_f32 writes for this layer (the caller sizes se_partial with it)
 extern "C" int mydet_dwconv_slices(int Ho, int Wo, int C, int K, int stride) {
     if (Ho <= 0 || Wo <= 0) return 0;
-    if (stride == 1 && (K == 3 || K == 5) && dw_tiled() && C >= 32) return ((Ho + 7) / 8) * ((Wo + 15) / 16);      // LDS-tiled kernel: one slice per tile
+    if (stride == 1 && (K == 3 || K == 5) && dw_tiled() && C >= 16)      // LDS-tiled kernel: one slice per tile (8 x 16, or 8 x 32 under 32 channels)
+        return ((Ho + 7) / 8) * (C >= 32 ? (Wo + 15) / 16 : (Wo + 31) / 32);
     int s = Ho * Wo / 16;
     s = s > 128 ? 128 : s;
     return s < 1 ? 1 : s;
@@ -726,13 +728,19 @@ static int launch_dw_tile(const DwArgs &a, int B, hipStream_t stream) {
     DwTArgs p;
     p.x = a.x; p.w = a.w; p.scale = a.scale; p.shift = a.shift; p.y = a.y; p.partial = a.partial; p.ldx = a.ldx; p.ldy = a.ldy;
     p.C = a.C; p.H = a.H; p.W = a.W; p.Ho = a.Ho; p.Wo = a.Wo; p.pad_t = a.pad_t; p.pad_l = a.pad_l; p.act = a.act;
-    p.tiles_x = (a.Wo + 15) / 16;
+    const bool narrow = a.C < 32;                            // 4 quads x (8 x 32) outputs instead of 8 quads x (8 x 16)
+    p.tiles_x = narrow ? (a.Wo + 31) / 32 : (a.Wo + 15) / 16;
     p.S = p.tiles_x * ((a.Ho + 7) / 8);
-    p.nchunks = ((a.C >> 2) + 7) / 8;
+    p.nchunks = narrow ? ((a.C >> 2) + 3) / 4 : ((a.C >> 2) + 7) / 8;
     const int64_t grid = (int64_t)B * p.S * p.nchunks;      // one workgroup per (image, tile, chunk): a persistent form with a
     if (grid > 0x7fffffff) return MYDET_E_UNSUPP;           // register prefetch of the next tile measured 20 % slower (profiles/r03_mbconv_notes.md)
-    if (a.partial) hipLaunchKernelGGL((dwconv_tile_kernel<K, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((dwconv_tile_kernel<K, false>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    if (narrow) {
+        if (a.partial) hipLaunchKernelGGL((dwconv_tile_kernel<K, true, 4>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((dwconv_tile_kernel<K, false, 4>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    } else {
+        if (a.partial) hipLaunchKernelGGL((dwconv_tile_kernel<K, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((dwconv_tile_kernel<K, false>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    }
     return mydet_launch_status();
 }
 
@@ -749,7 +757,7 @@ extern "C" int mydet_dwconv_f32(const float *x, int64_t ldx, const float *w, con
     p.C = C; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.pad_t = pad_t; p.pad_l = pad_l; p.act = act; p.S = S; p.total = 0;
     hipStream_t st = (hipStream_t)stream;
     if (se_partial && S != mydet_dwconv_slices(Ho, Wo, C, K, stride)) return MYDET_E_BADARG;
-    if (stride == 1 && dw_tiled() && C >= 32) return K == 3 ? launch_dw_tile<3>(p, B, st) : launch_dw_tile<5>(p, B, st);
+    if (stride == 1 && dw_tiled() && C >= 16) return K == 3 ? launch_dw_tile<3>(p, B, st) : launch_dw_tile<5>(p, B, st);
     if (K == 3) return stride == 1 ? launch_dw<3, 1>(p, B, st) : launch_dw<3, 2>(p, B, st);
     return stride == 1 ? launch_dw<5, 1>(p, B, st) : launch_dw<5, 2>(p, B, st);
 }

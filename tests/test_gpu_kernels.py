@@ -409,7 +409,8 @@ def test_nms_standalone_and_to_original(dev, golden):
 # ------------------------------------------------------------------ EfficientNet / BiFPN family kernels
 @pytest.mark.parametrize('k,s,pad,C,H,W,act', [(3, 1, (1, 1, 1, 1), 32, 20, 24, 2), (3, 2, (0, 0, 1, 1), 96, 16, 16, 2),
                                               (5, 1, (2, 2, 2, 2), 144, 12, 10, 2), (5, 2, (1, 1, 2, 2), 240, 10, 10, 2),
-                                              (3, 1, (1, 1, 1, 1), 88, 5, 5, 0)])
+                                              (3, 1, (1, 1, 1, 1), 88, 5, 5, 0), (3, 1, (1, 1, 1, 1), 16, 41, 70, 2),
+                                              (5, 1, (2, 2, 2, 2), 24, 19, 33, 2), (3, 1, (1, 1, 1, 1), 672, 40, 40, 2)])
 def test_dwconv(dev, k, s, pad, C, H, W, act):
     from mydetection_amd import ops
     g = torch.Generator().manual_seed(3)
