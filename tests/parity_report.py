@@ -6,6 +6,7 @@ For every model configuration: the HIP path's candidates (scores, boxes, class i
 the float32 CPU oracle (= the reference's arithmetic, tests/test_oracle_golden.py) -- the largest absolute error, the
 largest error in units of the test tolerance (|err| / (1e-4 + 1e-4 |ref|): must stay below 1), class-id agreement --
 and whether the post-processed detection records equal the oracle's post_process of the oracle's candidates."""
+import contextlib
 import json
 import os
 import sys
@@ -22,7 +23,8 @@ from oracle import efficientdet as oe, postprocess as opp, yolov3 as oy    # noq
 
 out = {}
 for name in ('yolov3_80', 'efficientdet-d1', 'd1_fcs2_atss', 'd1_fcs2', 'd1_fcs', 'd1_yv3'):
-    m, cfg = name_to_model(name)
+    with contextlib.redirect_stdout(sys.stderr):           # the factories print notices; stdout carries only the report
+        m, cfg = name_to_model(name)
     m.load_state_dict(synth.make_state_dict(m.state_dict(), name), strict=True)
     m = m.eval().cuda()
     sd = {k: v.cpu() for k, v in m.state_dict().items()}
