@@ -180,7 +180,9 @@ class ConvBn(nn.Sequential):
 
     def forward(self, x):
         w, scale, shift = prepare_conv(self, 'main', self[0], self[1])
-        return ops.conv2d(x, w, scale, shift, self.k, 1, (self.p,) * 4, ops.ACT_NONE)
+        # the 3x3 C6 / C7 convs (320->88 @20^2, 88->88 @10^2) take the Winograd kernels like every other 3x3 stride-1 layer
+        u, u4 = prepare_wino(self, 'wino', w) if self.k == 3 and self.p == 1 else (None, None)
+        return ops.conv2d(x, w, scale, shift, self.k, 1, (self.p,) * 4, ops.ACT_NONE, wino=u, wino4=u4)
 
 
 class SpconvBn(nn.Sequential):
