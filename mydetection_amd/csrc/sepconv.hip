@@ -464,9 +464,11 @@ __global__ __launch_bounds__(256, 4) void sepconv_decode_kernel(const SpDecArgs 
         wreg.load(P, (nb_) + 1, tid);                                                                 \
         float af[SpW<KS>::KQ * 4];                                                                    \
         SpW<KS>::fragments(ring + cur * WSLOT, lane, af);                                             \
-        const f32x4 sh_ = *reinterpret_cast<const f32x4 *>(P.shift + (nb_) * 16 + nsub);              \
+        /* clamped like sepconv_kernel's: a box node's shift has A*4 floats, not whole 16-channel blocks */ \
+        const int nq_ = min((nb_) * 16 + nsub, P.Cout - 4);                                           \
+        const f32x4 sh_ = *reinterpret_cast<const f32x4 *>(P.shift + nq_);                            \
         f32x4 sc_ = {1.f, 1.f, 1.f, 1.f};                                                             \
-        if (P.scale) sc_ = *reinterpret_cast<const f32x4 *>(P.scale + (nb_) * 16 + nsub);             \
+        if (P.scale) sc_ = *reinterpret_cast<const f32x4 *>(P.scale + nq_);                           \
         f32x4 acc0_ = {0.f, 0.f, 0.f, 0.f}, acc1_ = {0.f, 0.f, 0.f, 0.f};                             \
         _Pragma("unroll") for (int ks = 0; ks < KS; ks += 2) {                                        \
             acc0_ = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks], bf[ks], acc0_, 0, 0, 0);             \
@@ -601,6 +603,7 @@ extern "C" int mydet_sepconv_nodes_f32(int n, const mydet_sepconv_node *nodes, i
         p.nsplit = (p.nb + p.nb_per - 1) / p.nb_per;
         p.tile_begin = (int)tiles;
         tiles += (int64_t)p.tiles_per_img * B * p.nsplit;
+        if (tiles > 0x7fffffff) return MYDET_E_UNSUPP;           // (a forced split can exceed what the first check saw)
     }
     a.total = (int)tiles;
     hipLaunchKernelGGL((sepconv_kernel<22>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
@@ -658,6 +661,7 @@ extern "C" int mydet_sepconv_decode_retina_f32(int n, const mydet_sepconv_decode
         p.nsplit = (p.nb + p.nb_per - 1) / p.nb_per;
         p.tile_begin = (int)tiles;
         tiles += (int64_t)p.tiles_per_img * B * p.nsplit;
+        if (tiles > 0x7fffffff) return MYDET_E_UNSUPP;
     }
     if (nba == 5)
         hipLaunchKernelGGL((sepconv_decode_kernel<22, 5>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);

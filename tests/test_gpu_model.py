@@ -577,7 +577,8 @@ def test_graph_survives_workspace_growth_and_weight_reload(model, monkeypatch):
             assert torch.equal(got[k], eager_new[k]), k
     finally:
         m.load_state_dict(sd, strict=True)
-        ops._WINO4_WS.pop((dev.type, dev.index), None)
+        for k in [k for k in ops._WINO4_WS if k[:2] == (dev.type, dev.index)]:
+            ops._WINO4_WS.pop(k)                              # keys are (type, index, lane)
 
 
 def test_postprocess_flags_out_of_range_class_ids():

@@ -370,6 +370,13 @@ def test_pyramid_node_address_audit():
                     off_max = (((B - 1) * hw + oy.max()) * hw + oy.max()) * ldy + cout - 1
                     assert off_max < B * hw * hw * ldy
     assert checked == 2 * (5 * 1 + 4 * 2 + 5 * 3 + 5 * 2)
+    # the per-channel shift / scale reads of sepconv_decode_kernel (SP_DEC_BLOCK): a float4 at min(16 nb + nsub, Cout - 4)
+    # for every 16-channel block nb of the node and nsub = 0, 4, 8, 12.  A box node's vectors hold A*4 floats (36 for the
+    # nine RetinaNet anchors: the last block is a quarter full); a class node's A * nba * 16 (whole blocks per anchor)
+    for cout in (36, 4, 9 * 5 * 16, 9 * 6 * 16, 88):
+        nb = (cout + 15) // 16
+        offs = np.minimum(np.arange(nb).reshape(-1, 1) * 16 + np.array([0, 4, 8, 12]).reshape(1, -1), cout - 4)
+        assert offs.min() >= 0 and offs.max() + 3 < cout, (cout, offs.max())
     # and the ABI refuses what the kernel could not address: a missing input pointer inside n_in, odd maps under up2x
     from mydetection_amd import _lib
     node = _lib.SepconvNode()
