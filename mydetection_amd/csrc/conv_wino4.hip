@@ -12,11 +12,11 @@
 //
 // Two launches per layer:
 //  1. wino4_input_kernel: V = Bt d B once per (tile, input channel), written to a workspace in MFMA-fragment order
-//     [tile block of 32][k/4][position group of 4][k%4][tile] float4 = positions 4g..4g+3.  An HBM-bound pass (x read once
-//     through L2, 2.25x its size written).  Fusing it into the GEMM kernel was measured and lost: the 36 dword loads per
-//     (tile, channel) run the texture-address unit at 4 lanes/clock -- 100 % busy at two workgroups per CU, repeated by
-//     every output-channel block -- and the ~150 transform VALU per thread issue beside the MFMAs at full price
-//     (profiles/r02_wino4_notes.md).
+//     [tile block of 32][k/4][position group of 4][k%4][tile] float4 = positions 4g..4g+3.  An HBM-bound pass (x read once,
+//     2.25x its size written) with 16-byte accesses on both sides: 5.3-5.7 TB/s (round 4; the dword-load form of rounds
+//     2-3 ran at 2.8-4.3 TB/s).  Fusing it into the GEMM kernel was measured and lost: the patch loads per (tile, channel)
+//     are repeated by every output-channel block and the ~150 transform VALU per element issue beside the MFMAs at full
+//     price (profiles/r02_wino4_notes.md).
 //  2. conv_wino4_kernel: a workgroup of 4 waves owns 32 output channels x 32 tiles; wave (wc, wt) owns channels 16wc.. x
 //     tiles 16wt.. for all 36 positions (36 x 4 = 144 accumulator registers).  Two workgroups per CU (72 KB of LDS each,
 //     one wave of each per SIMD).  K = Cin is walked 4 channels (one MFMA k-step) per stage through two LDS stages; both
@@ -87,13 +87,18 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const float *base, int64_
     }
 
 
-// ---- 1. input transform.  Workgroup = 32 tiles (one tile block) x 8 input channels (two k-quads); thread = (tile,
-// channel): a wave covers 8 tiles x 8 channels, so a patch load touches 8 runs of 32 bytes and a store of one position
-// group writes 8 whole 128-byte lines (8 tiles x float4, per (k-quad, k)).
-__global__ __launch_bounds__(256) void wino4_input_kernel(const W4Args p) {
+// ---- 1. input transform.  Workgroup = 32 tiles (one tile block) x 8 k-quads (32 input channels); thread = (tile, k-quad):
+// it loads the 36 pixels of the patch as float4 -- a wave = 8 tiles x 8 quads reads eight whole 128-byte lines per load
+// instruction (rounds 2-3: one channel per thread, 36 dword loads: eight 32-byte sectors per instruction, four times as
+// many instructions, 2.8-4.3 TB/s) --, transforms its four channels side by side (the same expressions per element as
+// before: bit-identical V) and writes 36 float4 (position group g, channel k of the quad): per store instruction eight
+// whole 128-byte lines, one per k-quad.  231 VGPRs: two waves per SIMD, each with 36 KB of loads in flight -- the
+// launch is bandwidth-, not occupancy-bound (tools/micro/store_pattern.hip: this store pattern alone runs at the
+// rate of a linear fill).
+__global__ __launch_bounds__(256, 2) void wino4_input_kernel(const W4Args p) {
     const int tid = threadIdx.x;
-    const int sc = tid & 7, st = ((tid >> 6) << 3) | ((tid >> 3) & 7);       // channel of the 8, tile of the 32
-    const int mb = blockIdx.x, c = blockIdx.y * 8 + sc;
+    const int sq = tid & 7, st = tid >> 3;             // k-quad of the 8, tile of the 32 (wave w: tiles 8w .. 8w+7)
+    const int mb = blockIdx.x, q = blockIdx.y * 8 + sq, c = q * 4;
     const int tpi = p.TH * p.TW, nk = p.Cin >> 2;
     const int mt = mb * TILES + st;
     const int b0 = (mb * TILES) / tpi;
@@ -108,39 +113,44 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const W4Args p) {
     const int iy0 = 4 * ty - 1, ix0 = 4 * tx - 1;
     const unsigned vbase = mt < p.MT && c < p.Cin
                                ? (unsigned)((((((int64_t)(b - b0) * p.H + iy0) * p.W + ix0) * p.ldx + c) + lead) * 4)
-                               : OOB;                  // tiles past the end and channels past Cin transform zeros
+                               : OOB;                  // tiles past the end and quads past Cin transform zeros
     const unsigned colstep = (unsigned)(p.ldx * 4), rowstep = (unsigned)(p.W * p.ldx * 4);
-    float gv[36];
+    f32x4 gv[36];
 #pragma unroll
-    for (int q = 0; q < 36; ++q) {
-        const bool ok = (unsigned)(iy0 + q / 6) < (unsigned)p.H && (unsigned)(ix0 + q % 6) < (unsigned)p.W;
-        gv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+    for (int o = 0; o < 36; ++o) {
+        const bool ok = (unsigned)(iy0 + o / 6) < (unsigned)p.H && (unsigned)(ix0 + o % 6) < (unsigned)p.W;
+        gv[o] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                               xr, ok ? vbase : OOB,
-                                              __builtin_amdgcn_readfirstlane((unsigned)(q / 6) * rowstep + (unsigned)(q % 6) * colstep), 0));
-    }
-    // V = Bt d B in place: the column pass (Bt d), then the row pass; position p = 6i + j ends up in gv[p]
-#pragma unroll
-    for (int m = 0; m < 6; ++m) {
-        float o[6];
-        W4_BT(o, gv[m], gv[6 + m], gv[12 + m], gv[18 + m], gv[24 + m], gv[30 + m])
-#pragma unroll
-        for (int i = 0; i < 6; ++i) gv[6 * i + m] = o[i];
+                                              __builtin_amdgcn_readfirstlane((unsigned)(o / 6) * rowstep + (unsigned)(o % 6) * colstep), 0));
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        float o[6];
-        W4_BT(o, gv[6 * i], gv[6 * i + 1], gv[6 * i + 2], gv[6 * i + 3], gv[6 * i + 4], gv[6 * i + 5])
+    for (int e = 0; e < 4; ++e) {
 #pragma unroll
-        for (int m = 0; m < 6; ++m) gv[6 * i + m] = o[m];
+        for (int m = 0; m < 6; ++m) {
+            float o[6];
+            W4_BT(o, gv[m][e], gv[6 + m][e], gv[12 + m][e], gv[18 + m][e], gv[24 + m][e], gv[30 + m][e])
+#pragma unroll
+            for (int i = 0; i < 6; ++i) gv[6 * i + m][e] = o[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float o[6];
+            W4_BT(o, gv[6 * i][e], gv[6 * i + 1][e], gv[6 * i + 2][e], gv[6 * i + 3][e], gv[6 * i + 4][e], gv[6 * i + 5][e])
+#pragma unroll
+            for (int m = 0; m < 6; ++m) gv[6 * i + m][e] = o[m];
+        }
     }
     if (c < p.Cin) {                                   // Cin % 4 == 0: a k-quad is written whole or not at all
-        // non-temporal: V is read back by the next launch from HBM / the Infinity Cache, not from this XCD's L2 (-5 %);
-        // staging the block's 36 KB through LDS for 1 KB-contiguous stores was measured and changes nothing -- the
-        // launch is bound by the 2.25 x input bytes it writes (3.9 TB/s with the loads removed)
-        f32x4 *dst = reinterpret_cast<f32x4 *>(p.v) + (((int64_t)mb * nk + (c >> 2)) * NPG * KC + (c & 3)) * TILES + st;
+        // non-temporal: V is read back by the next launch from HBM / the Infinity Cache, not from this XCD's L2 (in the
+        // model +0.8 % images/s over plain stores; back to back on its own the plain form is the faster one)
+        f32x4 *dst = reinterpret_cast<f32x4 *>(p.v) + ((int64_t)mb * nk + q) * (NPG * KC * TILES) + st;
 #pragma unroll
         for (int g = 0; g < NPG; ++g)
-            __builtin_nontemporal_store(f32x4{gv[4 * g], gv[4 * g + 1], gv[4 * g + 2], gv[4 * g + 3]}, dst + g * KC * TILES);
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                const f32x4 val = f32x4{gv[4 * g][k], gv[4 * g + 1][k], gv[4 * g + 2][k], gv[4 * g + 3][k]};
+                __builtin_nontemporal_store(val, dst + (g * KC + k) * TILES);
+            }
     }
 }
 
@@ -333,7 +343,7 @@ int launch_w4(W4Args a, hipStream_t stream) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino4_kernel<ACT, RES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     }
-    hipLaunchKernelGGL(wino4_input_kernel, dim3((a.MT + TILES - 1) / TILES, (a.Cin + 7) / 8), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(wino4_input_kernel, dim3((a.MT + TILES - 1) / TILES, (a.Cin + 31) / 32), dim3(256), 0, stream, a);
     hipLaunchKernelGGL((conv_wino4_kernel<ACT, RES>), dim3(a.nblk), dim3(64 * NW), LDS_BYTES, stream, a);
     return mydet_launch_status();
 }
@@ -391,7 +401,7 @@ extern "C" int mydet_conv2d_wino4_f32(const float *x, int64_t ldx, const float *
     const int64_t nbm = (a.nmb + (64 >> a.rn_log2) - 1) / (64 >> a.rn_log2);
     if (nbm * a.nbn * 64 > 0x7FFFFFFF) return MYDET_E_UNSUPP;
     a.nblk = (int)(nbm * a.nbn * 64);
-    if ((MT + TILES - 1) / TILES > 0x7FFFFFFF || (Cin + 7) / 8 > 65535) return MYDET_E_UNSUPP;
+    if ((MT + TILES - 1) / TILES > 0x7FFFFFFF || (Cin + 31) / 32 > 65535) return MYDET_E_UNSUPP;
     hipStream_t s = (hipStream_t)stream;
     const bool res = residual != nullptr;
     switch (act) {
