@@ -26,11 +26,12 @@ struct StemArgs {
 constexpr int ST_LD = 36;          // LDS row per pixel: 32 channels + pad (16-byte aligned, conflict-free b128)
 
 __global__ __launch_bounds__(256) void conv_stem_kernel(const StemArgs p) {
-    __shared__ __attribute__((aligned(16))) float tile[4][64 * ST_LD];     // one strip per wave
+    __shared__ __attribute__((aligned(16))) float tile[4][32 * ST_LD];     // one strip per wave: 32 pixels at a time
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t mw = (int64_t)blockIdx.x * 256 + wave * 64;               // first pixel of this wave
     const int64_t m = mw + lane;
     float *strip = tile[wave];
+    f32x4 o[8];
     if (m < p.M) {
         const int ow = (int)(m % p.Wo);
         const int64_t t = m / p.Wo;
@@ -52,7 +53,6 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const StemArgs p) {
         }
 #pragma unroll
         for (int n4 = 0; n4 < 8; ++n4) {
-            f32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = n4 * 4 + j;
@@ -62,19 +62,27 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const StemArgs p) {
                 for (int k = 0; k < 27; ++k) acc = fmaf(in[k], wr[k], acc);
                 const float scl = p.scale ? p.scale[n] : 1.0f;
                 const float sft = p.shift ? p.shift[n] : 0.0f;
-                o[j] = mydet_act(acc * scl + sft, p.act);
+                o[n4][j] = mydet_act(acc * scl + sft, p.act);
             }
-            *reinterpret_cast<f32x4 *>(strip + lane * ST_LD + n4 * 4) = o;
         }
     }
-    __builtin_amdgcn_wave_barrier();
-    // transposed write-out: 8 consecutive lanes emit one pixel's 128-byte line
+    // transposed write-out, the wave's pixels in two halves of 32 (the strip is 4.6 KB per wave -- 18 KB per workgroup,
+    // eight workgroups per CU): 8 consecutive lanes emit one pixel's 128-byte line, an instruction writes 1 KB
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int q = lane + 64 * j, px = q >> 3, part = q & 7;
-        if (mw + px < p.M)
-            *reinterpret_cast<f32x4 *>(p.y + (mw + px) * p.ldy + part * 4) =
-                *reinterpret_cast<const f32x4 *>(strip + px * ST_LD + part * 4);
+    for (int h = 0; h < 2; ++h) {
+        if ((lane >> 5) == h) {
+#pragma unroll
+            for (int n4 = 0; n4 < 8; ++n4) *reinterpret_cast<f32x4 *>(strip + (lane & 31) * ST_LD + n4 * 4) = o[n4];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = lane + 64 * j, px = q >> 3, part = q & 7;
+            if (mw + 32 * h + px < p.M)
+                __builtin_nontemporal_store(*reinterpret_cast<const f32x4 *>(strip + px * ST_LD + part * 4),
+                                            reinterpret_cast<f32x4 *>(p.y + (mw + 32 * h + px) * p.ldy + part * 4));
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
