@@ -23,7 +23,11 @@ The JSON line also carries
   cpu_baseline -- the CPU oracle (port of the reference path) timed on this host's cores on a bounded sample
                   (rank 0, N=1 only): forward and post-process separately, median of 5
   stages       -- per-kernel-family time per step, incl. the NMS launch (latency-bound; p50 reported)
+  parity_check -- the timed step's own records against the oracle (first images of the batch): NMS decisions exact, and --
+                  with the CPU baseline's oracle forward at hand -- scores / boxes within 1e-4 and the detection sets equal
+                  wherever no decision sits inside the observed round-off; a failure exits with code 4
 `--nms-worst` measures the isolated NMS worst cases of SURVEY 8d instead (512 boxes in 1 / in 80 classes).
+`--profile` is the command to put behind `rocprofv3 ... --`: nothing but warm-up and timed passes is launched.
 """
 import argparse
 import json
@@ -65,6 +69,12 @@ def parse_args(argv=None):
     ap.add_argument('--cpu-sample-batch', type=int, default=2)
     ap.add_argument('--cpu-repeats', type=int, default=5)
     ap.add_argument('--cpu-threads', type=int, default=16)
+    ap.add_argument('--lanes', default=None,
+                    help="batch lanes of the replayed graph: a number, 'auto' (capture with 1 and 2, keep the faster: rank 0 decides "
+                         "for all ranks), default: MYDET_LANES or the model's batch_lanes_hint -- the rule api.Detector uses")
+    ap.add_argument('--profile', action='store_true',
+                    help='for rocprofv3: only capture warm-up + warm-up + timed replays run (no lane trial, no pricing pass, no NMS '
+                         'p50 loop, no CPU baseline): every kernel count in the trace = launches per step x `passes` of the JSON line')
     return ap.parse_args(argv)
 
 
@@ -130,6 +140,8 @@ def cpu_baseline(config, cfg, size, sample_batch, repeats, max_threads=16):
         return t1 - t0, time.perf_counter() - t1
     once()
     runs = [once() for _ in range(repeats)]
+    with torch.no_grad():
+        bb, ci, sc = fwd()                           # the oracle's candidates of the sample images: bench's parity check
     f_med = statistics.median(r[0] for r in runs)
     p_med = statistics.median(r[1] for r in runs)
     tot = statistics.median(r[0] + r[1] for r in runs)
@@ -138,7 +150,68 @@ def cpu_baseline(config, cfg, size, sample_batch, repeats, max_threads=16):
             'forward_ms_per_image': round(f_med / sample_batch * 1e3, 2),
             'post_process_ms_per_image': round(p_med / sample_batch * 1e3, 3),
             'sample': f'oracle/ (torch-CPU restatement of the reference path + C NMS), {config} batch {sample_batch} '
-                      f'{size}x{size}, forward and per-image post_process timed separately, median of {repeats} after 1 warm-up'}
+                      f'{size}x{size}, forward and per-image post_process timed separately, median of {repeats} after 1 warm-up'}, \
+        (bb.numpy(), ci.numpy(), sc.numpy())
+
+
+def parity_check(cand, rec, conf, nms, oracle_cand=None, images=2, extra_conf=()):
+    """SURVEY 8d "parity gates run with every measurement": the first `images` images of the timed batch.
+    * always: the GPU's detection records == the oracle's post_process (oracle/postprocess.py: reference filter / top-512
+      / class-aware NMS order) of the GPU's own candidates -- count, candidate indices, classes, order, exactly;
+    * with the oracle's forward at hand (the cpu_baseline leg computes it for its timing anyway): every candidate's score
+      within 1e-4 and box within 1e-4 + 1e-4 |ref| (north_star), and the detection sets equal to the oracle's own
+      wherever no post-processing decision sits within twice the observed score error of flipping
+      (oracle.postprocess.decision_margins)."""
+    import numpy as np
+    from oracle import postprocess as opp
+    bb, ci, sc = (t[:images].cpu().numpy() for t in cand)
+    n = bb.shape[0]
+    count = rec['count'][:n].cpu().numpy()
+    index = rec['index'][:n].cpu().numpy()
+    cls = rec['class_idx'][:n].cpu().numpy()
+    out = {'images': int(n), 'nms_equals_oracle_on_gpu_candidates': True}
+    for b in range(n):
+        _, oc, _, oi = opp.post_process(bb[b], ci[b], sc[b], conf, nms)
+        k = int(count[b])
+        if k != len(oi) or not np.array_equal(index[b, :k], oi) or not np.array_equal(cls[b, :k], oc):
+            out['nms_equals_oracle_on_gpu_candidates'] = False
+    ok = out['nms_equals_oracle_on_gpu_candidates']
+    if oracle_cand is not None:
+        obb, oci, osc = (a[:n] for a in oracle_cand)
+        s_err = float(np.abs(sc - osc).max())
+        b_err = float((np.abs(bb - obb) / (1e-4 + 1e-4 * np.abs(obb))).max())
+        safe = equal = 0
+        for b in range(n):
+            if opp.decision_margins(osc[b], oci[b], conf, eps=max(2.0 * s_err, 2e-6)) is None:
+                safe += 1
+                _, rc, _, ri = opp.post_process(obb[b], oci[b], osc[b], conf, nms)
+                k = int(count[b])
+                equal += int(k == len(ri) and np.array_equal(index[b, :k], ri) and np.array_equal(cls[b, :k], rc))
+        # the same comparison at the demo thresholds (fresh post-process launches on the step's candidates): at the AP
+        # threshold thousands of long-tailed scores crowd the top-512 cut, and few images are margin-safe there
+        from mydetection_amd.utils.structures import batched_post_process
+        extra = {}
+        for t in extra_conf:
+            r_t = batched_post_process(*(c[:n] for c in cand), t, nms)
+            cnt_t, idx_t, cls_t = (r_t[k].cpu().numpy() for k in ('count', 'index', 'class_idx'))
+            s_t = e_t = 0
+            for b in range(n):
+                if opp.decision_margins(osc[b], oci[b], t, eps=max(2.0 * s_err, 2e-6)) is None:
+                    s_t += 1
+                    _, rc, _, ri = opp.post_process(obb[b], oci[b], osc[b], t, nms)
+                    k = int(cnt_t[b])
+                    e_t += int(k == len(ri) and np.array_equal(idx_t[b, :k], ri) and np.array_equal(cls_t[b, :k], rc))
+            extra[f'conf_{t}'] = f'{e_t}/{s_t}'
+            safe, equal = safe + s_t, equal + e_t
+        if extra:
+            out['sets_equal_other_thresholds'] = extra
+        out.update({'max_score_err': s_err, 'max_box_err_over_tol': round(b_err, 4),
+                    'class_id_agreement': round(float((ci == oci).mean()), 6),
+                    'sets_equal': f'{equal}/{safe} margin-safe (image, threshold) pairs equal the oracle\'s detections (count, candidate indices, classes, order)',
+                    'margin_safe_pairs': safe, 'tolerance': 'scores 1e-4 abs; boxes 1e-4 + 1e-4 |ref|'})
+        ok = ok and s_err <= 1e-4 and b_err <= 1.0 and equal == safe
+    out['ok'] = bool(ok)
+    return out
 
 
 def nms_worst_cases(dev, iters=200, warm=20):
@@ -220,9 +293,29 @@ def main():
     x = synth.make_image_set(lo, hi, args.size, cfg['general.input_format']).to(dev)
 
     graphed = None
+    lanes_rule = None
     if args.graph:
         from mydetection_amd.graph import GraphedPath
-        graphed = GraphedPath(model, x, conf, nms)
+        # lane count: ONE rule for every rank (lanes change the last float bits, and --verify compares ranks bit for bit):
+        # --lanes / MYDET_LANES when numeric, else the model's hint (what api.Detector does); 'auto' = rank 0 times both
+        # captures and tells the others
+        want = args.lanes if args.lanes is not None else os.environ.get('MYDET_LANES', '')
+        if str(want) == 'auto' and not args.profile:
+            lanes_rule = 'auto (rank 0 timed 1 and 2 lanes' + (', broadcast)' if dist_on else ')')
+            if rank == 0:
+                graphed = GraphedPath(model, x, conf, nms, lanes='auto')
+            n_l, lanes_per_rank = parallel.agree_on_lanes(graphed.lanes if rank == 0 else None, device=dev)
+            if rank != 0:
+                graphed = GraphedPath(model, x, conf, nms, lanes=n_l)
+        else:
+            n_l = int(want) if str(want).isdigit() else int(getattr(model, 'batch_lanes_hint', 1))
+            if n_l < 1 or batch % max(n_l, 1):
+                n_l = 1
+            lanes_rule = ('--lanes' if args.lanes is not None and str(want).isdigit() else
+                          'MYDET_LANES' if str(want).isdigit() else 'model.batch_lanes_hint')
+            n_l, lanes_per_rank = parallel.agree_on_lanes(n_l, device=dev)     # (all ranks computed the same rule: a check)
+            graphed = GraphedPath(model, x, conf, nms, lanes=n_l)
+        assert graphed.lanes == n_l
 
     def local_records(inp=None, pricing=False):
         if graphed is not None and inp is None:
@@ -230,7 +323,15 @@ def main():
         if graphed is not None and not pricing:
             return {k: v.clone() for k, v in graphed.eager(inp).items()}      # the replayed decomposition, host-issued
         with torch.no_grad():
-            bb, ci, sc = model.forward_candidates(x if inp is None else inp)
+            src = x if inp is None else inp
+            if pricing and graphed is not None and graphed.lanes > 1:
+                # the kernels the replayed graph runs (a lane sees batch / lanes images: other tile rules than the full
+                # batch), lane after lane on ONE stream so that their event times do not overlap
+                for part in src.tensor_split(graphed.lanes):
+                    bb, ci, sc = model.forward_candidates(part)
+                    out = batched_post_process(bb, ci, sc, conf, nms)
+                return out
+            bb, ci, sc = model.forward_candidates(src)
             return batched_post_process(bb, ci, sc, conf, nms)
 
     def step():
@@ -257,6 +358,41 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     timer, ops.TIMER = ops.TIMER, None
+
+    # launches of the step's kernels over the whole process: GraphedPath runs two eager warm-up passes before a capture
+    passes = (None if lanes_rule and lanes_rule.startswith('auto') else
+              (2 if graphed is not None else 0) + args.warmup + args.steps)
+    if args.profile:
+        # nothing else may launch: the profiler's per-kernel counts are then launches per step x `passes` (graph mode: two
+        # eager warm-up passes inside GraphedPath before the capture, which itself launches nothing)
+        if dist_on:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            elapsed = float(t.item())
+        if rank == 0:
+            print(json.dumps({'metric': f'images/sec at batch {batch}, {args.size}x{args.size}, {args.config} (profile run)',
+                              'value': round(total * args.steps / elapsed, 2), 'unit': 'images/sec', 'n_gpus': world,
+                              'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+                              'passes': passes, 'batch_lanes': graphed.lanes if graphed is not None else 1,
+                              'mode': 'hipGraph replay' if graphed is not None else 'eager',
+                              'note': 'profile run: every kernel of the step appears launches-per-step x passes times in the trace'}))
+        if dist_on:
+            torch.distributed.destroy_process_group()
+        return
+
+    # the parity check's GPU side: the candidates and records of the LAST TIMED STEP (first images of this rank's shard)
+    n_pc = min(args.cpu_sample_batch, batch)
+    with torch.no_grad():
+        if graphed is not None:
+            pc_cand = tuple(t[:n_pc].clone() for t in graphed.cand)
+            pc_rec = {k: rec[k][lo:lo + n_pc].clone() for k in ('count', 'index', 'class_idx')}
+        else:
+            cand_e = model.forward_candidates(x)
+            rec_e = batched_post_process(*cand_e, conf, nms)
+            pc_cand = tuple(t[:n_pc].clone() for t in cand_e)
+            pc_rec = {k: rec_e[k][:n_pc].clone() for k in ('count', 'index', 'class_idx')}
+            del cand_e, rec_e
+
     if timer is None:        # graph replay hides the launches from the event timer: price the kernels eagerly, after
         ops.TIMER = ops.KernelTimer()
         for _ in range(args.steps):
@@ -394,7 +530,8 @@ def main():
         'kernel_ms_per_step': round(kernel_ms, 3),
         'timer': ('HIP events on the launch stream; eager runs chain them (the event closing one launch opens the next), so '
                   'per-kernel times include inter-launch gaps and kernel_ms_per_step ~ ms_per_step by construction'
-                  if not args.graph else 'HIP events on the launch stream around each launch of an eager re-run after the replayed timed region'),
+                  if not args.graph else 'HIP events on the launch stream around each launch of an eager re-run after the replayed timed '
+                  'region (the same kernels: with batch lanes the lanes\' launch sequences one after the other on one stream)'),
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
@@ -404,6 +541,8 @@ def main():
                                'random-init calibrated weights' + (f', hipGraph replay ({graphed.lanes} batch lane{"s" if graphed.lanes > 1 else ""} per GPU)' if args.graph else ', eager launches'),
                    'global_batch': total, 'image_size': args.size, 'parallelism': f'dp{world}',
                    'batch_lanes': graphed.lanes if graphed is not None else 1,
+                   'batch_lanes_rule': lanes_rule, 'batch_lanes_per_rank': lanes_per_rank if graphed is not None else [1] * world,
+                   'passes': passes,
                    'exchange': f'one all-gather of {parallel.WORDS * 4} B detection records per image' if world > 1 else 'none'},
         'roofline': roofline,
         'stages': stages,
@@ -411,15 +550,21 @@ def main():
     }
     if verify is not None:
         out['verify'] = verify
+    oracle_cand = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(args.config, cfg, args.size, args.cpu_sample_batch, args.cpu_repeats, args.cpu_threads)
+        out['cpu_baseline'], oracle_cand = cpu_baseline(args.config, cfg, args.size, args.cpu_sample_batch, args.cpu_repeats, args.cpu_threads)
         out['cpu_baseline']['gpu_over_cpu'] = round(out['value'] / out['cpu_baseline']['value'], 1)
     if rank == 0:
+        # parity gate of this very measurement: the timed step's records against the oracle
+        extra_conf = sorted({0.05, float(cfg.get('test.default_conf_thres', 0.5))} - {float(conf)})
+        out['parity_check'] = parity_check(pc_cand, pc_rec, conf, nms, oracle_cand, images=n_pc, extra_conf=extra_conf)
         print(json.dumps(out))
     if dist_on:
         torch.distributed.destroy_process_group()
     if verify is not None and rank == 0 and not verify['ok']:
         sys.exit(3)
+    if rank == 0 and not out['parity_check']['ok']:
+        sys.exit(4)
 
 
 if __name__ == '__main__':

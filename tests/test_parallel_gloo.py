@@ -41,6 +41,11 @@ def _worker(rank, world, port, total, q):
         ok = False
     except ValueError:
         pass
+    # the lane count bench.py --gpus N replays with: rank 0's choice reaches every rank, whatever the others wished for
+    lanes, per_rank = parallel.agree_on_lanes(2 if rank == 0 else 1)
+    ok = ok and lanes == 2 and per_rank == [2] * world
+    lanes, per_rank = parallel.agree_on_lanes(1 if rank == 0 else None)
+    ok = ok and lanes == 1 and per_rank == [1] * world
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
@@ -87,3 +92,4 @@ def test_pack_unpack_roundtrip_and_sharding():
     sizes = [parallel.shard_range(10, r, 4) for r in range(4)]
     assert sizes == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert parallel.gather_detections(rec) is rec            # no process group: identity
+    assert parallel.agree_on_lanes(2) == (2, [2])
