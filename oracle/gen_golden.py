@@ -33,7 +33,7 @@ def gen_yolov3(batch=1, size=512, name='yolov3_b1_512', config='yolov3_80', seed
     only defined where that gap exceeds round-off) and, per threshold, `pp_<tag>_margin`: the largest eps for which
     oracle.postprocess.decision_margins finds no post-processing decision within eps of flipping (0 = exact score ties,
     broken by candidate index).  Thousands of long-tailed scores pass 0.005, so gaps at the top-512 cut are ~1e-6 at
-    best: `seed` is the image seed with the widest margin among the first ten (640: seed 1, u5m 256: seed 4 -- see
+    best: `seed` is the image seed with the widest margin among the first ten (512: seed 14 of seventy, 640: seed 1, u5m 256: seed 4 -- see
     DESIGN.md section 2), and the GPU tests demand exact decisions only when their own score error is inside it."""
     model, cfg = _refimport.build_reference_model(config)
     return _gen_yolov3(model, cfg, batch, size, name, seed, thresholds)
@@ -119,11 +119,11 @@ def _check_decision_margins(scores, cats, conf, what, eps=2e-5):
     assert why is None, f'{what}: {why}'
 
 
-def gen_efficientdet(config, size=256, batch=1):
+def gen_efficientdet(config, size=256, batch=1, seeds=16):
     """efficientdet-d1 / d1_fcs2_atss: stage samples, all candidates, post-processed detections.  The image seed is
     the first one whose decisions are all margin-safe (_check_decision_margins); the fixture records it."""
     model, cfg = _refimport.build_reference_model(config)
-    for seed in range(16):
+    for seed in range(seeds):
         try:
             return _gen_efficientdet(model, cfg, config, size, batch, seed)
         except AssertionError as e:
@@ -389,8 +389,14 @@ if __name__ == '__main__':
         gen_postprocess()
     if 'detlayers' in which:
         gen_detlayers()
-    if 'yolov3' in which:
-        gen_yolov3(1, 512, 'yolov3_b1_512')
+    if 'yolov3' in which:               # BASELINE configs[0] shape; seed 14: the widest post-processing margins (2e-6 at all
+                                        # three settings) of the first seventy image seeds ('yolov3_512_scan' lists them)
+        gen_yolov3(1, 512, 'yolov3_b1_512', seed=14)
+    if 'yolov3_512_scan' in which:      # prints the margins of the candidate seeds (writes scratch files only)
+        lo, hi = (int(v) for v in os.environ.get('SCAN_SEEDS', '0,10').split(','))
+        for sd in range(lo, hi):
+            gen_yolov3(1, 512, f'_scan_yolov3_b1_512_seed{sd}', seed=sd)
+            os.remove(os.path.join(OUT, f'_scan_yolov3_b1_512_seed{sd}.npz'))
     if 'yolov3_640' in which:           # BASELINE configs[1] resolution, pinned by the reference itself (batch 1)
         gen_yolov3(1, 640, 'yolov3_b1_640', seed=1)
     if 'ultralytics' in which:          # registry plug-ins 'ultralytics' backbone + FPN under the YOLO head
@@ -399,6 +405,9 @@ if __name__ == '__main__':
     if 'efficientdet' in which:
         gen_efficientdet('efficientdet-d1')
         gen_efficientdet('d1_fcs2_atss')
+    if 'efficientdet_640' in which:     # BASELINE configs[2] / [3] resolution, pinned by the reference itself (batch 1)
+        gen_efficientdet('efficientdet-d1', size=640, seeds=40)
+        gen_efficientdet('d1_fcs2_atss', size=640, seeds=40)
     if 'fcos_variants' in which:        # registry plug-ins 'FCOS2' and 'effrpn_ct' + 'FCOS' 
         gen_efficientdet('d1_fcs2')
         gen_efficientdet('d1_fcs')

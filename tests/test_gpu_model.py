@@ -72,6 +72,18 @@ def _check_yolo_golden(m, g, what):
     _class_ids_exact_where_safe(cats, g['cats_0'], g['cls_margin_0'], what)
     err = float(np.abs(scores - g['scores_0']).max())
     exact_tags = 0
+    # the post-process kernel on the REFERENCE's own candidates reproduces the reference's detections exactly at all three
+    # settings (count, classes, order, scores and boxes bit for bit): with the 1e-4 gate on every candidate above, this pins
+    # the detections to the reference without leaning on score gaps that are narrower than float32 round-off
+    from mydetection_amd.utils.structures import ImageObjects
+    ref_d = ImageObjects(torch.from_numpy(g['bboxes_0']).cuda(), torch.from_numpy(g['cats_0']).cuda(), None,
+                         torch.from_numpy(g['scores_0']).cuda(), d._bb_format, d.img_hw)
+    for tag in ('ap', 'mid', 'demo'):
+        if float(g[f'pp_{tag}_margin']) > 0.0:            # (exact score ties are broken by torch.topk's unspecified order)
+            rr = ref_d.post_process(float(g[f'pp_{tag}_conf']), float(g[f'pp_{tag}_nms']))
+            np.testing.assert_array_equal(rr.cats.cpu().numpy(), g[f'pp_{tag}_cats_0'], err_msg=f'{what} {tag}')
+            np.testing.assert_array_equal(rr.scores.cpu().numpy(), g[f'pp_{tag}_scores_0'], err_msg=f'{what} {tag}')
+            np.testing.assert_array_equal(rr.bboxes.cpu().numpy(), g[f'pp_{tag}_bboxes_0'], err_msg=f'{what} {tag}')
     for tag in ('ap', 'mid', 'demo'):
         conf, nms = float(g[f'pp_{tag}_conf']), float(g[f'pp_{tag}_nms'])
         r = d.post_process(conf, nms)
@@ -169,15 +181,18 @@ def test_ultralytics_plugins_vs_reference_golden(golden):
     m2 = m2.eval().cuda()
     with torch.no_grad():
         bb, ci, sc = m2.forward_candidates(x2.cuda())
-        outs = []
+        outs, gaps = [], []
         for lvl, r in enumerate(oy_head(ou.forward_features(x2, sd2), sd2)):
             t = r.permute(0, 2, 3, 1)
             outs.append(decoders.fcos_decode({'bbox': t[..., 0:4], 'conf': t[..., 4:5], 'class': t[..., 5:]}, (320, 256), (8, 16, 32)[lvl]))
+            top2 = torch.sigmoid(t[..., 5:]).reshape(t.shape[0], -1, t.shape[-1] - 5).topk(2, dim=-1).values
+            gaps.append(top2[..., 0] - top2[..., 1])
     ob, oc, os_ = (torch.cat([o[j] for o in outs], dim=1) for j in range(3))
     assert bb.shape == ob.shape
     np.testing.assert_allclose(sc.cpu().numpy(), os_.numpy(), rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(bb.cpu().numpy(), ob.numpy(), rtol=RTOL, atol=ATOL)
-    assert (ci.cpu() != oc).float().mean().item() < 1e-3
+    # class ids: exact wherever the oracle's own two largest class probabilities are further apart than round-off
+    _class_ids_exact_where_safe(ci.cpu().numpy(), oc.numpy(), torch.cat(gaps, dim=1).numpy(), 'u5m_fcs2')
 
 
 def oy_head(feats, sd):
@@ -272,9 +287,25 @@ def test_effdet_family_vs_reference_golden(effdet, golden):
     post_process) against the imported reference (batch 1, 256x256): north_star's gate -- boxes/scores within 1e-4
     (rtol and atol), class ids and detection counts exact -- at every stage, on every candidate and at all three
     post-process settings (each keeps hundreds of detections)."""
-    from mydetection_amd import synth
     name, m, cfg = effdet
-    g = golden(name.replace('-', '_') + '_b1_256')
+    _check_effdet_golden(name, m, golden(name.replace('-', '_') + '_b1_256'))
+
+
+def test_effdet_vs_reference_golden_640(effdet, golden):
+    """BASELINE configs[2] / [3] at the benchmark resolution (640 x 640, batch 1), pinned by the imported reference itself:
+    stage samples of trunk / first BiFPN layer / pyramid, head logits, all 76 725 / 8 525 candidates within 1e-4, class ids
+    exact where defined, detections (count, classes, order; scores / boxes 1e-4) at the three settings.  The fixture's
+    image seed is the first whose post-processing decisions are all 2e-5 clear of a boundary (oracle/gen_golden.py)."""
+    name, m, cfg = effdet
+    if name not in ('efficientdet-d1', 'd1_fcs2_atss'):
+        pytest.skip('640 x 640 reference fixtures exist for the two benchmark configurations')
+    g = golden(name.replace('-', '_') + '_b1_640')
+    assert g['bboxes_0'].shape[0] == (76725 if name == 'efficientdet-d1' else 8525)
+    _check_effdet_golden(name, m, g)
+
+
+def _check_effdet_golden(name, m, g):
+    from mydetection_amd import synth
     x = synth.make_normalized_images(int(g['batch']), int(g['size']), seed=int(g['image_seed'])).cuda()
     with torch.no_grad():
         c = m.backbone(x)
@@ -437,8 +468,14 @@ def test_effdet_full_size_properties_640(name, batch):
         np.testing.assert_allclose(bp.cpu().numpy(), bb[perm].cpu().numpy(), rtol=1e-5, atol=1e-5)
         assert (cp != ci[perm]).float().mean().item() < 1e-4
         for i in (0, batch - 1):
-            # solo run vs the same image inside the batch: two float32 evaluations whose small-grid layers are cut along K
-            # differently (and, at batch 1, take other tile shapes) -- 3e-5, a third of north_star's tolerance
+            # solo run vs the same image inside the batch: two float32 evaluations with different summation orders -- 3e-5, a
+            # third of north_star's tolerance.  Where they part (tools/solo_vs_batch.py, profiles/r04_solo_vs_batch.txt):
+            # blocks 0 and 1 agree bit for bit; the first difference (6.7e-6 absolute) is MBConv block 2's project conv
+            # 96->24 @160^2, which runs pw_skinny_kernel (k order permuted to the MFMA operand layout) once the launch has
+            # M = B*160^2 >= 65 536 rows and conv_igemm_kernel (k in order) for one image (M = 25 600); blocks 3-7 make the
+            # same switch, the small-grid layers of the 20^2 stages are cut along K in the batch-1 run only.  The
+            # difference stays at 0.7-1.3e-5 absolute through the trunk and BiFPN (no growth: the conditioned weights), and
+            # reaches the candidates as <= 2.3e-5 relative on the scores (measured: D1 image 15 of 16, FCOS image 31 of 32)
             b1, c1, s1 = m.forward_candidates(x[i:i + 1])
             np.testing.assert_allclose(s1[0].cpu().numpy(), sc[i].cpu().numpy(), rtol=3e-5, atol=1e-5)
             np.testing.assert_allclose(b1[0].cpu().numpy(), bb[i].cpu().numpy(), rtol=3e-5, atol=1e-5)

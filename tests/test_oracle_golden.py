@@ -163,12 +163,15 @@ def test_yolov3_640_and_ultralytics_match_reference(golden):
             np.testing.assert_array_equal(b, g[f'pp_{tag}_bboxes_0'])
 
 
-@pytest.mark.parametrize('config', ['efficientdet-d1', 'd1_fcs2_atss', 'd1_fcs2', 'd1_fcs', 'd1_yv3', 'd1_fcs2_p3'])
-def test_efficientdet_family_matches_reference(golden, config):
+@pytest.mark.parametrize('config,size', [('efficientdet-d1', 256), ('d1_fcs2_atss', 256), ('d1_fcs2', 256), ('d1_fcs', 256),
+                                         ('d1_yv3', 256), ('d1_fcs2_p3', 256),
+                                         ('efficientdet-d1', 640), ('d1_fcs2_atss', 640)])     # 640: BASELINE configs[2] / [3]
+def test_efficientdet_family_matches_reference(golden, config, size):
     """Oracle restatement of EfficientNet-B1 + BiFPN + EfDetHead + decode vs the imported reference."""
     from mydetection_amd.models.general import state_dict_template
     from oracle import efficientdet as oe
-    g = golden(config.replace('-', '_') + '_b1_256')
+    g = golden(config.replace('-', '_') + f'_b1_{size}')
+    assert int(g['size']) == size
     sd = synth.make_state_dict(state_dict_template(config), config)
     x = synth.make_normalized_images(int(g['batch']), int(g['size']), seed=int(g['image_seed']))
     torch.set_num_threads(8)
