@@ -6,7 +6,7 @@
 
 Counters are in KB.  MI355X_MICROARCH.md (HBM / rocprofv3): on gfx950 FETCH_SIZE reports half the bytes of a wide
 coalesced streaming read (16 B per lane), so it is doubled for the kernel families whose global loads are 16 B per lane;
-families that load dwords (the Winograd kernel's activation patches, raw_buffer_load_b32) are outside the calibrated
+families that load dwords (the F(2x2) Winograd kernel's activation patches, raw_buffer_load_b32) are outside the calibrated
 case and are reported with both factors.  WRITE_SIZE is exact for 16-byte-per-lane stores.
 Kernels are grouped into the families bench.py names.
 """
@@ -17,7 +17,7 @@ import sys
 from collections import defaultdict
 
 # (substring of the kernel name, family, FETCH_SIZE correction or None = uncalibrated: report x1 and x2)
-FAMILIES = [('conv_wino4_kernel', 'conv_wino4_gemm', 2.0), ('wino4_input_kernel', 'wino4_input', None), ('wino4_weights', None, None),
+FAMILIES = [('conv_wino4_kernel', 'conv_wino4_gemm', 2.0), ('wino4_input_kernel', 'wino4_input', 2.0), ('wino4_weights', None, None),
             ('conv_wino_kernel', 'conv_wino', None), ('conv_igemm_kernel', 'conv_igemm', 2.0), ('conv_fixup', 'conv_igemm_fixup', 2.0),
             ('conv_stem', 'conv_stem', None), ('stem_dw', 'stem_dw', None), ('upsample_concat', 'upsample_concat', 2.0), ('decode_kernel', 'decode', 2.0),
             ('postprocess', 'postprocess', None), ('dwconv', 'dwconv', 2.0), ('sepconv_decode', 'sepconv_decode', 2.0),
@@ -62,11 +62,9 @@ for fam in fetch:
 # bench.py times the F(4x4) Winograd layer as one unit (input-transform launch + GEMM launch): the same unit here.  The GEMM
 # kernel's loads are all 16-byte DMA (x2 correction); the input kernel's patch loads are dwords (x1 .. x2)
 if 'conv_wino4_gemm' in out and 'wino4_input' in out:
-    g, t = out['conv_wino4_gemm'], out['wino4_input']
+    g, t = out['conv_wino4_gemm'], out['wino4_input']      # (round 4: the input kernel loads 16 bytes per lane too: x2)
     out['conv_wino4'] = {'launches': g['launches'], 'unit': 'wino4_input_kernel + conv_wino4_kernel',
-                         'hbm_read_bytes_per_launch': g['hbm_read_bytes_per_launch'] + t['hbm_read_bytes_per_launch_x1'],
-                         'hbm_read_bytes_per_launch_upper': g['hbm_read_bytes_per_launch'] + t['hbm_read_bytes_per_launch_x2'],
+                         'hbm_read_bytes_per_launch': g['hbm_read_bytes_per_launch'] + t['hbm_read_bytes_per_launch'],
                          'hbm_write_bytes_per_launch': g['hbm_write_bytes_per_launch'] + t['hbm_write_bytes_per_launch'],
-                         'hbm_bytes_per_launch': g['hbm_bytes_per_launch'] + t['hbm_bytes_per_launch'],
-                         'hbm_bytes_per_launch_upper': g['hbm_bytes_per_launch'] + t['hbm_bytes_per_launch_upper']}
+                         'hbm_bytes_per_launch': g['hbm_bytes_per_launch'] + t['hbm_bytes_per_launch']}
 print(json.dumps(out, indent=1))
