@@ -306,11 +306,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fixup_kernel(const ConvArgs
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                f32x4 t = src[((i * TN + j) * 4 + v) * NT];
-                for (int sp = 1; sp < p.splits; ++sp) {
-                    const f32x4 o = src[((int64_t)sp * NV4 + (i * TN + j) * 4 + v) * NT];
-                    t[0] += o[0]; t[1] += o[1]; t[2] += o[2]; t[3] += o[3];
-                }
+                // all slices requested before the first add (splits <= 16: one round trip instead of one per slice),
+                // summed in slice order
+                f32x4 o[16];
+#pragma unroll
+                for (int sp = 0; sp < 16; ++sp)
+                    if (sp < p.splits) o[sp] = src[((int64_t)sp * NV4 + (i * TN + j) * 4 + v) * NT];
+                f32x4 t = o[0];
+#pragma unroll
+                for (int sp = 1; sp < 16; ++sp)
+                    if (sp < p.splits) { t[0] += o[sp][0]; t[1] += o[sp][1]; t[2] += o[sp][2]; t[3] += o[sp][3]; }
                 acc[i][j][4 * v] = t[0]; acc[i][j][4 * v + 1] = t[1]; acc[i][j][4 * v + 2] = t[2]; acc[i][j][4 * v + 3] = t[3];
             }
     const int m_base = m0 + wm * TM * 32, n_base = n0 + wn * TN * 32;

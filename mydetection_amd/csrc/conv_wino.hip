@@ -72,7 +72,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // lane are in flight before its first store.
 template <int ACT, bool RES>
 __device__ __forceinline__ void wino_epilogue(const WinoArgs &p, const f32x4 (&out)[2][4], int m0, int n0, int b0,
-                                              int wc, int wt, int fr, int fq) {
+                                              int wc, int wt, int fr, int fq, int only = -1) {   // only >= 0: just out[only >> 2][only & 3]
     const int tpi = p.TH * p.TW;
     const int n = n0 + wc * 16 + fq * 4;
     const bool nok = n < p.Cout;                       // Cout % 4 == 0: the four channels stand or fall together
@@ -96,7 +96,7 @@ __device__ __forceinline__ void wino_epilogue(const WinoArgs &p, const f32x4 (&o
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
             const int a = o >> 1, c = o & 1;
-            const bool ok = tok && oy + a < p.H && ox + c < p.W;
+            const bool ok = tok && oy + a < p.H && ox + c < p.W && (only < 0 || only == blk * 4 + o);
             const int64_t px = pix + (int64_t)a * p.W + c;
             yo[blk][o] = ok ? (unsigned)((px * p.ldy + n) * 4) : OOB;
             if (RES)
@@ -345,28 +345,45 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_wino_kernel(con
 }
 
 // Items whose K range was cut by the stream-K schedule: sum the pieces in K order, then the usual epilogue.
-// One workgroup per schedule boundary; the first boundary inside an item owns it, the others exit.
+// blockIdx.x = item of the stream-K tail (an item that one workgroup summed whole returns at once).
 template <int ACT, bool RES, int NW>
 __global__ __launch_bounds__(64 * NW) void conv_wino_fixup_kernel(const WinoArgs p) {
     constexpr int TILES = 8 * NW, NT = 64 * NW;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int w = blockIdx.x + 1;                      // boundary between workgroups w-1 and w
     const int nk = p.nk;
     const int tail0 = (p.nblk / p.nwg) * p.nwg;        // the stream-K tail starts after the whole rounds
     const int64_t total = (int64_t)(p.nblk - tail0) * nk;
-    const int64_t cut = sk_begin(w, total, p.nwg);
-    const int item = tail0 + (int)(cut / nk);
-    const int64_t first = (cut / nk) * nk;
-    if (cut == first || sk_begin(w - 1, total, p.nwg) > first) return;   // no cut here / not the first cut of the item
-    const f32x4 *ws = reinterpret_cast<const f32x4 *>(p.ws) + tid;
+    const int item = tail0 + (int)blockIdx.x;
+    const int64_t first = (int64_t)blockIdx.x * nk;    // the item's slab iterations: [first, first + nk)
+    // the first share boundary inside the item: smallest w with floor(w * total / nwg) > first
+    const int w = (int)(((first + 1) * p.nwg + total - 1) / total);
+    if (w >= p.nwg || sk_begin(w, total, p.nwg) >= first + nk) return;    // not cut
+    // blockIdx.y = which of the thread's eight output float4 (2 tile blocks x 2 x 2 pixels) this workgroup sums: a cut item
+    // is 17 pieces of 64 KB at batch 1, and ONE workgroup pulling them through one CU took 17 us (the CU's intake, not
+    // the loads' latency); eight workgroups per item take 1/8 each
+    const int j = blockIdx.y;
+    const f32x4 *ws = reinterpret_cast<const f32x4 *>(p.ws) + tid + (int64_t)j * NT;
+    f32x4 sum = ws[(int64_t)(2 * (w - 1) + 1) * 8 * NT];                                               // starts the item
+    // later pieces: counted first, then fetched eight at a time (independent loads in flight) and added in K order
+    // first workgroup whose share begins at or beyond the item's end: floor(v * total / nwg) >= X  <=>  v >= X * nwg / total
+    // (one 64-bit division instead of one per piece)
+    const int64_t xe = (first + nk) * p.nwg;
+    int last = (int)((xe + total - 1) / total);
+    if (last > p.nwg) last = p.nwg;
+    for (int v0 = w; v0 < last; v0 += 8) {
+        f32x4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (v0 + u < last) t[u] = ws[(int64_t)(2 * (v0 + u)) * 8 * NT];                            // uniform
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (v0 + u < last) sum += t[u];
+    }
     f32x4 out[2][4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) out[j >> 2][j & 3] = ws[((int64_t)(2 * (w - 1) + 1) * 8 + j) * NT];   // starts the item
-    for (int v = w; v < p.nwg && sk_begin(v, total, p.nwg) < first + nk; ++v)                           // later pieces
-#pragma unroll
-        for (int j = 0; j < 8; ++j) out[j >> 2][j & 3] += ws[((int64_t)(2 * v) * 8 + j) * NT];
+    for (int jj = 0; jj < 8; ++jj) out[jj >> 2][jj & 3] = sum;       // only component j is stored
     const int m0 = (item / p.ntn) * TILES, n0 = (item % p.ntn) * CH;
-    wino_epilogue<ACT, RES>(p, out, m0, n0, m0 / (p.TH * p.TW), wave & 3, wave >> 2, lane & 15, lane >> 4);
+    wino_epilogue<ACT, RES>(p, out, m0, n0, m0 / (p.TH * p.TW), wave & 3, wave >> 2, lane & 15, lane >> 4, j);
 }
 
 // U = G g Gt in float64, rounded once; layout [Cin/8][8 position pairs][4 k quarters][CoutP][4] with the float4 =
@@ -436,7 +453,9 @@ int launch_nw(WinoArgs a, hipStream_t stream) {
         hipLaunchKernelGGL((conv_wino_kernel<ACT, RES, NW, true>), dim3(nwg), dim3(NT), LDS, stream, a);
         int rc = mydet_launch_status();
         if (rc || nwg < 2) return rc;
-        hipLaunchKernelGGL((conv_wino_fixup_kernel<ACT, RES, NW>), dim3(nwg - 1), dim3(NT), 0, stream, a);
+        const int tail_items = a.nblk - (a.nblk / nwg) * nwg;
+        if (tail_items == 0) return rc;
+        hipLaunchKernelGGL((conv_wino_fixup_kernel<ACT, RES, NW>), dim3(tail_items, 8), dim3(NT), 0, stream, a);
         return mydet_launch_status();
     }
     a.nwg = 0;
