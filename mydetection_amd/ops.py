@@ -190,10 +190,12 @@ def wino_weights(w_ohwi):
 
 
 # F(4x4,3x3) for the 3x3 layers with Cin >= WINO4_MIN_CIN whose grid fills the chip (>= WINO4_MIN_ITEMS workgroups of
-# 32 tiles x 32 channels; smaller grids stay on F(2x2,3x3), which cuts them along K); MYDET_CONV_WINO4=0 turns it off
+# 32 tiles x 32 channels; smaller grids stay on F(2x2,3x3), which cuts them along K); MYDET_CONV_WINO4=0 turns it off.
+# 512 = one full round of the resident workgroups (round 4; 768 before): the 16^2 layers of batch 32 at 512^2 are exactly
+# that (2 134 -> 2 289 images/s), the FCOS head's dense 3x3 at 80^2 in a 16-image lane has 600 (+0.5 %)
 WINOGRAD4 = os.environ.get('MYDET_CONV_WINO4', '1') != '0'
 WINO4_MIN_CIN = int(os.environ.get('MYDET_WINO4_MIN_CIN', '64'))
-WINO4_MIN_ITEMS = int(os.environ.get('MYDET_WINO4_MIN_ITEMS', '768'))
+WINO4_MIN_ITEMS = int(os.environ.get('MYDET_WINO4_MIN_ITEMS', '512'))
 
 
 def wino4_items(B, H, W, Cout):
