@@ -517,7 +517,9 @@ extern "C" int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *
     // (tools/sweep_pointwise.py: 79 -> 73 us, 35.7 -> 32.9 us at batch 16; under 4 800 rows -- batch 8 at 20^2 -- the
     // 64 x 64 tiles are ahead again: 320->1920 47 -> 44 us)
     if (KH * KW == 1 && K <= 512 && Cout >= 1024 && (M64 >= 4800 || K <= 256)) return launch_cfg(8, a, s);
-    if (Cout <= 64) return launch_cfg(KH * KW > 1 ? 6 : 1, a, s);
+    // (1x1 with 33..64 outputs behind a long K -- YOLOv3's 128->64 @160^2 -- also does better with BK = 16 and five workgroups
+    // per CU: 0.172 -> 0.156 ms in the model, round 4)
+    if (Cout <= 64) return launch_cfg(KH * KW > 1 || K >= 96 ? 6 : 1, a, s);
     // (3x3 layers with K >= 512 and a big grid already prefer the 8-wave tile: 64->128 stride 2 @320^2 +7 %)
     if ((K <= 1024 && !(KH * KW > 1 && K >= 512)) || blocks128 < 1024) return launch_cfg(3, a, s);
     return launch_cfg(8, a, s);
