@@ -51,6 +51,12 @@ struct W4Args {
     int B, H, W, Cin, Cout, CoutP;
     int TH, TW, MT, ntn, nblk;
     int nmb, nbn, rn_log2;                             // item order of the GEMM kernel (see there)
+#ifdef MYDET_DIAG
+    // diagnostic build only (`make EXTRA=-DMYDET_DIAG`, tools/r04_clock.py; the results of such a build are NOT valid):
+    // MYDET_W4_DBG & 7 = 1 every stage reads the same 36 KB, 2 no DMA after stage 1, 3 U always stage 0; & 8 = stamp the K
+    // loop of every workgroup (s_memtime / s_memrealtime) into the consumed V workspace
+    int dbg;
+#endif
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -184,11 +190,21 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino4_kernel(const W4Args p) 
     const __amdgpu_buffer_rsrc_t ur = rsrc(p.u, (int64_t)p.Cin * 36 * p.CoutP * 4);
     const unsigned urun = (unsigned)p.CoutP * 16u;
     const unsigned uoff = (unsigned)((n0 + (lane & 31)) * 16) + (lane >> 5) * urun;
+#ifdef MYDET_DIAG
+    const int dmode = p.dbg & 7;
+    const __amdgpu_buffer_rsrc_t vr = rsrc(p.v + (int64_t)(dmode == 1 ? 0 : mb) * nk * (V_BYTES / 4), (int64_t)nk * V_BYTES);
+#else
     const __amdgpu_buffer_rsrc_t vr = rsrc(p.v + (int64_t)mb * nk * (V_BYTES / 4), (int64_t)nk * V_BYTES);
+#endif
     const unsigned voff = (unsigned)(lane * 16);
     auto load_stage = [&](int kt) __attribute__((always_inline)) {
         char *dst = smem + (kt & 1) * STAGE;
+#ifdef MYDET_DIAG
+        if (dmode == 2 && kt > 1) return;
+        const unsigned su = dmode == 1 || dmode == 3 ? 0u : (unsigned)kt * 36u * urun, sv = dmode == 1 ? 0u : (unsigned)kt * V_BYTES;
+#else
         const unsigned su = (unsigned)kt * 36u * urun, sv = (unsigned)kt * V_BYTES;
+#endif
 #pragma unroll
         for (int j = 0; j < (UP + 18 + NW - 1) / NW; ++j) {
             const int i = wave + NW * j;               // index in [U pieces | V pieces]
@@ -236,6 +252,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino4_kernel(const W4Args p) 
     load_stage(0);
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): the DMA'd stage has landed
     __syncthreads();
+#ifdef MYDET_DIAG
+    const uint64_t dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) load_stage(kt + 1);           // its buffer was last read before the previous barrier
         if (RES && kt == nk - 1) {
@@ -270,6 +289,13 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino4_kernel(const W4Args p) 
         __syncthreads();
     }
 
+#ifdef MYDET_DIAG
+    if ((p.dbg & 8) && tid == 0) {                     // shader cycles / 100 MHz ticks of the K loop, per workgroup
+        int *d = reinterpret_cast<int *>(p.v) + ((int64_t)mb * nk) * (V_BYTES / 4) + nb * 4;
+        d[0] = (int)(__builtin_amdgcn_s_memtime() - dbg_t0);
+        d[1] = (int)(__builtin_amdgcn_s_memrealtime() - dbg_r0);
+    }
+#endif
     // ---- epilogue: output transform Y = At M A in place on the accumulators: the column pass leaves
     // s[a][m] = sum_i At[a][i] M[i][m] in acc[6a + m], the row pass takes out[c] = sum_m s[a][m] At[c][m]
     const int nc = nok ? n : 0;
@@ -393,6 +419,9 @@ extern "C" int mydet_conv2d_wino4_f32(const float *x, int64_t ldx, const float *
     const int64_t ldmax = ldx > ldy ? (ldx > a.ldr ? ldx : a.ldr) : (ldy > a.ldr ? ldy : a.ldr);
     if ((int64_t)H * W * ldmax * 4 * span >= 0x7FFFFFF0ll || (int64_t)36 * Cin * a.CoutP * 4 >= 0x7FFFFFF0ll) return MYDET_E_UNSUPP;
     a.MT = (int)MT;
+#ifdef MYDET_DIAG
+    { const char *e = getenv("MYDET_W4_DBG"); a.dbg = e && *e ? atoi(e) : 0; }
+#endif
     a.ntn = (Cout + CH - 1) / CH;
     a.nmb = (int)((MT + TILES - 1) / TILES);
     a.rn_log2 = 0;

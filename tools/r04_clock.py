@@ -1,5 +1,9 @@
-"""In-kernel clock of the F(4x4) GEMM launch's main loop (diagnostic: MYDET_W4_DBG=5 normal loads, 6 no DMA after stage 1).
-The stamped build writes (delta s_memtime, delta s_memrealtime) per workgroup into the consumed V workspace."""
+"""In-kernel clock and K-loop cycles of the F(4x4) GEMM launch, per workgroup.  Needs the DIAGNOSTIC build of the library:
+    make -C mydetection_amd/csrc clean all EXTRA=-DMYDET_DIAG        (rebuild without EXTRA afterwards: its results are not valid)
+    MYDET_W4_DBG=8 python tools/r04_clock.py <Cin> <Cout> <H=W> <batch>      8 = stamps; + 1 every stage the same 36 KB,
+                                                                            + 2 no DMA after stage 1, + 3 U always stage 0
+The stamped build writes (delta s_memtime, delta s_memrealtime) per workgroup into the consumed V workspace.
+Round-4 results: profiles/r04_experiments/exp5.txt, exp6.txt; profiles/HISTORY.md."""
 import os, sys, time
 import numpy as np
 import torch
