@@ -153,6 +153,19 @@ int mydet_upsample_concat_f32(const float *a, int64_t lda, int Ha, int Wa, int C
                               const float *b, int64_t ldb, int C2,
                               float *y, int64_t ldy, int B, int Ho, int Wo, void *stream);
 
+/* The same concatenation consumed on the fly by the 1x1 ConvBnLeaky that follows it in YOLOBranch.forward
+ * (models/fpns.py:62-66: `x = cat((upsample(pre), x), 1); x = self.cbl_0(x)`):
+ *   y = LeakyReLU_0.1((conv1x1(cat((up2x_nearest(x_lo), x_hi), 1)) * scale + shift)
+ * x_lo [B,H/2,W/2,ld_lo] (C_lo channels), x_hi [B,H,W,ld_hi] (C_hi channels), w [Cout][C_lo + C_hi] (OHWI, the
+ * concatenation's channel order), y [B,H,W,ldy].  The concatenated tensor is never written; the sums run in the same k
+ * order and tile shape as mydet_conv2d_igemm_f32 on the materialised tensor: bit-identical results.
+ * workspace: as for mydet_conv2d_igemm_f32.  Needs H, W even, C_lo % 32 == 0, C_hi % 32 == 0, act == MYDET_ACT_LEAKY;
+ * otherwise MYDET_E_UNSUPP and the caller uses mydet_upsample_concat_f32 + mydet_conv2d_igemm_f32. */
+int mydet_conv1x1_upcat_f32(const float *x_lo, int64_t ld_lo, int C_lo, const float *x_hi, int64_t ld_hi, int C_hi,
+                            const float *w, const float *scale, const float *shift, void *workspace,
+                            int64_t workspace_bytes, float *y, int64_t ldy, int B, int H, int W, int Cout, int act,
+                            void *stream);
+
 /* Focus.forward of the Ultralytics backbone (external/ultralytics/common.py:79-86): 2x2 space-to-depth,
  *   y[b, yo, xo, g*C + c] = x[b, c, 2*yo + dy, 2*xo + dx],  g = 0:(dy 0, dx 0) 1:(dy 1, dx 0) 2:(dy 0, dx 1) 3:(dy 1, dx 1)
  * -- the channel order of torch.cat([x[..., ::2, ::2], x[..., 1::2, ::2], x[..., ::2, 1::2], x[..., 1::2, 1::2]], 1).

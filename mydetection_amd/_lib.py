@@ -35,6 +35,8 @@ SIGNATURES = {
     'mydet_conv2d_stem_f32': [c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64] + [c_int] * 10 + [c_ptr],
     'mydet_upsample_concat_f32': [c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_int,
                                   c_int, c_ptr],
+    'mydet_conv1x1_upcat_f32': [c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64]
+    + [c_int] * 5 + [c_ptr],
     'mydet_space_to_depth_f32': [c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr],
     'mydet_spp_concat_f32': [c_ptr, c_i64, c_ptr, c_i64] + [c_int] * 7 + [c_ptr],
     'mydet_decode_levels_f32': [c_int, c_int, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

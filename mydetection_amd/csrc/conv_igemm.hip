@@ -40,6 +40,11 @@ struct ConvArgs {
     int tile0, splits;        // split-K tail: first logical tile of this launch, K slices per tile (1 = whole K)
     float *ws;                // split-K partial accumulators
     size_t ws_bytes;
+    // CAT (1x1 only): channels [0, C1) of A come from x1 = a [B, H/2, W/2, ldx1] map read through nearest 2x upsampling, the
+    // remaining Cin - C1 from x -- conv1x1(cat((up2x(x1), x), 1)) without the concatenated tensor
+    const float *x1;
+    int64_t ldx1;
+    int C1;
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -103,7 +108,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs &p, f32x16 (&acc)[TM][TN
     }
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool CIN32, int ACT, bool RES, bool GATE, bool SPLIT = false>
+template <int BM, int BN, int WM, int WN, int BK, bool CIN32, int ACT, bool RES, bool GATE, bool SPLIT = false, bool CAT = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs p) {
     constexpr int NT = WM * WN * 64;                // threads: one wave per (wm, wn)
     constexpr int LDS_LD = BK + 4;                 // padded LDS row (floats)
@@ -128,6 +133,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     const int64_t img = (int64_t)p.H * p.W * p.ldx;
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x + b0 * img, (p.B - b0) * img * 4);
     const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, (int64_t)p.Cout * p.K * 4);
+    const int64_t img1 = (int64_t)(p.H >> 1) * (p.W >> 1) * p.ldx1;      // CAT: the half-resolution source
+    const __amdgpu_buffer_rsrc_t xr1 = make_rsrc(CAT ? p.x1 + b0 * img1 : p.w, CAT ? (p.B - b0) * img1 * 4 : 16);
     // SE gate (1x1 convs only): A[m][k] is multiplied by gate[image(m)][k] while it is staged
     const __amdgpu_buffer_rsrc_t gr = make_rsrc(GATE ? p.gate : p.w, (int64_t)p.B * p.Cin * 4);
 
@@ -137,6 +144,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     int aoff[AI];                                   // byte offset of tap (0,0), channel 4*sc, from the window base
     unsigned amask[AI];                             // bit t: tap t of this row is inside the image
     unsigned gbase[AI];                             // GATE: byte offset of the row's image in gate[B][Cin]
+    unsigned aoff1[AI];                             // CAT: byte offset of the row's pixel (oh / 2, ow / 2) in x1, channel 4*sc
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
         const int m = m0 + sr + RP * i;
@@ -152,6 +160,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
         }
         amask[i] = m < p.M ? mask : 0u;
         if (GATE) gbase[i] = (unsigned)(b * p.Cin) * 4u;
+        if (CAT) aoff1[i] = (unsigned)((((int64_t)(b - b0) * (p.H >> 1) + (oh >> 1)) * (p.W >> 1) + (ow >> 1)) * p.ldx1 + sc * 4) * 4u;
     }
     unsigned boff[BI];
 #pragma unroll
@@ -180,11 +189,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
 
     auto load_slab = [&](int kt) {
         if (CIN32) {
-            const unsigned uoff = (unsigned)(tapoff + c0 * 4);
+            const bool lo = CAT && c0 < p.C1;              // uniform: this slab's channels come from the upsampled map
+            const unsigned uoff = (unsigned)(tapoff + (c0 - (CAT ? p.C1 : 0)) * 4);
 #pragma unroll
             for (int i = 0; i < AI; ++i) {
                 const bool ok = (amask[i] >> tap) & 1u;
-                areg[i] = buf_load16(xr, ok ? (unsigned)aoff[i] + uoff : OOB);
+                if (lo) areg[i] = buf_load16(xr1, ok ? aoff1[i] + (unsigned)(c0 * 4) : OOB);
+                else areg[i] = buf_load16(xr, ok ? (unsigned)aoff[i] + uoff : OOB);
                 if (GATE) areg[i] *= buf_load16(gr, gbase[i] + (unsigned)(c0 + sc * 4) * 4u);
             }
             c0 += BK;
@@ -325,9 +336,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fixup_kernel(const ConvArgs
         epilogue<ACT, RES, false, TM, TN>(p, acc, m_base, n_base, fr, fh);
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool CIN32, int ACT, bool RES, bool GATE = false, bool SPLIT = false>
+template <int BM, int BN, int WM, int WN, int BK, bool CIN32, int ACT, bool RES, bool GATE = false, bool SPLIT = false, bool CAT = false>
 int launch_inst(const ConvArgs &a, size_t lds, hipStream_t stream) {
-    auto kern = &conv_igemm_kernel<BM, BN, WM, WN, BK, CIN32, ACT, RES, GATE, SPLIT>;
+    auto kern = &conv_igemm_kernel<BM, BN, WM, WN, BK, CIN32, ACT, RES, GATE, SPLIT, CAT>;
     static unsigned long long attr_set = 0;                  // > 64 KiB of dynamic LDS needs the opt-in once per device
     if (mydet_first_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -408,6 +419,15 @@ int launch(const ConvArgs &a0, int slots, hipStream_t stream) {
     a.tile0 = 0; a.splits = 1;
     a.nblk = split ? total - rem : total;
     int rc = 0;
+    if (a.x1) {         // upsample + concat read on the fly: instantiated for the YOLOv3 pyramid's use (64 x 64 tile, LeakyReLU)
+        if (!(BM == 64 && BN == 64 && BK == 32) || !cin || a.act != MYDET_ACT_LEAKY || a.res || a.gate) return MYDET_E_UNSUPP;
+        if (a.nblk > 0) rc = launch_inst<64, 64, 2, 2, 32, true, MYDET_ACT_LEAKY, false, false, false, true>(a, lds, stream);
+        if (rc || !split) return rc;
+        a.tile0 = total - rem; a.splits = splits; a.nblk = rem * splits;
+        rc = launch_inst<64, 64, 2, 2, 32, true, MYDET_ACT_NONE, false, false, true, true>(a, lds, stream);
+        if (rc) return rc;
+        return launch_fixup_act<BM, BN, WM, WN>(a, rem, stream);
+    }
     if (a.nblk > 0)
         rc = cin ? launch_act<BM, BN, WM, WN, BK, true>(a, lds, stream) : launch_act<BM, BN, WM, WN, BK, false>(a, lds, stream);
     if (rc || !split) return rc;
@@ -488,6 +508,7 @@ extern "C" int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *
     a.pad_t = pad_t; a.pad_l = pad_l; a.Ho = Ho; a.Wo = Wo; a.act = act;
     a.M = (int)M64; a.K = KH * KW * Cin; a.ntiles = 0; a.nblk = 0;
     a.tile0 = 0; a.splits = 1;
+    a.x1 = nullptr; a.ldx1 = 0; a.C1 = 0;
     a.ws = ((uintptr_t)workspace & 15) ? nullptr : (float *)workspace;
     a.ws_bytes = workspace_bytes > 0 ? (size_t)workspace_bytes : 0;
     hipStream_t s = (hipStream_t)stream;
@@ -523,4 +544,34 @@ extern "C" int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *
     // (3x3 layers with K >= 512 and a big grid already prefer the 8-wave tile: 64->128 stride 2 @320^2 +7 %)
     if ((K <= 1024 && !(KH * KW > 1 && K >= 512)) || blocks128 < 1024) return launch_cfg(3, a, s);
     return launch_cfg(8, a, s);
+}
+
+extern "C" int mydet_conv1x1_upcat_f32(const float *x_lo, int64_t ld_lo, int C_lo, const float *x_hi, int64_t ld_hi, int C_hi,
+                                       const float *w, const float *scale, const float *shift, void *workspace,
+                                       int64_t workspace_bytes, float *y, int64_t ldy, int B, int H, int W, int Cout, int act,
+                                       void *stream) {
+    if (!x_lo || !x_hi || !w || !y || B <= 0 || H <= 0 || W <= 0 || C_lo <= 0 || C_hi <= 0 || Cout <= 0) return MYDET_E_BADARG;
+    if ((ld_lo & 3) || (ld_hi & 3) || ld_lo < C_lo || ld_hi < C_hi || ldy < Cout || (ldy & 3)) return MYDET_E_BADARG;
+    if (((uintptr_t)x_lo & 15) || ((uintptr_t)x_hi & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15) ||
+        (scale && ((uintptr_t)scale & 15)) || (shift && ((uintptr_t)shift & 15)))
+        return MYDET_E_BADARG;
+    if ((H & 1) || (W & 1) || (C_lo & 31) || (C_hi & 31) || act != MYDET_ACT_LEAKY) return MYDET_E_UNSUPP;
+    const int64_t M64 = (int64_t)B * H * W;
+    const int Cin = C_lo + C_hi;
+    if (M64 > (int64_t)1 << 30 || M64 * ldy * 4 >= 0x7FFFFFF0ll) return MYDET_E_UNSUPP;
+    const int64_t span_imgs = 256 / ((int64_t)H * W) + 2;
+    if ((int64_t)H * W * ld_hi * 4 * span_imgs >= 0x7FFFFFF0ll || (int64_t)(H >> 1) * (W >> 1) * ld_lo * 4 * span_imgs >= 0x7FFFFFF0ll ||
+        (int64_t)Cout * Cin * 4 >= 0x7FFFFFF0ll)
+        return MYDET_E_UNSUPP;
+    ConvArgs a;
+    a.x = x_hi; a.w = w; a.scale = scale; a.shift = shift; a.res = nullptr; a.gate = nullptr; a.y = y;
+    a.ldx = ld_hi; a.ldr = 0; a.ldy = ldy;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = 1; a.KW = 1; a.stride = 1;
+    a.pad_t = 0; a.pad_l = 0; a.Ho = H; a.Wo = W; a.act = act;
+    a.M = (int)M64; a.K = Cin; a.ntiles = 0; a.nblk = 0;
+    a.tile0 = 0; a.splits = 1;
+    a.x1 = x_lo; a.ldx1 = ld_lo; a.C1 = C_lo;
+    a.ws = ((uintptr_t)workspace & 15) ? nullptr : (float *)workspace;
+    a.ws_bytes = workspace_bytes > 0 ? (size_t)workspace_bytes : 0;
+    return launch_cfg(3, a, (hipStream_t)stream);          // the tile the 1x1 layers of this shape take anyway (same k order)
 }

@@ -51,8 +51,13 @@ class YOLOBranch(nn.Module):
     def forward(self, x, previous=None):
         if previous is not None:
             pre = self.process(previous)
-            x = ops.upsample_concat(pre, tuple(x.shape[2:4]), x)      # cat((pre, x), dim=1)
-        x = self.cbl_0(x)
+            y = self.cbl_0.forward_upcat(pre, x)                      # cbl_0(cat((up2x(pre), x), 1)) in one launch ...
+            if y is None:                                             # ... or, for shapes that launch does not cover, in two
+                x = ops.upsample_concat(pre, tuple(x.shape[2:4]), x)  # cat((pre, x), dim=1)
+                y = self.cbl_0(x)
+            x = y
+        else:
+            x = self.cbl_0(x)
         x = self.cbl_1(x)
         x = self.cbl_2(x)
         x = self.cbl_3(x)

@@ -94,6 +94,17 @@ class ConvBnLeaky(nn.Module, FusedConvMixin):
         return ops.conv2d(x, w, scale, shift, self.k, self.s, (p, p, p, p), ops.ACT_LEAKY, residual=residual, wino=u, wino4=u4)
 
 
+    def forward_upcat(self, lo, hi):
+        """self(cat((nearest_2x(lo), hi), 1)) without the concatenated tensor (1x1 layers; reference: models/fpns.py:62-66);
+        None when the fused launch does not cover the shape."""
+        if self.training:
+            raise NotImplementedError('mydetection_amd implements the inference path only; call model.eval()')
+        if self.k != 1 or self.s != 1:
+            return None
+        w, scale, shift = self._prepared(self.conv, self.bn)
+        return ops.conv1x1_upcat(lo, hi, w, scale, shift, ops.ACT_LEAKY)
+
+
 class DarkBlock(nn.Module):
     '''
     Residual block in Darknet53: x + cbl_1(cbl_0(x)); the add rides in cbl_1's epilogue

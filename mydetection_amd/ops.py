@@ -639,6 +639,36 @@ def upsample_concat(a, size, b=None):
     return out
 
 
+# MYDET_FUSED_UPCAT=0 keeps nearest-upsample + concat and the 1x1 conv behind them as two launches (A/B measurements)
+FUSED_UPCAT = os.environ.get('MYDET_FUSED_UPCAT', '1') != '0'
+
+
+def conv1x1_upcat(a, b, w_ohwi, scale, shift, act):
+    """act(conv1x1(cat((nearest_2x(a), b), dim=1)) * scale + shift) in ONE launch -- the concatenated tensor is read on the
+    fly, never written; bit-identical to `upsample_concat` + `conv2d`.  a [B,C1,H/2,W/2], b [B,C2,H,W].  Returns None when
+    the shape is not covered (the caller then runs the two launches)."""
+    require_gpu(a, 'conv1x1_upcat')
+    B, C1, Ha, Wa = a.shape
+    _, C2, H, W = b.shape
+    Cout = w_ohwi.shape[0]
+    if not FUSED_UPCAT or (H, W) != (2 * Ha, 2 * Wa) or C1 % 32 or C2 % 32 or act != ACT_LEAKY or w_ohwi.shape[1:3] != (1, 1):
+        return None
+    a, lda = to_nhwc(a)
+    b, ldb = to_nhwc(b)
+    out, ldy = empty_nhwc(B, Cout, H, W, a.device)
+    ws = conv_workspace(a.device)
+    t0 = TIMER.start() if TIMER else None
+    code = _lib.lib().mydet_conv1x1_upcat_f32(_ptr(a), lda, C1, _ptr(b), ldb, C2, _ptr(w_ohwi), _ptr(scale), _ptr(shift), _ptr(ws),
+                                              ws.numel() * 4, _ptr(out), ldy, B, H, W, Cout, act, _stream())
+    if code == -2:                                  # MYDET_E_UNSUPP: the caller runs the two launches
+        return None
+    if t0:
+        name = f'conv_igemm {C1}^+{C2}->{Cout} k1s1 {H}x{W}' if TIMER_DETAIL else 'conv_igemm'
+        TIMER.stop(name, t0, 2.0 * B * H * W * Cout * (C1 + C2), 4.0 * (B * (Ha * Wa * C1 + H * W * C2) + B * H * W * Cout + (C1 + C2) * Cout))
+    _lib.check(code, 'mydet_conv1x1_upcat_f32')
+    return out
+
+
 def space_to_depth(x):
     """Focus' 2x2 space-to-depth (external/ultralytics/common.py:84-86): [B,C,H,W] (any strides) -> [B,4C,H/2,W/2]
     channels-last, channel g*C + c with g = 0:(dy 0,dx 0) 1:(1,0) 2:(0,1) 3:(1,1)."""

@@ -72,6 +72,31 @@ def test_conv_igemm_vs_fp64(dev, case):
     _conv_case(dev, **case)
 
 
+@pytest.mark.parametrize('shape', [(2, 256, 512, 256, 20, 20), (1, 128, 256, 128, 32, 32), (3, 64, 32, 255, 6, 10), (32, 128, 256, 128, 40, 40)])
+def test_conv1x1_upcat_equals_two_launches(dev, shape):
+    """cbl_0(cat((up2x(pre), x), 1)) of YOLOBranch in ONE launch (mydet_conv1x1_upcat_f32: the concatenation is read on the fly)
+    == upsample_concat + conv2d bit for bit (same k order, same tile shape) -- big grids, the batch-1 K-cut path, ragged
+    rows and channels -- and within round-off of float64; shapes it does not cover return None."""
+    from mydetection_amd import ops
+    B, C1, C2, Cout, Ha, Wa = shape
+    g = torch.Generator().manual_seed(21)
+    lo = torch.randn(B, C1, Ha, Wa, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    hi = torch.randn(B, C2, 2 * Ha, 2 * Wa, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, 1, 1, C1 + C2, generator=g) / (C1 + C2) ** 0.5).to(dev)
+    sc, sh = (torch.rand(Cout, generator=g) + 0.5).to(dev), torch.randn(Cout, generator=g).to(dev)
+    y = ops.conv1x1_upcat(lo, hi, w, sc, sh, ops.ACT_LEAKY)
+    cat = ops.upsample_concat(lo, (2 * Ha, 2 * Wa), hi)
+    y2 = ops.conv2d(cat, w, sc, sh, 1, 1, (0, 0, 0, 0), ops.ACT_LEAKY)
+    assert y is not None and torch.equal(y, y2)
+    ref = torch.nn.functional.leaky_relu(
+        torch.einsum('bchw,oc->bohw', torch.cat((torch.nn.functional.interpolate(lo.double().cpu(), scale_factor=2, mode='nearest'),
+                                                 hi.double().cpu()), 1), w.double().cpu().view(Cout, -1))
+        * sc.double().cpu().view(1, -1, 1, 1) + sh.double().cpu().view(1, -1, 1, 1), 0.1)
+    assert (y.double().cpu() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    assert ops.conv1x1_upcat(lo[:, :24], hi, w[..., :24 + C2].contiguous(), sc, sh, ops.ACT_LEAKY) is None      # C1 % 32 != 0
+    assert ops.conv1x1_upcat(lo, hi, w, sc, sh, ops.ACT_SWISH) is None
+
+
 @pytest.mark.parametrize('case', [
     dict(B=1, Cin=32, Cout=64, H=16, W=16, act=1, residual=True),      # DarkBlock 3x3 + residual, one workgroup row
     dict(B=2, Cin=128, Cout=256, H=20, W=20, act=1, residual=True),    # 4 channel blocks, tiles straddle images
