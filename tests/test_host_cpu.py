@@ -436,3 +436,40 @@ def test_decode_node_abi_and_argument_checks():
     assert f(1, ptr, 1, 88, 9, 80, 64, 64, fake, fake, fake, 9 * 64, None) == -1        # Cout != A * 16 * ceil(n_cls / 16)
     arr[0].node.Cout = 9 * 80
     assert f(1, ptr, 1, 88, 9, 80, 64, 64, fake, fake, fake, 9 * 64, None) == -1        # null input / weights
+
+
+def test_bench_parity_check_logic():
+    """bench.py's `parity_check` (the gate every bench line carries) on the CPU: records that equal the oracle's post-process
+    of the same candidates pass; a dropped detection, a swapped pair or a wrong class fails."""
+    import importlib.util
+    import numpy as np
+    from oracle import postprocess as opp
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rng = np.random.Generator(np.random.PCG64(3))
+    B, N = 2, 3000
+    bb = np.concatenate([rng.random((B, N, 2), dtype=np.float32) * 500 + 50, rng.random((B, N, 2), dtype=np.float32) * 80 + 10], axis=-1)
+    ci = rng.integers(0, 20, size=(B, N)).astype(np.int64)
+    sc = (rng.random((B, N), dtype=np.float32) ** 4).astype(np.float32)
+    conf, nms = 0.05, 0.45
+    count = np.zeros(B, dtype=np.int32)
+    index = np.zeros((B, 512), dtype=np.int32)
+    cls = np.zeros((B, 512), dtype=np.int64)
+    for b in range(B):
+        _, oc, _, oi = opp.post_process(bb[b], ci[b], sc[b], conf, nms)
+        count[b], index[b, :len(oi)], cls[b, :len(oi)] = len(oi), oi, oc
+    cand = tuple(torch.from_numpy(a) for a in (bb, ci, sc))
+    rec = {'count': torch.from_numpy(count), 'index': torch.from_numpy(index), 'class_idx': torch.from_numpy(cls)}
+    out = bench.parity_check(cand, rec, conf, nms, oracle_cand=None, images=B)
+    assert out['ok'] and out['nms_equals_oracle_on_gpu_candidates'] and out['images'] == B
+    assert count.min() >= 4
+    for tamper in ('drop', 'swap', 'class'):
+        r2 = {k: v.clone() for k, v in rec.items()}
+        if tamper == 'drop':
+            r2['count'][1] -= 1
+        elif tamper == 'swap':
+            r2['index'][0, [0, 1]] = r2['index'][0, [1, 0]]
+        else:
+            r2['class_idx'][1, 2] += 1
+        assert not bench.parity_check(cand, r2, conf, nms, oracle_cand=None, images=B)['ok'], tamper
