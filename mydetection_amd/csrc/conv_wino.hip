@@ -47,12 +47,15 @@ struct WinoArgs {
     // that does not cover its item's whole K writes its output-domain partial sums to ws (slot 2w: piece that starts
     // inside an item, 2w+1: piece that starts an item but does not finish it) for conv_wino_fixup_kernel
     int nwg, nk;
+    int skq, skr;             // slab iterations of the stream-K tail = skq * nwg + skr (host side: no 64-bit division on the device)
     float *ws;
     size_t ws_bytes;
 };
 
 // first slab iteration of persistent workgroup w: floor(w * total / nwg)
-__device__ __forceinline__ int64_t sk_begin(int w, int64_t total, int nwg) { return (int64_t)w * total / nwg; }
+// = w * q + floor(w * r / nwg) with total = q * nwg + r: 32-bit arithmetic (the tail has < nwg items of <= a few hundred slabs;
+// the 64-bit divisions this replaces cost a small-grid launch -- batch 1 -- a microsecond of pure latency)
+__device__ __forceinline__ int sk_begin(int w, const WinoArgs &p) { return w * p.skq + (int)((unsigned)(w * p.skr) / (unsigned)p.nwg); }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -154,9 +157,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_wino_kernel(con
     // an equal share [it, it_end) of the slab iterations of the remaining `nblk - rounds * G` items
     const int rounds = SK ? p.nblk / p.nwg : 1;
     const int tail0 = SK ? rounds * p.nwg : 0;                            // first item of the stream-K tail
-    const int64_t total = (int64_t)(p.nblk - tail0) * nk;
-    int64_t it = SK ? sk_begin(lid, total, p.nwg) : 0;
-    const int64_t it_end = SK ? sk_begin(lid + 1, total, p.nwg) : 0;
+    int it = SK ? sk_begin(lid, p) : 0;
+    const int it_end = SK ? sk_begin(lid + 1, p) : 0;
     int round = 0;
     const int wc = wave & 3, wt = wave >> 2;           // compute role: channels 16*wc.., tiles 32*wt..32*wt+31
     const int fr = lane & 15, fq = lane >> 4;
@@ -173,10 +175,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_wino_kernel(con
             k_lo = 0; k_hi = nk;
             ++round;
         } else if (SK && it < it_end) {
-            const int ti = (int)(it / nk);
+            const int ti = it / nk;
             item = tail0 + ti;
-            k_lo = (int)(it - (int64_t)ti * nk);
-            k_hi = (int64_t)nk - k_lo < it_end - it ? nk : k_lo + (int)(it_end - it);
+            k_lo = it - ti * nk;
+            k_hi = nk - k_lo < it_end - it ? nk : k_lo + (it_end - it);
             it += k_hi - k_lo;
         } else {
             return false;
@@ -352,12 +354,12 @@ __global__ __launch_bounds__(64 * NW) void conv_wino_fixup_kernel(const WinoArgs
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nk = p.nk;
     const int tail0 = (p.nblk / p.nwg) * p.nwg;        // the stream-K tail starts after the whole rounds
-    const int64_t total = (int64_t)(p.nblk - tail0) * nk;
+    const int total = p.skq * p.nwg + p.skr;
     const int item = tail0 + (int)blockIdx.x;
-    const int64_t first = (int64_t)blockIdx.x * nk;    // the item's slab iterations: [first, first + nk)
+    const int first = (int)blockIdx.x * nk;            // the item's slab iterations: [first, first + nk)
     // the first share boundary inside the item: smallest w with floor(w * total / nwg) > first
-    const int w = (int)(((first + 1) * p.nwg + total - 1) / total);
-    if (w >= p.nwg || sk_begin(w, total, p.nwg) >= first + nk) return;    // not cut
+    const int w = (int)(((int64_t)(first + 1) * p.nwg + total - 1) / total);
+    if (w >= p.nwg || sk_begin(w, p) >= first + nk) return;    // not cut
     // blockIdx.y = which of the thread's eight output float4 (2 tile blocks x 2 x 2 pixels) this workgroup sums: a cut item
     // is 17 pieces of 64 KB at batch 1, and ONE workgroup pulling them through one CU took 17 us (the CU's intake, not
     // the loads' latency); eight workgroups per item take 1/8 each
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wino_fixup_kernel(const WinoArgs
     // later pieces: counted first, then fetched eight at a time (independent loads in flight) and added in K order
     // first workgroup whose share begins at or beyond the item's end: floor(v * total / nwg) >= X  <=>  v >= X * nwg / total
     // (one 64-bit division instead of one per piece)
-    const int64_t xe = (first + nk) * p.nwg;
+    const int64_t xe = (int64_t)(first + nk) * p.nwg;
     int last = (int)((xe + total - 1) / total);
     if (last > p.nwg) last = p.nwg;
     for (int v0 = w; v0 < last; v0 += 8) {
@@ -450,6 +452,7 @@ int launch_nw(WinoArgs a, hipStream_t stream) {
     const bool covered = tail_total == 0 || tail_total >= nwg;
     if (forced_sk() != 0 && (NW == 8 || forced_sk() == 1) && a.ws && need <= a.ws_bytes && (big || small) && covered) {
         a.nwg = nwg;
+        a.skq = (int)(tail_total / nwg); a.skr = (int)(tail_total % nwg);
         hipLaunchKernelGGL((conv_wino_kernel<ACT, RES, NW, true>), dim3(nwg), dim3(NT), LDS, stream, a);
         int rc = mydet_launch_status();
         if (rc || nwg < 2) return rc;
@@ -458,7 +461,7 @@ int launch_nw(WinoArgs a, hipStream_t stream) {
         hipLaunchKernelGGL((conv_wino_fixup_kernel<ACT, RES, NW>), dim3(tail_items, 8), dim3(NT), 0, stream, a);
         return mydet_launch_status();
     }
-    a.nwg = 0;
+    a.nwg = 0; a.skq = 0; a.skr = 0;
     hipLaunchKernelGGL((conv_wino_kernel<ACT, RES, NW, false>), dim3(a.nblk), dim3(NT), LDS, stream, a);
     return mydet_launch_status();
 }
