@@ -145,10 +145,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     unsigned amask[AI];                             // bit t: tap t of this row is inside the image
     unsigned gbase[AI];                             // GATE: byte offset of the row's image in gate[B][Cin]
     unsigned aoff1[AI];                             // CAT: byte offset of the row's pixel (oh / 2, ow / 2) in x1, channel 4*sc
+    // pointwise, stride 1, unpadded (uniform): input pixel == output pixel, no index arithmetic beyond the row number (the
+    // three divisions per row below are pure latency in a small-grid launch)
+    const bool flat = !CAT && ntaps == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 && p.Ho == p.H && p.Wo == p.W;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
         const int m = m0 + sr + RP * i;
         const int mm = m < p.M ? m : p.M - 1;
+        if (flat) {
+            aoff[i] = (int)(((int64_t)(mm - b0 * hwo) * p.ldx + sc * 4) * 4);
+            amask[i] = m < p.M ? 1u : 0u;
+            if (GATE) gbase[i] = (unsigned)((mm / hwo) * p.Cin) * 4u;
+            continue;
+        }
         const int ow = mm % p.Wo, t = mm / p.Wo;
         const int oh = t % p.Ho, b = t / p.Ho;
         const int ih0 = oh * p.stride - p.pad_t, iw0 = ow * p.stride - p.pad_l;
@@ -175,8 +184,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     int kt0 = 0, nk = nk_all;                        // this block's slab range [kt0, nk)
     if (SPLIT) {
         const int sp = (int)blockIdx.x % p.splits;
-        kt0 = (int)((int64_t)nk_all * sp / p.splits);
-        nk = (int)((int64_t)nk_all * (sp + 1) / p.splits);
+        kt0 = (int)((unsigned)(nk_all * sp) / (unsigned)p.splits);          // (nk_all * splits < 2^31: no 64-bit division)
+        nk = (int)((unsigned)(nk_all * (sp + 1)) / (unsigned)p.splits);
     }
     int tap = 0, c0 = 0, tapoff = 0;                 // CIN32 path: uniform tap / channel base / byte offset
     if (SPLIT && CIN32) {
