@@ -414,9 +414,11 @@ int launch(const ConvArgs &a0, int slots, hipStream_t stream) {
     const int nk = (a.K + BK - 1) / BK;
     const int rounds = total / slots;
     int rem = total % slots;
-    // a grid that fills less than half of one round (batch-1 / small-map layers: M = Ho*Wo is a few tiles) is cut along K
+    // a grid that fills less than a quarter of one round (batch-1 / small-map layers: M = Ho*Wo is a few tiles) is cut along K
     // as a whole, so the chip is busy instead of a handful of CUs walking all of K
-    const bool small = rounds == 0 && total * 2 <= slots && nk >= 16;
+    // (a quarter, not half: between the two the K slices and the fixup launch cost more than the idle CUs -- round 4: batch 1
+    // 643 -> 654 images/s, EfficientDet-D1 +1.3 %, D1-FCOS2-ATSS +1.0 %; an eighth is worse again)
+    const bool small = rounds == 0 && total * 4 <= slots && nk >= 16;
     int splits = rem > 0 ? slots / rem : 0;
     if (splits > 16) splits = 16;
     if (splits > nk / 4) splits = nk / 4;
