@@ -26,7 +26,7 @@ prof() { TAG=$1; shift
   rm -rf $O/stats_$TAG $O/fetch_$TAG $O/write_$TAG
   timeout -k 5 $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$TAG -- python3 $R/bench.py --profile --steps 10 --warmup 8 "$@" > $O/stats_$TAG.log 2>&1 || { echo "stats $TAG failed"; tail -3 $O/stats_$TAG.log; return 1; }
   cp $(find $O/stats_$TAG -name '*kernel_stats.csv' | head -1) $O/r04_kernel_stats_$TAG.csv
-  tail -1 $O/stats_$TAG.log | cut -c1-300 > $O/r04_kernel_stats_$TAG.cmdline.json
+  grep "\"metric\"" $O/stats_$TAG.log | tail -1 | cut -c1-600 > $O/r04_kernel_stats_$TAG.cmdline.json
   timeout -k 5 $T rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch_$TAG -- python3 $R/bench.py --profile --eager --steps 3 --warmup 1 "$@" > $O/fetch_$TAG.log 2>&1 || { echo "fetch $TAG failed"; return 1; }
   timeout -k 5 $T rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write_$TAG -- python3 $R/bench.py --profile --eager --steps 3 --warmup 1 "$@" > $O/write_$TAG.log 2>&1 || { echo "write $TAG failed"; return 1; }
   python3 $R/tools/pmc_traffic.py $O/fetch_$TAG $O/write_$TAG > $O/r04_pmc_traffic_$TAG.json
