@@ -67,7 +67,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *base, i
 // Ragged tiles route out-of-range elements to offset 0xFFFFFFFF, which the range check drops.
 template <int ACT, bool RES, bool FULL, int TM, int TN>
 __device__ __forceinline__ void epilogue(const ConvArgs &p, f32x16 (&acc)[TM][TN], int m_base, int n_base,
-                                         int fr, int fh) {
+                                         int fr, int fh, const float (&pscl)[TN], const float (&psft)[TN]) {
     const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y, (int64_t)p.M * p.ldy * 4);
     const __amdgpu_buffer_rsrc_t rr = make_rsrc(RES ? p.res : p.y, (int64_t)p.M * (RES ? p.ldr : p.ldy) * 4);
     const unsigned ldy4 = (unsigned)p.ldy * 4u, ldr4 = (unsigned)p.ldr * 4u;
@@ -75,9 +75,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs &p, f32x16 (&acc)[TM][TN
     for (int j = 0; j < TN; ++j) {
         const int n = n_base + j * 32 + fr;
         const bool nok = FULL || n < p.Cout;
-        const int nc = nok ? n : 0;
-        const float scl = p.scale ? p.scale[nc] : 1.0f;
-        const float sft = p.shift ? p.shift[nc] : 0.0f;
+        const float scl = pscl[j], sft = psft[j];      // requested before the K loop (a round trip per workgroup otherwise)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int mrow = m_base + i * 32 + 4 * fh;          // + (r&3) + 8*(r>>2)
@@ -260,6 +258,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
 
     const int a_off = (wm * TM * 32 + fr) * LDS_LD + fh * 4;
     const int b_off = (wn * TN * 32 + fr) * LDS_LD + fh * 4;
+    float pscl[TN], psft[TN];                          // this lane's output channels' scale / shift: in flight under the K loop
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + fr;
+        const int nc = n < p.Cout ? n : 0;
+        pscl[j] = (!SPLIT && p.scale) ? p.scale[nc] : 1.0f;
+        psft[j] = (!SPLIT && p.shift) ? p.shift[nc] : 0.0f;
+    }
 
     auto compute = [&](int buf) {
         const float *a = As + buf * BM * LDS_LD + a_off;
@@ -320,9 +326,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     }
     const int m_base = m0 + wm * TM * 32, n_base = n0 + wn * TN * 32;
     if ((m0 + BM <= p.M) && (n0 + BN <= p.Cout))
-        epilogue<ACT, RES, true, TM, TN>(p, acc, m_base, n_base, fr, fh);
+        epilogue<ACT, RES, true, TM, TN>(p, acc, m_base, n_base, fr, fh, pscl, psft);
     else
-        epilogue<ACT, RES, false, TM, TN>(p, acc, m_base, n_base, fr, fh);
+        epilogue<ACT, RES, false, TM, TN>(p, acc, m_base, n_base, fr, fh, pscl, psft);
 }
 
 // Split-K tail: sums the K-slice partials of one tile in slice order and applies the fused epilogue.
@@ -358,10 +364,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fixup_kernel(const ConvArgs
                 acc[i][j][4 * v] = t[0]; acc[i][j][4 * v + 1] = t[1]; acc[i][j][4 * v + 2] = t[2]; acc[i][j][4 * v + 3] = t[3];
             }
     const int m_base = m0 + wm * TM * 32, n_base = n0 + wn * TN * 32;
+    float pscl[TN], psft[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n_base + j * 32 + fr;
+        const int nc = n < p.Cout ? n : 0;
+        pscl[j] = p.scale ? p.scale[nc] : 1.0f;
+        psft[j] = p.shift ? p.shift[nc] : 0.0f;
+    }
     if ((m0 + BM <= p.M) && (n0 + BN <= p.Cout))
-        epilogue<ACT, RES, true, TM, TN>(p, acc, m_base, n_base, fr, fh);
+        epilogue<ACT, RES, true, TM, TN>(p, acc, m_base, n_base, fr, fh, pscl, psft);
     else
-        epilogue<ACT, RES, false, TM, TN>(p, acc, m_base, n_base, fr, fh);
+        epilogue<ACT, RES, false, TM, TN>(p, acc, m_base, n_base, fr, fh, pscl, psft);
 }
 
 template <int BM, int BN, int WM, int WN, int BK, bool CIN32, int ACT, bool RES, bool GATE = false, bool SPLIT = false, bool CAT = false>
