@@ -75,7 +75,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // lane are in flight before its first store.
 template <int ACT, bool RES>
 __device__ __forceinline__ void wino_epilogue(const WinoArgs &p, const f32x4 (&out)[2][4], int m0, int n0, int b0,
-                                              int wc, int wt, int fr, int fq, int only = -1) {   // only >= 0: just out[only >> 2][only & 3]
+                                              int wc, int wt, int fr, int fq) {
     const int tpi = p.TH * p.TW;
     const int n = n0 + wc * 16 + fq * 4;
     const bool nok = n < p.Cout;                       // Cout % 4 == 0: the four channels stand or fall together
@@ -99,7 +99,7 @@ __device__ __forceinline__ void wino_epilogue(const WinoArgs &p, const f32x4 (&o
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
             const int a = o >> 1, c = o & 1;
-            const bool ok = tok && oy + a < p.H && ox + c < p.W && (only < 0 || only == blk * 4 + o);
+            const bool ok = tok && oy + a < p.H && ox + c < p.W;
             const int64_t px = pix + (int64_t)a * p.W + c;
             yo[blk][o] = ok ? (unsigned)((px * p.ldy + n) * 4) : OOB;
             if (RES)
@@ -364,28 +364,66 @@ __global__ __launch_bounds__(64 * NW) void conv_wino_fixup_kernel(const WinoArgs
     // is 17 pieces of 64 KB at batch 1, and ONE workgroup pulling them through one CU took 17 us (the CU's intake, not
     // the loads' latency); eight workgroups per item take 1/8 each
     const int j = blockIdx.y;
+    // Everything this workgroup needs is requested before anything is waited for: the epilogue's operands (scale, shift, the
+    // residual pixel) and up to 17 pieces (the first one + 16: a batch-1 layer cuts every item 16-17 ways) -- one round trip
+    // instead of four dependent ones (first piece, two batches of eight, epilogue operands): 7 -> 5 us per launch at batch 1.
+    const int m0 = (item / p.ntn) * TILES, n0 = (item % p.ntn) * CH;
+    const int b0 = m0 / (p.TH * p.TW);
+    const int wc = wave & 3, wt = wave >> 2, fr = lane & 15, fq = lane >> 4;
+    const int n = n0 + wc * 16 + fq * 4;
+    const bool nok = n < p.Cout;
+    const int nc = nok ? n : 0;
+    const f32x4 scl = p.scale ? *reinterpret_cast<const f32x4 *>(p.scale + nc) : f32x4{1.f, 1.f, 1.f, 1.f};
+    const f32x4 sft = p.shift ? *reinterpret_cast<const f32x4 *>(p.shift + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t oimg = (int64_t)p.H * p.W;
+    const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y + b0 * oimg * p.ldy, (p.B - b0) * oimg * p.ldy * 4);
+    const __amdgpu_buffer_rsrc_t rr =
+        make_rsrc(RES ? p.res + b0 * oimg * p.ldr : p.y, (p.B - b0) * oimg * (RES ? p.ldr : p.ldy) * 4);
+    unsigned yo;
+    f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+    {
+        const int blk = j >> 2, o = j & 3, tpi = p.TH * p.TW;
+        const int mt = m0 + wt * 32 + blk * 16 + fr;
+        const int mm = mt < p.MT ? mt : p.MT - 1;
+        const int b = mm / tpi, r = mm - b * tpi, ty = r / p.TW, tx = r - ty * p.TW;
+        const int oy = 2 * ty + (o >> 1), ox = 2 * tx + (o & 1);
+        const bool ok = mt < p.MT && nok && oy < p.H && ox < p.W;
+        const int64_t px = ((int64_t)(b - b0) * p.H + oy) * p.W + ox;
+        yo = ok ? (unsigned)((px * p.ldy + n) * 4) : OOB;
+        if (RES)
+            rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ok ? (unsigned)((px * p.ldr + n) * 4) : OOB, 0, 0));
+    }
     const f32x4 *ws = reinterpret_cast<const f32x4 *>(p.ws) + tid + (int64_t)j * NT;
-    f32x4 sum = ws[(int64_t)(2 * (w - 1) + 1) * 8 * NT];                                               // starts the item
-    // later pieces: counted first, then fetched eight at a time (independent loads in flight) and added in K order
     // first workgroup whose share begins at or beyond the item's end: floor(v * total / nwg) >= X  <=>  v >= X * nwg / total
     // (one 64-bit division instead of one per piece)
     const int64_t xe = (int64_t)(first + nk) * p.nwg;
     int last = (int)((xe + total - 1) / total);
     if (last > p.nwg) last = p.nwg;
-    for (int v0 = w; v0 < last; v0 += 8) {
-        f32x4 t[8];
+    f32x4 sum = ws[(int64_t)(2 * (w - 1) + 1) * 8 * NT];                                               // starts the item
+    f32x4 t[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+        if (w + u < last) t[u] = ws[(int64_t)(2 * (w + u)) * 8 * NT];                                  // uniform
+#pragma unroll
+    for (int u = 0; u < 16; ++u)                       // added in K order
+        if (w + u < last) sum += t[u];
+    for (int v0 = w + 16; v0 < last; v0 += 8) {         // more than 17 pieces: eight at a time
+        f32x4 t8[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            if (v0 + u < last) t[u] = ws[(int64_t)(2 * (v0 + u)) * 8 * NT];                            // uniform
+            if (v0 + u < last) t8[u] = ws[(int64_t)(2 * (v0 + u)) * 8 * NT];
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            if (v0 + u < last) sum += t[u];
+            if (v0 + u < last) sum += t8[u];
     }
-    f32x4 out[2][4];
+    f32x4 v = sum * scl + sft;                         // as wino_epilogue
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj) out[jj >> 2][jj & 3] = sum;       // only component j is stored
-    const int m0 = (item / p.ntn) * TILES, n0 = (item % p.ntn) * CH;
-    wino_epilogue<ACT, RES>(p, out, m0, n0, m0 / (p.TH * p.TW), wave & 3, wave >> 2, lane & 15, lane >> 4, j);
+    for (int e = 0; e < 4; ++e) {
+        if (ACT == MYDET_ACT_LEAKY) v[e] = v[e] > 0.0f ? v[e] : v[e] * 0.1f;
+        if (ACT == MYDET_ACT_SWISH) v[e] = v[e] * mydet_sigmoid_fast(v[e]);
+    }
+    if (RES) v += rv;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, yo, 0, 0);
 }
 
 // U = G g Gt in float64, rounded once; layout [Cin/8][8 position pairs][4 k quarters][CoutP][4] with the float4 =
