@@ -267,7 +267,9 @@ int mydet_postprocess_records_f32(const float *bbox, const int64_t *class_idx, c
  * transform-domain weights made by mydet_wino4_weights_f32 from the OHWI weight (mydet_wino4_weights_floats(Cout, Cin)
  * floats; Cin % 4 == 0).  `ws` = device scratch of at least mydet_wino4_workspace_bytes(B, H, W, Cin) bytes
  * (36 floats per 4x4-output tile and input channel: the transform-domain input, written by a first launch and
- * streamed by the second); stream-ordered, so one buffer serves every layer of a stream.
+ * streamed by the second, plus 64 MiB for the partial tiles of the K-cut tail: when the workgroup count is whole rounds
+ * of the chip plus a small remainder, the remainder runs as K pieces that a fourth launch sums in K order -- deterministic);
+ * stream-ordered, so one buffer serves every layer of a stream.
  * MYDET_E_UNSUPP (-2) for shapes it does not cover: the caller then uses mydet_conv2d_wino_f32 / _igemm_f32.
  * Replaces the same reference code as mydet_conv2d_igemm_f32 (models/modules.py:69-73,94-95). */
 int64_t mydet_wino4_weights_floats(int Cout, int Cin);

@@ -10,7 +10,7 @@
 // float32 throughout; against float64 the error is ~3e-6 rms of O(1) outputs (the direct form: 2e-7; tests/
 // test_winograd_algebra.py), i.e. 30x inside the 1e-4 the detections are held to.
 //
-// Two launches per layer:
+// Two launches per layer (four when the K-cut tail applies, see mydet_conv2d_wino4_f32):
 //  1. wino4_input_kernel: V = Bt d B once per (tile, input channel), written to a workspace in MFMA-fragment order
 //     [tile block of 32][k/4][position group of 4][k%4][tile] float4 = positions 4g..4g+3.  An HBM-bound pass (x read once,
 //     2.25x its size written) with 16-byte accesses on both sides: 5.3-5.7 TB/s (round 4; the dword-load form of rounds
@@ -43,6 +43,7 @@ constexpr int V_BYTES = NPG * KC * TILES * 16;         // 18 432: one 4-channel 
 constexpr int STAGE = U_BYTES + V_BYTES;               // 36 864
 constexpr int LDS_BYTES = 2 * STAGE;                   // 73 728: two workgroups per CU
 constexpr int COUT_PAD = 64;                           // U rows are padded to this many output channels
+constexpr int64_t TAIL_BYTES = (int64_t)1024 * 16 * 64 * NW * 16;   // 64 MiB behind V: partial tiles of the K-cut tail (<= 1024 pieces)
 
 struct W4Args {
     const float *x, *u, *scale, *shift, *res;
@@ -51,6 +52,11 @@ struct W4Args {
     int B, H, W, Cin, Cout, CoutP;
     int TH, TW, MT, ntn, nblk;
     int nmb, nbn, rn_log2;                             // item order of the GEMM kernel (see there)
+    // K-cut tail (see launch_w4): the last `tail_blocks` 64-item blocks of the item order run as `splits` pieces along K whose
+    // output-domain partial tiles go to `part` ([block slot][piece][16 output pixels][256 threads] float4) and are summed by
+    // wino4_fixup_kernel; the main launch covers the ids below tail_id0
+    int tail_id0, tail_blocks, splits;
+    float *part;
 #ifdef MYDET_DIAG
     // diagnostic build only (`make EXTRA=-DMYDET_DIAG`, tools/r04_clock.py; the results of such a build are NOT valid):
     // MYDET_W4_DBG & 7 = 1 every stage reads the same 36 KB, 2 no DMA after stage 1, 3 U always stage 0; & 8 = stamp the K
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void wino4_input_kernel(const W4Args p) {
 }
 
 // ---- 2. transform-domain GEMMs + output transform + epilogue
-template <int ACT, bool RES>
+template <int ACT, bool RES, bool PART = false>
 __global__ __launch_bounds__(64 * NW, 2) void conv_wino4_kernel(const W4Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -171,7 +177,17 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino4_kernel(const W4Args p) 
     // from 256 output channels up).  They walk K together, so a V stage is fetched from HBM once per RN workgroups
     // and a U stage once per RM; with the tile-block-major order (RM = 2 at Cout = 1024) the deep layers re-read U
     // a dozen times over.  Ids of the padded grid that fall outside return at once.
-    const int id = mydet_xcd_remap(blockIdx.x, p.nblk);
+    // PART: the grid is `splits` copies of the tail's ids, piece-major -- the 64 workgroups an XCD runs together are one block
+    // at one K range, as in the main launch
+    int id, piece = 0;
+    if (PART) {
+        const int per = p.tail_blocks * 64;
+        const int lid = mydet_xcd_remap(blockIdx.x, per * p.splits);
+        piece = lid / per;
+        id = p.tail_id0 + (lid - piece * per);
+    } else {
+        id = mydet_xcd_remap(blockIdx.x, p.nblk);
+    }
     const int bi = id >> 6, w = id & 63;
     const int mb = (bi / p.nbn) * (64 >> p.rn_log2) + (w >> p.rn_log2);
     const int nb = (bi % p.nbn) * (1 << p.rn_log2) + (w & ((1 << p.rn_log2) - 1));
@@ -249,15 +265,17 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino4_kernel(const W4Args p) 
     }
     f32x4 rv[16];                                      // residual of the 4x4 outputs: loaded under the last stage's MFMAs
 
-    load_stage(0);
+    const int kt0 = PART ? (int)((unsigned)(nk * piece) / (unsigned)p.splits) : 0;
+    const int kt1 = PART ? (int)((unsigned)(nk * (piece + 1)) / (unsigned)p.splits) : nk;
+    load_stage(kt0);
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): the DMA'd stage has landed
     __syncthreads();
 #ifdef MYDET_DIAG
     const uint64_t dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_stage(kt + 1);           // its buffer was last read before the previous barrier
-        if (RES && kt == nk - 1) {
+    for (int kt = kt0; kt < kt1; ++kt) {
+        if (kt + 1 < kt1) load_stage(kt + 1);          // its buffer was last read before the previous barrier
+        if (RES && kt == kt1 - 1) {
 #pragma unroll
             for (int o = 0; o < 16; ++o)
                 rv[o] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
@@ -319,6 +337,12 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino4_kernel(const W4Args p) 
         out[1] = dd + 2.0f * ee;
         out[2] = pp + 4.0f * qq;
         out[3] = dd + 8.0f * ee + acc[6 * a + 5];
+        if (PART) {                                    // raw output-domain partial tile; scale / act / residual in the fixup
+            f32x4 *dst = reinterpret_cast<f32x4 *>(p.part) + ((int64_t)(id - p.tail_id0) * p.splits + piece) * (16 * 64 * NW) + tid;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dst[(4 * a + c) * (64 * NW)] = out[c];
+            continue;
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             f32x4 v = out[c] * scl + sft;
@@ -336,6 +360,66 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino4_kernel(const W4Args p) 
             const unsigned yo = ybase + (unsigned)((a * p.W + c) * p.ldy * 4);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, orow[a] && ocol[c] ? yo : OOB, 0, 0);
         }
+    }
+}
+
+// ---- 3. K-cut tail: sums the pieces of one tail item in K order and applies the epilogue.  blockIdx.x = id slot of the
+// tail (padded ids return), blockIdx.y = output row a of the 4x4 tiles; a thread has the role it had in the GEMM kernel
+// (same tile, same four channels).  Everything is requested before anything is waited for.
+template <int ACT, bool RES>
+__global__ __launch_bounds__(64 * NW) void wino4_fixup_kernel(const W4Args p) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int id = p.tail_id0 + (int)blockIdx.x, a = blockIdx.y;
+    const int bi = id >> 6, w = id & 63;
+    const int mb = (bi / p.nbn) * (64 >> p.rn_log2) + (w >> p.rn_log2);
+    const int nb = (bi % p.nbn) * (1 << p.rn_log2) + (w & ((1 << p.rn_log2) - 1));
+    if (mb >= p.nmb || nb >= p.ntn) return;
+    const int tpi = p.TH * p.TW;
+    const int m0 = mb * TILES, n0 = nb * CH, b0 = m0 / tpi;
+    const int wc = wave % (NW / 2), wt = wave / (NW / 2), fr = lane & 15, fq = lane >> 4;
+    const int n = n0 + wc * 16 + fq * 4;
+    const bool nok = n < p.Cout;
+    const int nc = nok ? n : 0;
+    const f32x4 scl = p.scale ? *reinterpret_cast<const f32x4 *>(p.scale + nc) : f32x4{1.f, 1.f, 1.f, 1.f};
+    const f32x4 sft = p.shift ? *reinterpret_cast<const f32x4 *>(p.shift + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t oimg = (int64_t)p.H * p.W;
+    const __amdgpu_buffer_rsrc_t yr = rsrc(p.y + b0 * oimg * p.ldy, (p.B - b0) * oimg * p.ldy * 4);
+    const __amdgpu_buffer_rsrc_t rr = rsrc(RES ? p.res + b0 * oimg * p.ldr : p.y, (p.B - b0) * oimg * (RES ? p.ldr : p.ldy) * 4);
+    const int mt = m0 + wt * 16 + fr;
+    const int mm = mt < p.MT ? mt : p.MT - 1;
+    const int b = mm / tpi, r = mm - b * tpi, ty = r / p.TW, tx = r - ty * p.TW;
+    const int oy = 4 * ty + a, ox = 4 * tx;
+    const bool rok = mt < p.MT && nok && oy < p.H;
+    const int64_t pix = ((int64_t)(b - b0) * p.H + oy) * p.W + ox;
+    unsigned yo[4];
+    f32x4 rv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const bool ok = rok && ox + c < p.W;
+        yo[c] = ok ? (unsigned)(((pix + c) * p.ldy + n) * 4) : OOB;
+        if (RES) rv[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ok ? (unsigned)(((pix + c) * p.ldr + n) * 4) : OOB, 0, 0));
+    }
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(p.part) + (int64_t)blockIdx.x * p.splits * (16 * 64 * NW) + (4 * a) * (64 * NW) + tid;
+    f32x4 t[4][8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            if (s < p.splits) t[c][s] = src[(int64_t)s * (16 * 64 * NW) + c * (64 * NW)];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        f32x4 sum = t[c][0];
+#pragma unroll
+        for (int s = 1; s < 8; ++s)
+            if (s < p.splits) sum += t[c][s];          // K order
+        f32x4 v = sum * scl + sft;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (ACT == MYDET_ACT_LEAKY) v[e] = v[e] > 0.0f ? v[e] : v[e] * 0.1f;
+            if (ACT == MYDET_ACT_SWISH) v[e] = v[e] * mydet_sigmoid_fast(v[e]);
+        }
+        if (RES) v += rv[c];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, yo[c], 0, 0);
     }
 }
 
@@ -369,7 +453,21 @@ int launch_w4(W4Args a, hipStream_t stream) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino4_kernel<ACT, RES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     }
+    static unsigned long long attr_set_p = 0;
+    if (mydet_first_on_device(attr_set_p)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino4_kernel<MYDET_ACT_NONE, false, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    }
     hipLaunchKernelGGL(wino4_input_kernel, dim3((a.MT + TILES - 1) / TILES, (a.Cin + 31) / 32), dim3(256), 0, stream, a);
+    if (a.tail_blocks > 0) {
+        // whole rounds of whole items, then the remainder cut along K so that it fills the chip once, then the sums
+        a.nblk = a.tail_id0;                           // (the XCD remap of the main launch runs over its own grid)
+        hipLaunchKernelGGL((conv_wino4_kernel<ACT, RES>), dim3(a.tail_id0), dim3(64 * NW), LDS_BYTES, stream, a);
+        hipLaunchKernelGGL((conv_wino4_kernel<MYDET_ACT_NONE, false, true>), dim3(a.tail_blocks * 64 * a.splits), dim3(64 * NW),
+                           LDS_BYTES, stream, a);
+        hipLaunchKernelGGL((wino4_fixup_kernel<ACT, RES>), dim3(a.tail_blocks * 64, 4), dim3(64 * NW), 0, stream, a);
+        return mydet_launch_status();
+    }
     hipLaunchKernelGGL((conv_wino4_kernel<ACT, RES>), dim3(a.nblk), dim3(64 * NW), LDS_BYTES, stream, a);
     return mydet_launch_status();
 }
@@ -394,7 +492,7 @@ extern "C" int mydet_wino4_weights_f32(const float *w, int Cout, int Cin, float 
 extern "C" int64_t mydet_wino4_workspace_bytes(int B, int H, int W, int Cin) {
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3)) return 0;
     const int64_t MT = (int64_t)B * ((H + 3) / 4) * ((W + 3) / 4);
-    return (MT + TILES - 1) / TILES * (Cin >> 2) * V_BYTES;
+    return (MT + TILES - 1) / TILES * (Cin >> 2) * V_BYTES + TAIL_BYTES;
 }
 
 extern "C" int mydet_conv2d_wino4_f32(const float *x, int64_t ldx, const float *u, const float *scale, const float *shift,
@@ -431,6 +529,39 @@ extern "C" int mydet_conv2d_wino4_f32(const float *x, int64_t ldx, const float *
     if (nbm * a.nbn * 64 > 0x7FFFFFFF) return MYDET_E_UNSUPP;
     a.nblk = (int)(nbm * a.nbn * 64);
     if ((MT + TILES - 1) / TILES > 0x7FFFFFFF || (Cin + 31) / 32 > 65535) return MYDET_E_UNSUPP;
+    // K-cut tail.  Workgroups are equal, the chip holds `slots` of them, so T items cost ceil(T / slots) rounds: 1600 items
+    // (256->512 @40^2, batch 32) pay four rounds for 3.125.  When the remainder is small, the last blocks of the item order
+    // (the fewest that bring the rest down to whole rounds) are instead cut `splits` ways along K -- together one short round --
+    // and summed by a small launch.  Not worth it when the remainder is large (splits < 2) or K is short.
+    a.tail_id0 = a.nblk; a.tail_blocks = 0; a.splits = 1;
+    a.part = ws + (mydet_wino4_workspace_bytes(B, H, W, Cin) - TAIL_BYTES) / 4;
+    {
+        const char *te = getenv("MYDET_W4_TAIL");     // tuning / tests: minimum cut count, 0 = no tail (read per call)
+        const int tail_on = te ? atoi(te) : 4;      // (2 -- half a round of remainder cut two ways -- measured the same as 4 on the headline)
+        const int slots = 2 * mydet_cu_count();
+        const int64_t T = (int64_t)a.nmb * a.ntn;
+        const int64_t whole = T / slots * slots;
+        const int RM = 64 >> a.rn_log2, RN = 1 << a.rn_log2, nk = Cin >> 2;
+        if (tail_on && whole > 0 && T > whole) {
+            int64_t cut = 0;                           // items in the last `tb` blocks
+            int tb = 0;
+            const int64_t NB = nbm * a.nbn;
+            while (T - cut > whole && tb < NB) {
+                const int64_t blk = NB - 1 - tb;
+                const int64_t row = blk / a.nbn, col = blk % a.nbn;
+                const int64_t rows = (row + 1) * RM <= a.nmb ? RM : a.nmb - row * RM;
+                const int64_t cols = (col + 1) * RN <= a.ntn ? RN : a.ntn - col * RN;
+                cut += rows * cols;
+                ++tb;
+            }
+            int splits = cut > 0 ? (int)(slots / cut) : 0;
+            splits = splits > 8 ? 8 : splits;
+            if (splits > nk / 4) splits = nk / 4;
+            if (splits >= 2 && splits >= tail_on && (int64_t)tb * 64 * splits <= 1024 && tb < NB) {
+                a.tail_blocks = tb; a.splits = splits; a.tail_id0 = (int)((NB - tb) * 64);
+            }
+        }
+    }
     hipStream_t s = (hipStream_t)stream;
     const bool res = residual != nullptr;
     switch (act) {

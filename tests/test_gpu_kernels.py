@@ -126,6 +126,8 @@ def test_conv_winograd_vs_fp64(dev, case):
     dict(B=2, Cin=132, Cout=84, H=5, W=7, act=2, residual=True),       # ragged everything, swish
     dict(B=32, Cin=128, Cout=256, H=40, W=40, act=1, residual=True),   # big grid (XCD remap path)
     dict(B=1, Cin=256, Cout=512, H=32, W=32, act=1, residual=True),    # batch-1 layer
+    dict(B=17, Cin=64, Cout=512, H=32, W=32, act=1, residual=True),    # K-cut tail: 544 items = one round + 32 items cut 4 ways (nk / 4)
+    dict(B=24, Cin=136, Cout=200, H=37, W=37, act=2, residual=True),   # K-cut tail, ragged: 525 items, a 21-item block cut 8 ways
 ])
 def test_conv_winograd4_vs_fp64(dev, case):
     """Fused Winograd F(4x4,3x3) kernel (3x3, stride 1, pad 1) against the float64 reference."""
@@ -155,6 +157,36 @@ def test_conv_winograd4_repeatable(dev, case):
         assert torch.equal(o, outs[0])
     assert (outs[0] - direct).abs().max().item() <= 1e-4 * max(1.0, direct.abs().max().item())
 
+
+
+@pytest.mark.parametrize('case', [
+    dict(B=17, Cin=64, Cout=512, H=32, W=32, act=1, residual=True),
+    dict(B=24, Cin=136, Cout=200, H=37, W=37, act=2, residual=True),
+    dict(B=32, Cin=256, Cout=512, H=40, W=40, act=1, residual=True),   # the headline's 40^2 layers: 1536 items + 64 cut 8 ways
+])
+def test_conv_winograd4_kcut_tail(dev, case, monkeypatch):
+    """F(4x4) launches whose item count is whole rounds plus a small remainder run the remainder as K pieces + a fixup launch
+    (conv_wino4.hip, launch rule in mydet_conv2d_wino4_f32).  Same sums in another association: equal to the uncut form
+    (MYDET_W4_TAIL=0) within float32 round-off, and bit-identical run after run."""
+    from mydetection_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, Cin, Cout, H, W = (case[k] for k in ('B', 'Cin', 'Cout', 'H', 'W'))
+    x = torch.randn(B, Cin, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) / (Cin * 9) ** 0.5).to(dev)
+    scale, shift = (torch.rand(Cout, generator=g) + 0.5).to(dev), (torch.randn(Cout, generator=g) * 0.1).to(dev)
+    res = torch.randn(B, Cout, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    u4 = ops.wino4_weights(w)
+
+    def run():
+        return ops.conv2d(x, w, scale, shift, 3, 1, (1, 1, 1, 1), case['act'], residual=res, wino4=u4).clone()
+    cut = [run() for _ in range(4)]
+    monkeypatch.setenv('MYDET_W4_TAIL', '0')
+    plain = run()
+    monkeypatch.delenv('MYDET_W4_TAIL')
+    for o in cut[1:]:
+        assert torch.equal(o, cut[0])
+    assert not torch.equal(cut[0], plain), 'the tail rule did not trigger on a shape chosen to trigger it'
+    assert (cut[0] - plain).abs().max().item() <= 2e-5 * max(1.0, plain.abs().max().item())
 
 
 def test_conv_winograd_unsupported_shapes_stay_direct(dev):
