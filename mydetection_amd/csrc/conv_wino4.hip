@@ -52,10 +52,12 @@ struct W4Args {
     int B, H, W, Cin, Cout, CoutP;
     int TH, TW, MT, ntn, nblk;
     int nmb, nbn, rn_log2;                             // item order of the GEMM kernel (see there)
-    // K-cut tail (see launch_w4): the last `tail_blocks` 64-item blocks of the item order run as `splits` pieces along K whose
+    // K-cut tail (see mydet_conv2d_wino4_f32): the last 64-item blocks of the item order run in groups as `splits` pieces along K whose
     // output-domain partial tiles go to `part` ([block slot][piece][16 output pixels][256 threads] float4) and are summed by
     // wino4_fixup_kernel; the main launch covers the ids below tail_id0
-    int tail_id0, tail_blocks, splits;
+    // A group: blocks [tail_id0 / 64, + tail_blocks), of each the first `tail_stride` ids (a block of the ragged last row has
+    // its valid items in front), `splits` pieces; `part` is this group's share of the scratch.
+    int tail_id0, tail_blocks, tail_stride, splits;
     float *part;
 #ifdef MYDET_DIAG
     // diagnostic build only (`make EXTRA=-DMYDET_DIAG`, tools/r04_clock.py; the results of such a build are NOT valid):
@@ -179,12 +181,14 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino4_kernel(const W4Args p) 
     // a dozen times over.  Ids of the padded grid that fall outside return at once.
     // PART: the grid is `splits` copies of the tail's ids, piece-major -- the 64 workgroups an XCD runs together are one block
     // at one K range, as in the main launch
-    int id, piece = 0;
+    int id, piece = 0, slot = 0;
     if (PART) {
-        const int per = p.tail_blocks * 64;
+        const int per = p.tail_blocks * p.tail_stride;
         const int lid = mydet_xcd_remap(blockIdx.x, per * p.splits);
         piece = lid / per;
-        id = p.tail_id0 + (lid - piece * per);
+        slot = lid - piece * per;
+        const int blk = slot / p.tail_stride;
+        id = p.tail_id0 + blk * 64 + (slot - blk * p.tail_stride);
     } else {
         id = mydet_xcd_remap(blockIdx.x, p.nblk);
     }
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino4_kernel(const W4Args p) 
         out[2] = pp + 4.0f * qq;
         out[3] = dd + 8.0f * ee + acc[6 * a + 5];
         if (PART) {                                    // raw output-domain partial tile; scale / act / residual in the fixup
-            f32x4 *dst = reinterpret_cast<f32x4 *>(p.part) + ((int64_t)(id - p.tail_id0) * p.splits + piece) * (16 * 64 * NW) + tid;
+            f32x4 *dst = reinterpret_cast<f32x4 *>(p.part) + ((int64_t)slot * p.splits + piece) * (16 * 64 * NW) + tid;
 #pragma unroll
             for (int c = 0; c < 4; ++c) dst[(4 * a + c) * (64 * NW)] = out[c];
             continue;
@@ -369,7 +373,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino4_kernel(const W4Args p) 
 template <int ACT, bool RES>
 __global__ __launch_bounds__(64 * NW) void wino4_fixup_kernel(const W4Args p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int id = p.tail_id0 + (int)blockIdx.x, a = blockIdx.y;
+    const int blk = (int)blockIdx.x / p.tail_stride;
+    const int id = p.tail_id0 + blk * 64 + ((int)blockIdx.x - blk * p.tail_stride), a = blockIdx.y;
     const int bi = id >> 6, w = id & 63;
     const int mb = (bi / p.nbn) * (64 >> p.rn_log2) + (w >> p.rn_log2);
     const int nb = (bi % p.nbn) * (1 << p.rn_log2) + (w & ((1 << p.rn_log2) - 1));
@@ -447,7 +452,7 @@ __global__ void wino4_weights_kernel(const float *w, int Cout, int Cin, int Cout
 }
 
 template <int ACT, bool RES>
-int launch_w4(W4Args a, hipStream_t stream) {
+int launch_w4(W4Args a, const W4Args *groups, int ngroups, hipStream_t stream) {
     static unsigned long long attr_set = 0;                      // > 64 KiB of dynamic LDS needs the opt-in once per device
     if (mydet_first_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino4_kernel<ACT, RES>),
@@ -459,13 +464,20 @@ int launch_w4(W4Args a, hipStream_t stream) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     }
     hipLaunchKernelGGL(wino4_input_kernel, dim3((a.MT + TILES - 1) / TILES, (a.Cin + 31) / 32), dim3(256), 0, stream, a);
-    if (a.tail_blocks > 0) {
-        // whole rounds of whole items, then the remainder cut along K so that it fills the chip once, then the sums
-        a.nblk = a.tail_id0;                           // (the XCD remap of the main launch runs over its own grid)
-        hipLaunchKernelGGL((conv_wino4_kernel<ACT, RES>), dim3(a.tail_id0), dim3(64 * NW), LDS_BYTES, stream, a);
-        hipLaunchKernelGGL((conv_wino4_kernel<MYDET_ACT_NONE, false, true>), dim3(a.tail_blocks * 64 * a.splits), dim3(64 * NW),
-                           LDS_BYTES, stream, a);
-        hipLaunchKernelGGL((wino4_fixup_kernel<ACT, RES>), dim3(a.tail_blocks * 64, 4), dim3(64 * NW), 0, stream, a);
+    if (ngroups > 0) {
+        // whole rounds of whole items, then the remainder in groups cut along K (each about one short round), then their sums
+        W4Args m = a;
+        m.nblk = groups[0].tail_id0;                   // (the XCD remap of the main launch runs over its own grid)
+        hipLaunchKernelGGL((conv_wino4_kernel<ACT, RES>), dim3(m.nblk), dim3(64 * NW), LDS_BYTES, stream, m);
+        for (int g = 0; g < ngroups; ++g) {
+            const W4Args &t = groups[g];
+            hipLaunchKernelGGL((conv_wino4_kernel<MYDET_ACT_NONE, false, true>), dim3(t.tail_blocks * t.tail_stride * t.splits),
+                               dim3(64 * NW), LDS_BYTES, stream, t);
+        }
+        for (int g = 0; g < ngroups; ++g) {
+            const W4Args &t = groups[g];
+            hipLaunchKernelGGL((wino4_fixup_kernel<ACT, RES>), dim3(t.tail_blocks * t.tail_stride, 4), dim3(64 * NW), 0, stream, t);
+        }
         return mydet_launch_status();
     }
     hipLaunchKernelGGL((conv_wino4_kernel<ACT, RES>), dim3(a.nblk), dim3(64 * NW), LDS_BYTES, stream, a);
@@ -530,43 +542,78 @@ extern "C" int mydet_conv2d_wino4_f32(const float *x, int64_t ldx, const float *
     a.nblk = (int)(nbm * a.nbn * 64);
     if ((MT + TILES - 1) / TILES > 0x7FFFFFFF || (Cin + 31) / 32 > 65535) return MYDET_E_UNSUPP;
     // K-cut tail.  Workgroups are equal, the chip holds `slots` of them, so T items cost ceil(T / slots) rounds: 1600 items
-    // (256->512 @40^2, batch 32) pay four rounds for 3.125.  When the remainder is small, the last blocks of the item order
-    // (the fewest that bring the rest down to whole rounds) are instead cut `splits` ways along K -- together one short round --
-    // and summed by a small launch.  Not worth it when the remainder is large (splits < 2) or K is short.
-    a.tail_id0 = a.nblk; a.tail_blocks = 0; a.splits = 1;
+    // (256->512 @40^2, batch 32) pay four rounds for 3.125.  The last blocks of the item order (the fewest that bring the rest
+    // down to whole rounds) are instead cut along K in up to two groups -- each about one short round -- and summed by small
+    // launches: 64 items 8 ways @40^2, 128 items 4 ways @80^2, 256 items 2 ways + 32 items 8 ways @20^2.  Not when K is
+    // short or the groups would cost about the round they replace.
+    a.tail_id0 = a.nblk; a.tail_blocks = 0; a.tail_stride = 64; a.splits = 1;
     a.part = ws + (mydet_wino4_workspace_bytes(B, H, W, Cin) - TAIL_BYTES) / 4;
+    W4Args groups[3];
+    int ngroups = 0;
     {
-        const char *te = getenv("MYDET_W4_TAIL");     // tuning / tests: minimum cut count, 0 = no tail (read per call)
-        const int tail_on = te ? atoi(te) : 4;      // (2 -- half a round of remainder cut two ways -- measured the same as 4 on the headline)
+        const char *te = getenv("MYDET_W4_TAIL");     // tuning / tests: minimum cut count of the last group, 0 = no tail (read per call)
+        const int tail_on = te ? atoi(te) : 4;
+        const char *ge = getenv("MYDET_W4_TAIL_GROUPS");
+        const int max_groups = ge ? atoi(ge) : 2;
         const int slots = 2 * mydet_cu_count();
         const int64_t T = (int64_t)a.nmb * a.ntn;
         const int64_t whole = T / slots * slots;
         const int RM = 64 >> a.rn_log2, RN = 1 << a.rn_log2, nk = Cin >> 2;
-        if (tail_on && whole > 0 && T > whole) {
-            int64_t cut = 0;                           // items in the last `tb` blocks
-            int tb = 0;
-            const int64_t NB = nbm * a.nbn;
-            while (T - cut > whole && tb < NB) {
-                const int64_t blk = NB - 1 - tb;
-                const int64_t row = blk / a.nbn, col = blk % a.nbn;
-                const int64_t rows = (row + 1) * RM <= a.nmb ? RM : a.nmb - row * RM;
-                const int64_t cols = (col + 1) * RN <= a.ntn ? RN : a.ntn - col * RN;
-                cut += rows * cols;
-                ++tb;
+        const int64_t NB = nbm * a.nbn;
+        auto items_of = [&](int64_t blk) {
+            const int64_t row = blk / a.nbn, col = blk % a.nbn;
+            const int64_t rows = (row + 1) * RM <= a.nmb ? RM : a.nmb - row * RM;
+            const int64_t cols = (col + 1) * RN <= a.ntn ? RN : a.ntn - col * RN;
+            return rows * cols;
+        };
+        auto stride_of = [&](int64_t blk) {            // valid ids of a block are w = r * RN + c, r < rows: a prefix when no column is cut
+            const int64_t row = blk / a.nbn;
+            const int64_t rows = (row + 1) * RM <= a.nmb ? RM : a.nmb - row * RM;
+            return (int)(rows * RN);
+        };
+        if (tail_on > 0 && whole > 0 && T > whole && nk >= 8) {
+            int64_t cut = 0;
+            int64_t first = NB;                        // first block of the tail: the fewest blocks that leave whole rounds
+            while (T - cut > whole && first > 0) cut += items_of(--first);
+            // groups in id order.  While what is left is more than half a round, a group of up to half a round is cut two ways;
+            // the rest is one group cut slots / items ways (at most 8, at least 4 K stages per piece).
+            int64_t blk = first, left = cut, used = 0;
+            double cost = 0.0;                         // in rounds: 1 / splits per group + ~0.12 for its two launches
+            bool ok = true;
+            while (left > 0 && ok) {
+                if (ngroups == 3 || ngroups == max_groups) { ok = false; break; }
+                W4Args t = a;
+                t.tail_id0 = (int)(blk * 64);
+                int64_t n = 0;
+                int nb = 0, stride = 0;
+                const bool last = left * 2 <= slots;
+                while (blk + nb < NB && (last || n + items_of(blk + nb) <= slots / 2)) {
+                    n += items_of(blk + nb);
+                    stride = stride_of(blk + nb) > stride ? stride_of(blk + nb) : stride;
+                    ++nb;
+                }
+                int splits = last ? (int)(slots / n) : 2;
+                splits = splits > 8 ? 8 : splits;
+                if (splits > nk / 4) splits = nk / 4;
+                if (n == 0 || splits < 2 || (last && splits < tail_on)) { ok = false; break; }
+                t.tail_blocks = nb; t.tail_stride = stride; t.splits = splits;
+                t.part = a.part + used / 4;
+                used += (int64_t)nb * stride * splits * (16 * 64 * NW * 16);
+                if (used > TAIL_BYTES) { ok = false; break; }
+                cost += 1.0 / splits + 0.12;
+                groups[ngroups++] = t;
+                blk += nb; left -= n;
             }
-            int splits = cut > 0 ? (int)(slots / cut) : 0;
-            splits = splits > 8 ? 8 : splits;
-            if (splits > nk / 4) splits = nk / 4;
-            if (splits >= 2 && splits >= tail_on && (int64_t)tb * 64 * splits <= 1024 && tb < NB) {
-                a.tail_blocks = tb; a.splits = splits; a.tail_id0 = (int)((NB - tb) * 64);
-            }
+            // (0.9 admits a two-way group + an eight-way group = 0.865: 512->1024 @20^2, 800 items = one round + 256 + 32)
+            const char *ce = getenv("MYDET_W4_TAIL_COST");
+            if (!ok || cost > (ce ? atof(ce) : 0.9)) ngroups = 0;
         }
     }
     hipStream_t s = (hipStream_t)stream;
     const bool res = residual != nullptr;
     switch (act) {
-        case MYDET_ACT_LEAKY: return res ? launch_w4<MYDET_ACT_LEAKY, true>(a, s) : launch_w4<MYDET_ACT_LEAKY, false>(a, s);
-        case MYDET_ACT_SWISH: return res ? launch_w4<MYDET_ACT_SWISH, true>(a, s) : launch_w4<MYDET_ACT_SWISH, false>(a, s);
-        default: return res ? launch_w4<MYDET_ACT_NONE, true>(a, s) : launch_w4<MYDET_ACT_NONE, false>(a, s);
+        case MYDET_ACT_LEAKY: return res ? launch_w4<MYDET_ACT_LEAKY, true>(a, groups, ngroups, s) : launch_w4<MYDET_ACT_LEAKY, false>(a, groups, ngroups, s);
+        case MYDET_ACT_SWISH: return res ? launch_w4<MYDET_ACT_SWISH, true>(a, groups, ngroups, s) : launch_w4<MYDET_ACT_SWISH, false>(a, groups, ngroups, s);
+        default: return res ? launch_w4<MYDET_ACT_NONE, true>(a, groups, ngroups, s) : launch_w4<MYDET_ACT_NONE, false>(a, groups, ngroups, s);
     }
 }

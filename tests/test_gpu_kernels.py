@@ -163,6 +163,7 @@ def test_conv_winograd4_repeatable(dev, case):
     dict(B=17, Cin=64, Cout=512, H=32, W=32, act=1, residual=True),
     dict(B=24, Cin=136, Cout=200, H=37, W=37, act=2, residual=True),
     dict(B=32, Cin=256, Cout=512, H=40, W=40, act=1, residual=True),   # the headline's 40^2 layers: 1536 items + 64 cut 8 ways
+    dict(B=32, Cin=512, Cout=1024, H=20, W=20, act=1, residual=True),  # the headline's 20^2 layers: 512 + 256 (2 ways) + 32 (8 ways, ragged block row)
 ])
 def test_conv_winograd4_kcut_tail(dev, case, monkeypatch):
     """F(4x4) launches whose item count is whole rounds plus a small remainder run the remainder as K pieces + a fixup launch
