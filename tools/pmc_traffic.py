@@ -17,7 +17,8 @@ import sys
 from collections import defaultdict
 
 # (substring of the kernel name, family, FETCH_SIZE correction or None = uncalibrated: report x1 and x2)
-FAMILIES = [('conv_wino4_kernel', 'conv_wino4_gemm', 2.0), ('wino4_input_kernel', 'wino4_input', 2.0), ('wino4_weights', None, None),
+FAMILIES = [('conv_wino4_kernel', 'conv_wino4_gemm', 2.0), ('wino4_input_kernel', 'wino4_input', 2.0), ('wino4_fixup', 'wino4_fixup', 2.0),
+            ('wino4_weights', None, None),
             ('conv_wino_kernel', 'conv_wino', None), ('conv_igemm_kernel', 'conv_igemm', 2.0), ('conv_fixup', 'conv_igemm_fixup', 2.0),
             ('conv_stem', 'conv_stem', None), ('stem_dw', 'stem_dw', None), ('upsample_concat', 'upsample_concat', 2.0), ('decode_kernel', 'decode', 2.0),
             ('postprocess', 'postprocess', None), ('dwconv', 'dwconv', 2.0), ('sepconv_decode', 'sepconv_decode', 2.0),
@@ -59,12 +60,14 @@ for fam in fetch:
     else:
         e.update({'fetch_correction': corr, 'hbm_read_bytes_per_launch': corr * rd, 'hbm_bytes_per_launch': corr * rd + wr})
     out[fam] = e
-# bench.py times the F(4x4) Winograd layer as one unit (input-transform launch + GEMM launch): the same unit here.  The GEMM
-# kernel's loads are all 16-byte DMA (x2 correction); the input kernel's patch loads are dwords (x1 .. x2)
+# bench.py times the F(4x4) Winograd layer as one unit: the input-transform launch, the GEMM launch(es) -- whole items and, where
+# the K-cut tail applies, its pieces -- and the tail's fixup launch.  The same unit here: all their bytes over the number of
+# layers (= input-transform launches).  All of these kernels load 16 bytes per lane (x2 correction).
 if 'conv_wino4_gemm' in out and 'wino4_input' in out:
-    g, t = out['conv_wino4_gemm'], out['wino4_input']      # (round 4: the input kernel loads 16 bytes per lane too: x2)
-    out['conv_wino4'] = {'launches': g['launches'], 'unit': 'wino4_input_kernel + conv_wino4_kernel',
-                         'hbm_read_bytes_per_launch': g['hbm_read_bytes_per_launch'] + t['hbm_read_bytes_per_launch'],
-                         'hbm_write_bytes_per_launch': g['hbm_write_bytes_per_launch'] + t['hbm_write_bytes_per_launch'],
-                         'hbm_bytes_per_launch': g['hbm_bytes_per_launch'] + t['hbm_bytes_per_launch']}
+    layers = out['wino4_input']['launches']
+    parts = [out[k] for k in ('conv_wino4_gemm', 'wino4_input', 'wino4_fixup') if k in out]
+    rd = sum(e['hbm_read_bytes_per_launch'] * e['launches'] for e in parts) / layers
+    wr = sum(e['hbm_write_bytes_per_launch'] * e['launches'] for e in parts) / layers
+    out['conv_wino4'] = {'launches': layers, 'unit': 'per layer: wino4_input_kernel + conv_wino4_kernel (whole items + K pieces) + wino4_fixup_kernel',
+                         'hbm_read_bytes_per_launch': rd, 'hbm_write_bytes_per_launch': wr, 'hbm_bytes_per_launch': rd + wr}
 print(json.dumps(out, indent=1))
