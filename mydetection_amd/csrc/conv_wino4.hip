@@ -544,8 +544,8 @@ extern "C" int mydet_conv2d_wino4_f32(const float *x, int64_t ldx, const float *
     // K-cut tail.  Workgroups are equal, the chip holds `slots` of them, so T items cost ceil(T / slots) rounds: 1600 items
     // (256->512 @40^2, batch 32) pay four rounds for 3.125.  The last blocks of the item order (the fewest that bring the rest
     // down to whole rounds) are instead cut along K in up to two groups -- each about one short round -- and summed by small
-    // launches: 64 items 8 ways @40^2, 128 items 4 ways @80^2, 256 items 2 ways + 32 items 8 ways @20^2.  Not when K is
-    // short or the groups would cost about the round they replace.
+    // launches: 64 items 8 ways @40^2, 256 items 2 ways + 32 items 8 ways @20^2.  Not when K is short, the groups would cost
+    // about the round they replace, or there are more than four whole rounds.
     a.tail_id0 = a.nblk; a.tail_blocks = 0; a.tail_stride = 64; a.splits = 1;
     a.part = ws + (mydet_wino4_workspace_bytes(B, H, W, Cin) - TAIL_BYTES) / 4;
     W4Args groups[3];
@@ -571,7 +571,10 @@ extern "C" int mydet_conv2d_wino4_f32(const float *x, int64_t ldx, const float *
             const int64_t rows = (row + 1) * RM <= a.nmb ? RM : a.nmb - row * RM;
             return (int)(rows * RN);
         };
-        if (tail_on > 0 && whole > 0 && T > whole && nk >= 8) {
+        // (after many whole rounds the workgroups no longer finish together and the last partial round is cheap already:
+        // 128->256 @80^2, 6.25 rounds, ran 0.6 % of the headline FASTER without its tail -- up to four whole rounds only)
+        const char *re = getenv("MYDET_W4_TAIL_MAXR");
+        if (tail_on > 0 && whole > 0 && T > whole && nk >= 8 && whole / slots <= (re ? atoi(re) : 4)) {
             int64_t cut = 0;
             int64_t first = NB;                        // first block of the tail: the fewest blocks that leave whole rounds
             while (T - cut > whole && first > 0) cut += items_of(--first);
