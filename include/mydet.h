@@ -278,6 +278,11 @@ int64_t mydet_wino4_workspace_bytes(int B, int H, int W, int Cin);
 int mydet_conv2d_wino4_f32(const float *x, int64_t ldx, const float *u, const float *scale, const float *shift,
                            const float *residual, int64_t ldr, float *ws, int64_t ws_bytes, float *y, int64_t ldy,
                            int B, int H, int W, int Cin, int Cout, int act, void *stream);
+/* Test hook (host only, no GPU call): the K-cut tail plan mydet_conv2d_wino4_f32 uses on a chip that holds `slots` of its
+ * workgroups (2 per CU).  Items are ids of 64-id blocks; out[0] = ids covered by the main launch, out[1] = groups, then per
+ * group {first id, blocks, ids taken per block, cuts along K, scratch offset in KiB} (out: 17 ints).  Returns the number of
+ * groups (0 = no tail) or a negative MYDET_E_*.  No reference counterpart. */
+int mydet_wino4_tail_plan(int B, int H, int W, int Cin, int Cout, int slots, int32_t *out);
 
 /* Bilinear resize of one 8-bit RGB image [H][W][3] -> [oh][ow][3] (rows src_row_bytes / dst_row_bytes apart, so the
  * result can land inside a padded batch buffer), bit-exact with PIL.Image.resize(size, BILINEAR), i.e. with the

@@ -451,6 +451,73 @@ __global__ void wino4_weights_kernel(const float *w, int Cout, int Cin, int Cout
         }
 }
 
+// K-cut tail plan (host only; also exported as mydet_wino4_tail_plan so that the rule is testable without a GPU).
+// Workgroups are equal, the chip holds `slots` of them, so T items cost ceil(T / slots) rounds: 1600 items (256->512 @40^2,
+// batch 32) pay four rounds for 3.125.  The last blocks of the item order (the fewest that bring the rest down to whole
+// rounds) are instead cut along K in up to two groups -- each about one short round -- and summed by small launches: 64 items
+// 8 ways @40^2, 256 items 2 ways + 32 items 8 ways @20^2.  Not when K is short, the groups would cost about the round they
+// replace, or there are more than four whole rounds.
+struct TailGroup { int id0, blocks, stride, splits; int64_t part_bytes; };
+
+int plan_tail(int nmb, int ntn, int nbn, int rn_log2, int Cin, int slots, TailGroup *groups) {
+    int ngroups = 0;
+    const char *te = getenv("MYDET_W4_TAIL");         // tuning / tests: minimum cut count of the last group, 0 = no tail (read per call)
+    const int tail_on = te ? atoi(te) : 4;
+    const char *ge = getenv("MYDET_W4_TAIL_GROUPS");
+    const int max_groups = ge ? atoi(ge) : 2;
+    const int64_t T = (int64_t)nmb * ntn;
+    const int64_t whole = T / slots * slots;
+    const int RM = 64 >> rn_log2, RN = 1 << rn_log2, nk = Cin >> 2;
+    const int64_t nbm = (nmb + RM - 1) / RM;
+    const int64_t NB = nbm * nbn;
+    auto items_of = [&](int64_t blk) {
+        const int64_t row = blk / nbn, col = blk % nbn;
+        const int64_t rows = (row + 1) * RM <= nmb ? RM : nmb - row * RM;
+        const int64_t cols = (col + 1) * RN <= ntn ? RN : ntn - col * RN;
+        return rows * cols;
+    };
+    auto stride_of = [&](int64_t blk) {                // valid ids of a block are w = r * RN + c, r < rows: a prefix when no column is cut
+        const int64_t row = blk / nbn;
+        const int64_t rows = (row + 1) * RM <= nmb ? RM : nmb - row * RM;
+        return (int)(rows * RN);
+    };
+    // (after many whole rounds the workgroups no longer finish together and the last partial round is cheap already:
+    // 128->256 @80^2, 6.25 rounds, ran 0.6 % of the headline FASTER without its tail -- up to four whole rounds only)
+    const char *re = getenv("MYDET_W4_TAIL_MAXR");
+    if (!(tail_on > 0 && whole > 0 && T > whole && nk >= 8 && whole / slots <= (re ? atoi(re) : 4))) return 0;
+    int64_t cut = 0;
+    int64_t first = NB;                                // first block of the tail: the fewest blocks that leave whole rounds
+    while (T - cut > whole && first > 0) cut += items_of(--first);
+    // groups in id order.  While what is left is more than half a round, a group of up to half a round is cut two ways;
+    // the rest is one group cut slots / items ways (at most 8, at least 4 K stages per piece).
+    int64_t blk = first, left = cut, used = 0;
+    double cost = 0.0;                                 // in rounds: 1 / splits per group + ~0.12 for its two launches
+    while (left > 0) {
+        if (ngroups == 3 || ngroups == max_groups) return 0;
+        int64_t n = 0;
+        int nb = 0, stride = 0;
+        const bool last = left * 2 <= slots;
+        while (blk + nb < NB && (last || n + items_of(blk + nb) <= slots / 2)) {
+            n += items_of(blk + nb);
+            stride = stride_of(blk + nb) > stride ? stride_of(blk + nb) : stride;
+            ++nb;
+        }
+        int splits = last ? (int)(slots / (n > 0 ? n : 1)) : 2;
+        splits = splits > 8 ? 8 : splits;
+        if (splits > nk / 4) splits = nk / 4;
+        if (n == 0 || splits < 2 || (last && splits < tail_on)) return 0;
+        groups[ngroups] = TailGroup{(int)(blk * 64), nb, stride, splits, used};
+        used += (int64_t)nb * stride * splits * (16 * 64 * NW * 16);
+        if (used > TAIL_BYTES) return 0;
+        cost += 1.0 / splits + 0.12;
+        ++ngroups;
+        blk += nb; left -= n;
+    }
+    // (0.9 admits a two-way group + an eight-way group = 0.865: 512->1024 @20^2, 800 items = one round + 256 + 32)
+    const char *ce = getenv("MYDET_W4_TAIL_COST");
+    return cost > (ce ? atof(ce) : 0.9) ? 0 : ngroups;
+}
+
 template <int ACT, bool RES>
 int launch_w4(W4Args a, const W4Args *groups, int ngroups, hipStream_t stream) {
     static unsigned long long attr_set = 0;                      // > 64 KiB of dynamic LDS needs the opt-in once per device
@@ -507,6 +574,30 @@ extern "C" int64_t mydet_wino4_workspace_bytes(int B, int H, int W, int Cin) {
     return (MT + TILES - 1) / TILES * (Cin >> 2) * V_BYTES + TAIL_BYTES;
 }
 
+/* Test hook (host only, no GPU call): the K-cut tail plan mydet_conv2d_wino4_f32 would use on a chip of `slots` resident
+ * workgroups.  out[0] = ids of the main launch, out[1] = groups, then per group {first id, blocks, ids per block, cuts,
+ * scratch offset in KiB}; returns the number of groups or a negative MYDET_E_*. */
+extern "C" int mydet_wino4_tail_plan(int B, int H, int W, int Cin, int Cout, int slots, int32_t *out) {
+    if (!out || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || slots <= 0 || (Cin & 3) || (Cout & 3)) return MYDET_E_BADARG;
+    const int64_t MT = (int64_t)B * ((H + 3) / 4) * ((W + 3) / 4);
+    if (MT > (int64_t)1 << 30) return MYDET_E_UNSUPP;
+    const int ntn = (Cout + CH - 1) / CH, nmb = (int)((MT + TILES - 1) / TILES);
+    int rn_log2 = 0;
+    while ((1 << rn_log2) < ntn && rn_log2 < 3) ++rn_log2;
+    const int nbn = (ntn + (1 << rn_log2) - 1) >> rn_log2;
+    const int64_t nbm = (nmb + (64 >> rn_log2) - 1) / (64 >> rn_log2);
+    if (nbm * nbn * 64 > 0x7FFFFFFF) return MYDET_E_UNSUPP;
+    TailGroup plan[3];
+    const int ng = plan_tail(nmb, ntn, nbn, rn_log2, Cin, slots, plan);
+    out[0] = ng ? plan[0].id0 : (int)(nbm * nbn * 64);
+    out[1] = ng;
+    for (int g = 0; g < ng; ++g) {
+        out[2 + 5 * g] = plan[g].id0; out[3 + 5 * g] = plan[g].blocks; out[4 + 5 * g] = plan[g].stride;
+        out[5 + 5 * g] = plan[g].splits; out[6 + 5 * g] = (int)(plan[g].part_bytes >> 10);
+    }
+    return ng;
+}
+
 extern "C" int mydet_conv2d_wino4_f32(const float *x, int64_t ldx, const float *u, const float *scale, const float *shift,
                                       const float *residual, int64_t ldr, float *ws, int64_t ws_bytes, float *y, int64_t ldy,
                                       int B, int H, int W, int Cin, int Cout, int act, void *stream) {
@@ -541,76 +632,16 @@ extern "C" int mydet_conv2d_wino4_f32(const float *x, int64_t ldx, const float *
     if (nbm * a.nbn * 64 > 0x7FFFFFFF) return MYDET_E_UNSUPP;
     a.nblk = (int)(nbm * a.nbn * 64);
     if ((MT + TILES - 1) / TILES > 0x7FFFFFFF || (Cin + 31) / 32 > 65535) return MYDET_E_UNSUPP;
-    // K-cut tail.  Workgroups are equal, the chip holds `slots` of them, so T items cost ceil(T / slots) rounds: 1600 items
-    // (256->512 @40^2, batch 32) pay four rounds for 3.125.  The last blocks of the item order (the fewest that bring the rest
-    // down to whole rounds) are instead cut along K in up to two groups -- each about one short round -- and summed by small
-    // launches: 64 items 8 ways @40^2, 256 items 2 ways + 32 items 8 ways @20^2.  Not when K is short, the groups would cost
-    // about the round they replace, or there are more than four whole rounds.
+    // K-cut tail (plan_tail)
     a.tail_id0 = a.nblk; a.tail_blocks = 0; a.tail_stride = 64; a.splits = 1;
     a.part = ws + (mydet_wino4_workspace_bytes(B, H, W, Cin) - TAIL_BYTES) / 4;
+    TailGroup plan[3];
+    const int ngroups = plan_tail(a.nmb, a.ntn, a.nbn, a.rn_log2, Cin, 2 * mydet_cu_count(), plan);
     W4Args groups[3];
-    int ngroups = 0;
-    {
-        const char *te = getenv("MYDET_W4_TAIL");     // tuning / tests: minimum cut count of the last group, 0 = no tail (read per call)
-        const int tail_on = te ? atoi(te) : 4;
-        const char *ge = getenv("MYDET_W4_TAIL_GROUPS");
-        const int max_groups = ge ? atoi(ge) : 2;
-        const int slots = 2 * mydet_cu_count();
-        const int64_t T = (int64_t)a.nmb * a.ntn;
-        const int64_t whole = T / slots * slots;
-        const int RM = 64 >> a.rn_log2, RN = 1 << a.rn_log2, nk = Cin >> 2;
-        const int64_t NB = nbm * a.nbn;
-        auto items_of = [&](int64_t blk) {
-            const int64_t row = blk / a.nbn, col = blk % a.nbn;
-            const int64_t rows = (row + 1) * RM <= a.nmb ? RM : a.nmb - row * RM;
-            const int64_t cols = (col + 1) * RN <= a.ntn ? RN : a.ntn - col * RN;
-            return rows * cols;
-        };
-        auto stride_of = [&](int64_t blk) {            // valid ids of a block are w = r * RN + c, r < rows: a prefix when no column is cut
-            const int64_t row = blk / a.nbn;
-            const int64_t rows = (row + 1) * RM <= a.nmb ? RM : a.nmb - row * RM;
-            return (int)(rows * RN);
-        };
-        // (after many whole rounds the workgroups no longer finish together and the last partial round is cheap already:
-        // 128->256 @80^2, 6.25 rounds, ran 0.6 % of the headline FASTER without its tail -- up to four whole rounds only)
-        const char *re = getenv("MYDET_W4_TAIL_MAXR");
-        if (tail_on > 0 && whole > 0 && T > whole && nk >= 8 && whole / slots <= (re ? atoi(re) : 4)) {
-            int64_t cut = 0;
-            int64_t first = NB;                        // first block of the tail: the fewest blocks that leave whole rounds
-            while (T - cut > whole && first > 0) cut += items_of(--first);
-            // groups in id order.  While what is left is more than half a round, a group of up to half a round is cut two ways;
-            // the rest is one group cut slots / items ways (at most 8, at least 4 K stages per piece).
-            int64_t blk = first, left = cut, used = 0;
-            double cost = 0.0;                         // in rounds: 1 / splits per group + ~0.12 for its two launches
-            bool ok = true;
-            while (left > 0 && ok) {
-                if (ngroups == 3 || ngroups == max_groups) { ok = false; break; }
-                W4Args t = a;
-                t.tail_id0 = (int)(blk * 64);
-                int64_t n = 0;
-                int nb = 0, stride = 0;
-                const bool last = left * 2 <= slots;
-                while (blk + nb < NB && (last || n + items_of(blk + nb) <= slots / 2)) {
-                    n += items_of(blk + nb);
-                    stride = stride_of(blk + nb) > stride ? stride_of(blk + nb) : stride;
-                    ++nb;
-                }
-                int splits = last ? (int)(slots / n) : 2;
-                splits = splits > 8 ? 8 : splits;
-                if (splits > nk / 4) splits = nk / 4;
-                if (n == 0 || splits < 2 || (last && splits < tail_on)) { ok = false; break; }
-                t.tail_blocks = nb; t.tail_stride = stride; t.splits = splits;
-                t.part = a.part + used / 4;
-                used += (int64_t)nb * stride * splits * (16 * 64 * NW * 16);
-                if (used > TAIL_BYTES) { ok = false; break; }
-                cost += 1.0 / splits + 0.12;
-                groups[ngroups++] = t;
-                blk += nb; left -= n;
-            }
-            // (0.9 admits a two-way group + an eight-way group = 0.865: 512->1024 @20^2, 800 items = one round + 256 + 32)
-            const char *ce = getenv("MYDET_W4_TAIL_COST");
-            if (!ok || cost > (ce ? atof(ce) : 0.9)) ngroups = 0;
-        }
+    for (int g = 0; g < ngroups; ++g) {
+        groups[g] = a;
+        groups[g].tail_id0 = plan[g].id0; groups[g].tail_blocks = plan[g].blocks; groups[g].tail_stride = plan[g].stride;
+        groups[g].splits = plan[g].splits; groups[g].part = a.part + plan[g].part_bytes / 4;
     }
     hipStream_t s = (hipStream_t)stream;
     const bool res = residual != nullptr;

@@ -473,3 +473,75 @@ def test_bench_parity_check_logic():
         else:
             r2['class_idx'][1, 2] += 1
         assert not bench.parity_check(cand, r2, conf, nms, oracle_cand=None, images=B)['ok'], tamper
+
+
+def _w4_items(B, H, W, Cout):
+    """(item validity by id, ids) of the F(4x4) GEMM launch, as conv_wino4.hip maps ids to (tile block, channel block)."""
+    MT = B * ((H + 3) // 4) * ((W + 3) // 4)
+    nmb, ntn = (MT + 31) // 32, (Cout + 31) // 32
+    rn = 0
+    while (1 << rn) < ntn and rn < 3:
+        rn += 1
+    RN, RM = 1 << rn, 64 >> rn
+    nbn, nbm = (ntn + RN - 1) // RN, (nmb + RM - 1) // RM
+
+    def valid(i):
+        bi, w = i >> 6, i & 63
+        mb, nb = (bi // nbn) * RM + (w >> rn), (bi % nbn) * RN + (w & (RN - 1))
+        return mb < nmb and nb < ntn
+    return valid, nbm * nbn * 64, nmb * ntn
+
+
+def test_wino4_tail_plan_covers_every_item_once():
+    """The K-cut tail plan of the F(4x4) GEMM launch (mydet_wino4_tail_plan: host only).  For a spread of shapes -- the three
+    models' layers, ragged maps and channel counts, other chip sizes -- the main launch and the groups together take every
+    valid item exactly once, the main launch is whole rounds of the chip (less at most a block), every group fits the chip once, pieces keep at
+    least four K stages, and the partial-tile scratch areas are disjoint and inside the 64 MiB the workspace reserves."""
+    from mydetection_amd import _lib
+    lib = _lib.lib()
+    shapes = [(32, 80, 80, 128, 256), (32, 40, 40, 256, 512), (32, 20, 20, 512, 1024), (32, 160, 160, 64, 128),
+              (32, 64, 64, 128, 256), (32, 32, 32, 256, 512), (32, 16, 16, 512, 1024), (17, 32, 32, 64, 512),
+              (24, 37, 37, 136, 200), (16, 20, 20, 88, 88), (32, 10, 10, 88, 88), (1, 32, 32, 256, 512)]
+    rng = __import__('random').Random(4)
+    for _ in range(300):
+        shapes.append((rng.randint(1, 40), rng.randint(5, 90), rng.randint(5, 90), 4 * rng.randint(8, 160), 4 * rng.randint(2, 260)))
+    seen_tail = 0
+    for B, H, W, Cin, Cout in shapes:
+        for slots in (512, 256, 608):
+            out = (ctypes.c_int32 * 17)()
+            ng = lib.mydet_wino4_tail_plan(B, H, W, Cin, Cout, slots, out)
+            assert 0 <= ng <= 3, (B, H, W, Cin, Cout, ng)
+            valid, nids, T = _w4_items(B, H, W, Cout)
+            if ng == 0:
+                assert out[0] == nids
+                continue
+            seen_tail += 1
+            taken = [0] * nids
+            for i in range(out[0]):
+                taken[i] += 1
+            main = sum(1 for i in range(out[0]) if valid(i))       # whole rounds, short of them by less than one block
+            assert T // slots * slots - 64 < main <= T // slots * slots and out[0] % 64 == 0
+            areas, nk = [], Cin // 4
+            for g in range(ng):
+                id0, blocks, stride, splits, off_kb = out[2 + 5 * g: 7 + 5 * g]
+                assert id0 % 64 == 0 and 1 <= stride <= 64 and 2 <= splits <= 8 and nk // splits >= 4
+                n = 0
+                for b in range(blocks):
+                    for w in range(64):
+                        i = id0 + 64 * b + w
+                        if w < stride:
+                            taken[i] += 1
+                            n += valid(i)
+                        else:
+                            assert not valid(i), 'a valid item lies beyond the ids the group takes from its block'
+                assert 0 < n * splits <= slots
+                areas.append((off_kb, off_kb + blocks * stride * splits * 64))          # 64 KiB per (slot, piece)
+            assert all(t == 1 if valid(i) else t <= 1 for i, t in enumerate(taken)), (B, H, W, Cin, Cout, slots)
+            areas.sort()
+            assert areas[0][0] == 0 and areas[-1][1] <= 64 * 1024
+            assert all(a[1] <= b[0] for a, b in zip(areas, areas[1:]))
+    assert seen_tail >= 20                       # the rule does trigger on this set (the 40^2 / 20^2 layers at least)
+    out = (ctypes.c_int32 * 17)()
+    assert lib.mydet_wino4_tail_plan(32, 40, 40, 256, 512, 512, out) == 1 and list(out[2:6]) == [1536, 2, 32, 8]
+    assert lib.mydet_wino4_tail_plan(32, 20, 20, 512, 1024, 512, out) == 2 and list(out[2:6]) == [512, 4, 64, 2] and list(out[7:11]) == [768, 4, 8, 8]
+    assert lib.mydet_wino4_tail_plan(32, 80, 80, 128, 256, 512, out) == 0          # six whole rounds: no tail
