@@ -458,8 +458,10 @@ int launch(const ConvArgs &a0, int slots, hipStream_t stream) {
     const size_t need = (size_t)rem * (splits > 0 ? splits : 0) * BM * BN * sizeof(float);
     // only long-K layers: on short ones the two extra launches cost more than the spared round
     // (shorter K -- 8 or 16 slabs, the 256->128 / 512->256 1x1 layers of YOLOv3 -- measured 1-3 % SLOWER with the tail cut)
+    // and at most four whole rounds: after more, the workgroups no longer finish together and the partial last round is cheap
+    // already (128->256 stride 2 @160^2, 6.25 rounds: headline 1 454 -> 1 459 images/s without its tail; the same holds for F(4x4))
     const bool split = rem > 0 && splits >= 2 && a0.ws && need <= a0.ws_bytes &&
-                       (small || (nk >= 32 && rounds >= 2 && rem * 2 <= slots));
+                       (small || (nk >= 32 && rounds >= 2 && rounds <= 4 && rem * 2 <= slots));
     a.tile0 = 0; a.splits = 1;
     a.nblk = split ? total - rem : total;
     int rc = 0;
