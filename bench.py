@@ -466,7 +466,8 @@ def main():
         kernels = {'conv_igemm': ('conv_igemm_kernel (implicit GEMM, v_mfma_f32_32x32x2_f32)', 1.0),
                    'conv_wino': ('conv_wino_kernel (fused Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32)', 2.25),
                    'conv_wino4': ('wino4_input_kernel + conv_wino4_kernel (Winograd F(4x4,3x3): input-transform launch + DMA-fed '
-                                  'v_mfma_f32_16x16x4_f32 GEMMs with fused output transform; timed as one unit)', 4.0)}
+                                  'v_mfma_f32_16x16x4_f32 GEMMs with fused output transform, + the K-cut tail\'s piece and fixup '
+                                  'launches where the item count leaves a remainder; one layer timed as one unit)', 4.0)}
         fams = {k: summ[k] for k in kernels if k in summ}
         dom = max(fams, key=lambda k: fams[k][1])
         n_k, ms_k, flops_k = fams[dom]
