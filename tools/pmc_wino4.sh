@@ -12,6 +12,7 @@ for pmc in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" \
            "SQ_WAVE_CYCLES SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INST_CYCLES_VMEM" \
            "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_SALU SQ_ACTIVE_INST_VALU"; do
   i=$((i+1))
+  rm -rf $R/gpurun_out/pmc_w4/p$i; mkdir -p $R/gpurun_out/pmc_w4
   timeout -k 5 $T rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $R/gpurun_out/pmc_w4/p$i -- python3 $R/tools/bench_conv.py $ARGS > $R/gpurun_out/pmc_w4/p$i.log 2>&1 || { tail -5 $R/gpurun_out/pmc_w4/p$i.log; exit 1; }
   python3 $R/tools/pmc_kernel.py $R/gpurun_out/pmc_w4/p$i conv_wino4_kernel
 done
