@@ -482,6 +482,23 @@ __global__ __launch_bounds__(1024) void se_fused_kernel(float *partial, int S, i
     const int b = blockIdx.x, tid = threadIdx.x;
     const int Q = C >> 2;
     float *pb = partial + (int64_t)b * (S + 1) * C;
+    // The kernel is a chain of dependent round trips (slice sums -> mean -> reduce-conv weights -> expand-conv weights) on
+    // one CU per image.  The weights do not depend on the data: the first 512 input channels of this wave's two reduce-conv
+    // rows and the first eight rows of this thread's expand-conv column are requested here, before the first barrier, and
+    // consumed in place of the same loads below (same values, same order of additions).
+    const int pwave = tid >> 6, plane = tid & 63;
+    float p0[8], p1[8], q2[8];
+    {
+        const int o0 = pwave < Cse ? pwave : 0, o1 = pwave + 16 < Cse ? pwave + 16 : o0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int c = plane + 64 * t;
+            p0[t] = c < C ? w1[(int64_t)o0 * C + c] : 0.f;
+            p1[t] = c < C ? w1[(int64_t)o1 * C + c] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q2[j] = (tid < C && j < Cse) ? w2t[(int64_t)j * C + tid] : 0.f;
+    }
     const int q = tid % Q, ph = tid / Q;
     if (ph < P) {
         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
@@ -524,6 +541,24 @@ __global__ __launch_bounds__(1024) void se_fused_kernel(float *partial, int S, i
         const float *wr0 = w1 + (int64_t)o0 * C, *wr1 = w1 + (int64_t)o1 * C;
         float a[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         int c = lane;
+        if (o0 == wave) {                              // first pair of rows: the two prefetched groups of four strides
+            if (c + 192 < C) {
+                const float m0 = mean[c], m1 = mean[c + 64], m2 = mean[c + 128], m3 = mean[c + 192];
+                a[0][0] = fmaf(p0[0], m0, a[0][0]); a[1][0] = fmaf(p1[0], m0, a[1][0]);
+                a[0][1] = fmaf(p0[1], m1, a[0][1]); a[1][1] = fmaf(p1[1], m1, a[1][1]);
+                a[0][2] = fmaf(p0[2], m2, a[0][2]); a[1][2] = fmaf(p1[2], m2, a[1][2]);
+                a[0][3] = fmaf(p0[3], m3, a[0][3]); a[1][3] = fmaf(p1[3], m3, a[1][3]);
+                c += 256;
+                if (c + 192 < C) {
+                    const float n0 = mean[c], n1 = mean[c + 64], n2 = mean[c + 128], n3 = mean[c + 192];
+                    a[0][0] = fmaf(p0[4], n0, a[0][0]); a[1][0] = fmaf(p1[4], n0, a[1][0]);
+                    a[0][1] = fmaf(p0[5], n1, a[0][1]); a[1][1] = fmaf(p1[5], n1, a[1][1]);
+                    a[0][2] = fmaf(p0[6], n2, a[0][2]); a[1][2] = fmaf(p1[6], n2, a[1][2]);
+                    a[0][3] = fmaf(p0[7], n3, a[0][3]); a[1][3] = fmaf(p1[7], n3, a[1][3]);
+                    c += 256;
+                }
+            }
+        }
         for (; c + 192 < C; c += 256) {
             const float m0 = mean[c], m1 = mean[c + 64], m2 = mean[c + 128], m3 = mean[c + 192];
             a[0][0] = fmaf(wr0[c], m0, a[0][0]); a[1][0] = fmaf(wr1[c], m0, a[1][0]);
@@ -552,6 +587,11 @@ __global__ __launch_bounds__(1024) void se_fused_kernel(float *partial, int S, i
     for (int c = tid; c < C; c += 1024) {
         float e[4] = {0.f, 0.f, 0.f, 0.f};
         int k = 0;
+        if (c == tid && Cse >= 8) {                    // the prefetched first eight rows
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j & 3] = fmaf(q2[j], hid[j], e[j & 3]);
+            k = 8;
+        }
         for (; k + 7 < Cse; k += 8) {
             float w[8];
 #pragma unroll
