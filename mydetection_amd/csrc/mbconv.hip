@@ -248,6 +248,13 @@ __global__ __launch_bounds__(256, 4) void dwconv_tile_kernel(const DwTArgs p) {
         const int tap = tid / CQ, q = min(q0 + tid % CQ, Q - 1);
         *reinterpret_cast<f32x4 *>(&wl[tid * 4]) = *reinterpret_cast<const f32x4 *>(p.w + (int64_t)tap * p.C + q * 4);
     }
+    // the BatchNorm terms of this thread's channel quad: requested with the patch, not after the taps loop
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (p.scale) {
+        const int qs = min(q0 + tid % CQ, Q - 1);
+        sc = *reinterpret_cast<const f32x4 *>(p.scale + qs * 4);
+        sh = *reinterpret_cast<const f32x4 *>(p.shift + qs * 4);
+    }
     // input patch -> LDS, one batch
     f32x4 v[NL];
 #pragma unroll
@@ -292,11 +299,6 @@ __global__ __launch_bounds__(256, 4) void dwconv_tile_kernel(const DwTArgs p) {
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
     const int oh = oh0 + row;
     if (q < Q && oh < p.Ho) {
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        if (p.scale) {
-            sc = *reinterpret_cast<const f32x4 *>(p.scale + q * 4);
-            sh = *reinterpret_cast<const f32x4 *>(p.shift + q * 4);
-        }
         float *yp = p.y + (((int64_t)b * p.Ho + oh) * p.Wo + ow0 + strip * 4) * p.ldy + q * 4;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
