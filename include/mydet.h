@@ -393,6 +393,11 @@ int mydet_sepconv_decode_retina_f32(int n, const mydet_sepconv_decode_node *node
 int mydet_bboxes_iou_f32(const float *a, int Na, const float *b, int Nb, int xyxy,
                          float *iou, void *stream);
 
+/* Centre format -> corner format, utils/bbox_ops.py:309-316: n rows of `width` >= 4 floats; columns 0..3 of a row
+ * become (cx - w/2, cy - h/2, cx + w/2, cy + h/2) with the reference's float32 operation order (bit-exact), columns
+ * 4.. are copied.  Out of place (in == out is allowed: a thread reads its row before it writes it). */
+int mydet_cxcywh_to_x1y1x2y2_f32(const float *cxcywh, float *x1y1x2y2, int64_t n, int width, void *stream);
+
 /* In-place undo of resize/pad on cxcywh boxes; utils/structures.py:175-189. */
 int mydet_bboxes_to_original_f32(float *bbox, int64_t n, float ori_w, float ori_h,
                                  float tl_x, float tl_y, float imw, float imh, void *stream);

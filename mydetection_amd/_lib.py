@@ -58,6 +58,7 @@ SIGNATURES = {
     'mydet_detections_to_json_f64': [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr],
     'mydet_resize_bilinear_u8': [c_ptr, c_int, c_int, c_i64, c_ptr, c_int, c_int, c_i64, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr],
     'mydet_preprocess_u8_f32': [c_ptr, c_int, c_int, c_int, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr],
+    'mydet_cxcywh_to_x1y1x2y2_f32': [c_ptr, c_ptr, c_i64, c_int, c_ptr],
     'mydet_bboxes_to_original_f32': [c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_ptr],
 }
 

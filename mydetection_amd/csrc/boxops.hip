@@ -2,6 +2,7 @@
 // exact float32 operation order (built with -ffp-contract=off).
 //   bboxes_iou          utils/bbox_ops.py:6-49   (chainercv form: en = prod(tl < br))
 //   bboxes_to_original_ utils/structures.py:175-189
+//   cxcywh_to_x1y1x2y2  utils/bbox_ops.py:309-316
 #include "common.h"
 
 namespace {
@@ -43,6 +44,22 @@ __global__ __launch_bounds__(256) void to_original_kernel(float *bbox, int64_t n
     v[2] = v[2] / imw * ori_w;
     v[3] = v[3] / imh * ori_h;
     *reinterpret_cast<f32x4 *>(bbox + i * 4) = v;
+}
+
+// cxcywh -> x1y1x2y2 on rows of `width` >= 4 floats (utils/bbox_ops.py:309-316): columns 0..3 become
+// (cx - w/2, cy - h/2, cx + w/2, cy + h/2) in float32, one division and one add / subtract each, in that order;
+// further columns (the angle of a rotated box) are carried over unchanged.  One thread per row.
+__global__ __launch_bounds__(256) void to_corners_kernel(const float *in, float *out, int64_t n, int width) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float *p = in + i * width;
+    float *o = out + i * width;
+    const float cx = p[0], cy = p[1], hw = p[2] / 2.0f, hh = p[3] / 2.0f;
+    o[0] = cx - hw;
+    o[1] = cy - hh;
+    o[2] = cx + hw;
+    o[3] = cy + hh;
+    for (int j = 4; j < width; ++j) o[j] = p[j];
 }
 
 // Batched forms over fixed-size detection records (one row group of K slots per image, `count` valid):
@@ -137,6 +154,16 @@ extern "C" int mydet_bboxes_to_original_f32(float *bbox, int64_t n, float ori_w,
     if (!bbox || ((uintptr_t)bbox & 15)) return MYDET_E_BADARG;
     hipLaunchKernelGGL(to_original_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, bbox,
                        n, ori_w, ori_h, tl_x, tl_y, imw, imh);
+    return mydet_launch_status();
+}
+
+extern "C" int mydet_cxcywh_to_x1y1x2y2_f32(const float *cxcywh, float *x1y1x2y2, int64_t n, int width, void *stream) {
+    if (n < 0 || width < 4) return MYDET_E_BADARG;
+    if (n == 0) return 0;
+    if (!cxcywh || !x1y1x2y2) return MYDET_E_BADARG;
+    if ((n + 255) / 256 > 0x7fffffff) return MYDET_E_UNSUPP;
+    hipLaunchKernelGGL(to_corners_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cxcywh,
+                       x1y1x2y2, n, width);
     return mydet_launch_status();
 }
 

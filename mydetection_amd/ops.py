@@ -813,6 +813,20 @@ def bboxes_iou(a, b, xyxy=False):
     return out
 
 
+def cxcywh_to_x1y1x2y2(boxes):
+    """Rows (cx, cy, w, h[, ...]) -> (x1, y1, x2, y2[, ...]) in a new tensor of the same shape (include/mydet.h:
+    mydet_cxcywh_to_x1y1x2y2_f32); any leading dimensions, last dimension >= 4."""
+    require_gpu(boxes, 'cxcywh_to_x1y1x2y2')
+    if boxes.dtype != torch.float32:
+        raise TypeError(f'cxcywh_to_x1y1x2y2: float32 boxes expected, got {boxes.dtype}')
+    src = boxes.contiguous()
+    out = torch.empty_like(src)
+    width = src.shape[-1]
+    code = _lib.lib().mydet_cxcywh_to_x1y1x2y2_f32(_ptr(src), _ptr(out), src.numel() // width if width else 0, width, _stream())
+    _lib.check(code, 'mydet_cxcywh_to_x1y1x2y2_f32')
+    return out
+
+
 def bboxes_to_original_(bbox, pad_info):
     require_gpu(bbox, 'bboxes_to_original_')
     assert bbox.is_contiguous() and bbox.dtype == torch.float32 and bbox.shape[-1] == 4

@@ -19,11 +19,13 @@ def bboxes_iou(bboxes_a, bboxes_b, xyxy=False):
     return ops.bboxes_iou(bboxes_a, bboxes_b.to(bboxes_a.device), xyxy=xyxy)
 
 
-def cxcywh_to_x1y1x2y2(cxcywh: torch.tensor) -> torch.tensor:
+def cxcywh_to_x1y1x2y2(cxcywh):
+    """Centre-format boxes [..., >= 4] -> corner format, a new tensor (reference: utils/bbox_ops.py:309-316).  One
+    launch of the to-corners kernel of csrc/boxops.hip: float32 `c - s / 2`, `c + s / 2` in the reference's operation
+    order, so the result is bit-identical; extra columns (a rotated box's angle) are carried over."""
     assert cxcywh.shape[-1] >= 4
-    x1y1x2y2 = cxcywh.clone()
-    x1y1x2y2[..., 0] = (cxcywh[..., 0] - cxcywh[..., 2] / 2)
-    x1y1x2y2[..., 1] = (cxcywh[..., 1] - cxcywh[..., 3] / 2)
-    x1y1x2y2[..., 2] = (cxcywh[..., 0] + cxcywh[..., 2] / 2)
-    x1y1x2y2[..., 3] = (cxcywh[..., 1] + cxcywh[..., 3] / 2)
-    return x1y1x2y2
+    if not cxcywh.is_cuda:
+        if not torch.cuda.is_available():
+            raise RuntimeError('cxcywh_to_x1y1x2y2 runs on MI355X only; no GPU is visible')
+        cxcywh = cxcywh.cuda()
+    return ops.cxcywh_to_x1y1x2y2(cxcywh)

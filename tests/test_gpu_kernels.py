@@ -310,6 +310,25 @@ def test_bboxes_iou_golden(dev, golden):
     np.testing.assert_array_equal(out.cpu().numpy(), g['iou_xyxy'])
 
 
+def test_cxcywh_to_x1y1x2y2_golden(dev, golden):
+    """The to-corners kernel against the reference's own cxcywh_to_x1y1x2y2 outputs (utils/bbox_ops.py:309-316), bit for
+    bit; leading dimensions, a fifth column (carried over), the input untouched, an empty set."""
+    from mydetection_amd.utils.bbox_ops import cxcywh_to_x1y1x2y2
+    g = golden('bbox_ops')
+    for src, want in ((g['a'], g['a_xyxy']), (g['b'], g['b_xyxy'])):
+        t = torch.from_numpy(src).to(dev)
+        out = cxcywh_to_x1y1x2y2(t)
+        np.testing.assert_array_equal(out.cpu().numpy(), want)
+        np.testing.assert_array_equal(t.cpu().numpy(), src)                 # a new tensor, as the reference's clone()
+    both = torch.from_numpy(np.stack([g['a'][:30], g['b'][:30]])).to(dev)     # [2,30,4]
+    np.testing.assert_array_equal(cxcywh_to_x1y1x2y2(both).cpu().numpy(), np.stack([g['a_xyxy'][:30], g['b_xyxy'][:30]]))
+    five = np.concatenate([g['a'], np.arange(37, dtype=np.float32)[:, None]], 1)
+    out5 = cxcywh_to_x1y1x2y2(torch.from_numpy(five).to(dev)).cpu().numpy()
+    np.testing.assert_array_equal(out5[:, :4], g['a_xyxy'])
+    np.testing.assert_array_equal(out5[:, 4], five[:, 4])
+    assert tuple(cxcywh_to_x1y1x2y2(torch.empty((0, 4), device=dev)).shape) == (0, 4)
+
+
 def _yolo_cfg():
     from mydetection_amd.models.general import load_config
     cfg = load_config('yolov3_80')
