@@ -69,6 +69,12 @@ def parse_args(argv=None):
     ap.add_argument('--cpu-sample-batch', type=int, default=2)
     ap.add_argument('--cpu-repeats', type=int, default=5)
     ap.add_argument('--cpu-threads', type=int, default=16)
+    ap.add_argument('--parity-images', type=int, default=4,
+                    help='images of the timed batch the parity check compares with the CPU oracle forward (the CPU baseline sample '
+                         'covers the first --cpu-sample-batch of them; the rest cost one more oracle forward each)')
+    ap.add_argument('--dry-run-launch', action='store_true', help='with --gpus N > 1: print the launcher command as JSON and exit')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='headline run only: skip the short runs of the other single-GPU BASELINE configs (`other_configs`)')
     ap.add_argument('--lanes', default=None,
                     help="batch lanes of the replayed graph: a number, 'auto' (capture with 1 and 2, keep the faster: rank 0 decides "
                          "for all ranks), default: MYDET_LANES or the model's batch_lanes_hint -- the rule api.Detector uses")
@@ -78,20 +84,29 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+def launch_command(args, port, argv=None):
+    """The command `--gpus N` starts when no launcher did: one rank per GPU of this node over RCCL, rendezvous on 127.0.0.1
+    (the driver's own launcher line)."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+
+
 def self_launch(args):
     """--gpus N > 1 without a launcher: start N ranks (one process per GPU) BEFORE this process touches the GPU and
     exit with their return code.  torch.cuda.device_count() does not initialise HIP; nothing else here does either."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = launch_command(args, port)
+    if args.dry_run_launch:
+        print(json.dumps({'launch': cmd}))
+        return 0
     import torch
     have = torch.cuda.device_count()
     if have < args.gpus:
         sys.stderr.write(f'bench.py: --gpus {args.gpus} but this machine exposes {have} GPU(s); nothing was run\n')
         return 2
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
-           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     return subprocess.run(cmd, env=env).returncode
 
@@ -154,6 +169,28 @@ def cpu_baseline(config, cfg, size, sample_batch, repeats, max_threads=16):
         (bb.numpy(), ci.numpy(), sc.numpy())
 
 
+def oracle_candidates(config, cfg, size, lo, hi, max_threads=16):
+    """The CPU oracle's candidates (bbox, class_idx, score as numpy) of images [lo, hi) of the global synthetic batch:
+    the checker side of `parity_check` (never timed as the product)."""
+    import numpy as np
+    import torch
+    from mydetection_amd import synth
+    from mydetection_amd.models.general import state_dict_template
+    if hi <= lo:
+        return None
+    torch.set_num_threads(min(len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1), max_threads))
+    sd = synth.make_state_dict(state_dict_template(config), config)
+    x = synth.make_image_set(lo, hi, size, cfg['general.input_format'])
+    with torch.no_grad():
+        if config == 'yolov3_80':
+            from oracle import yolov3 as oy
+            bb, ci, sc = oy.forward(x, sd)
+        else:
+            from oracle import efficientdet as oe
+            bb, ci, sc = oe.forward(x, sd, config)
+    return bb.numpy(), ci.numpy(), sc.numpy()
+
+
 def parity_check(cand, rec, conf, nms, oracle_cand=None, images=2, extra_conf=()):
     """SURVEY 8d "parity gates run with every measurement": the first `images` images of the timed batch.
     * always: the GPU's detection records == the oracle's post_process (oracle/postprocess.py: reference filter / top-512
@@ -181,19 +218,20 @@ def parity_check(cand, rec, conf, nms, oracle_cand=None, images=2, extra_conf=()
         s_err = float(np.abs(sc - osc).max())
         b_err = float((np.abs(bb - obb) / (1e-4 + 1e-4 * np.abs(obb))).max())
         safe = equal = 0
+        kept = {f'conf_{conf}': [int(k) for k in count]}     # detections per image at every threshold: the sets are not empty
         for b in range(n):
             if opp.decision_margins(osc[b], oci[b], conf, eps=max(2.0 * s_err, 2e-6)) is None:
                 safe += 1
                 _, rc, _, ri = opp.post_process(obb[b], oci[b], osc[b], conf, nms)
                 k = int(count[b])
                 equal += int(k == len(ri) and np.array_equal(index[b, :k], ri) and np.array_equal(cls[b, :k], rc))
-        # the same comparison at the demo thresholds (fresh post-process launches on the step's candidates): at the AP
-        # threshold thousands of long-tailed scores crowd the top-512 cut, and few images are margin-safe there
+        extra = {f'conf_{conf}': f'{equal}/{safe}'}
+        # the same comparison at the other two thresholds (fresh post-process launches on the step's candidates)
         from mydetection_amd.utils.structures import batched_post_process
-        extra = {}
         for t in extra_conf:
             r_t = batched_post_process(*(c[:n] for c in cand), t, nms)
             cnt_t, idx_t, cls_t = (r_t[k].cpu().numpy() for k in ('count', 'index', 'class_idx'))
+            kept[f'conf_{t}'] = [int(k) for k in cnt_t]
             s_t = e_t = 0
             for b in range(n):
                 if opp.decision_margins(osc[b], oci[b], t, eps=max(2.0 * s_err, 2e-6)) is None:
@@ -203,8 +241,8 @@ def parity_check(cand, rec, conf, nms, oracle_cand=None, images=2, extra_conf=()
                     e_t += int(k == len(ri) and np.array_equal(idx_t[b, :k], ri) and np.array_equal(cls_t[b, :k], rc))
             extra[f'conf_{t}'] = f'{e_t}/{s_t}'
             safe, equal = safe + s_t, equal + e_t
-        if extra:
-            out['sets_equal_other_thresholds'] = extra
+        out['sets_equal_by_threshold'] = extra
+        out['detections_per_image'] = kept
         out.update({'max_score_err': s_err, 'max_box_err_over_tol': round(b_err, 4),
                     'class_id_agreement': round(float((ci == oci).mean()), 6),
                     'sets_equal': f'{equal}/{safe} margin-safe (image, threshold) pairs equal the oracle\'s detections (count, candidate indices, classes, order)',
@@ -279,6 +317,55 @@ def main():
                           'unit': 'ms', 'cases': nms_worst_cases(dev)}))
         return
 
+    ctx = {'dev': dev, 'world': world, 'rank': rank, 'dist_on': dist_on, 'rehearse': rehearse}
+    out, code = measure(args, ctx)
+    # the other single-GPU BASELINE configs, briefly, inside the driver's default command (the headline fields above stay as
+    # they are): configs[2], configs[3] and the 512 x 512 batch north_star asks for -- value, roofline and parity gate each
+    if (out is not None and world == 1 and not dist_on and args.config == 'yolov3_80' and args.size == 640 and args.batch is None
+            and not args.eager and not args.no_other_configs and not args.verify):
+        others = {}
+        for name, key, bsz, size in OTHER_CONFIGS:
+            a = argparse.Namespace(**vars(args))
+            a.config, a.batch, a.size = name, bsz, size
+            a.steps, a.warmup = min(args.steps, 10), min(args.warmup, 3)
+            a.no_cpu_baseline, a.parity_images, a.lanes = True, 2, None
+            t0 = time.perf_counter()
+            o, c = measure(a, ctx)
+            code = code or c
+            others[key] = brief_line(o, time.perf_counter() - t0)
+        out['other_configs'] = others
+    if out is not None:
+        print(json.dumps(out))
+    if dist_on:
+        torch.distributed.destroy_process_group()
+    sys.exit(code)
+
+
+OTHER_CONFIGS = (('efficientdet-d1', 'efficientdet-d1_b16_640', 16, 640),        # BASELINE configs[2]
+                 ('d1_fcs2_atss', 'd1_fcs2_atss_b32_640', 32, 640),             # BASELINE configs[3]
+                 ('yolov3_80', 'yolov3_80_b32_512', 32, 512))                   # north_star: 512 x 512 batches as well
+
+
+def brief_line(o, wall_s):
+    """The fields of a full line that `other_configs` carries."""
+    keep = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'hbm_frac', 'mfma_frac', 'step_frac', 'fused_min_frac',
+            'fused_min_bytes', 'step_algorithmic_bytes', 'launches_per_step', 'avg_launch_ms', 'traffic', 'traffic_source',
+            'algorithmic_bytes_per_launch')
+    return {'metric': o['metric'], 'value': o['value'], 'unit': o['unit'], 'ms_per_step': o['ms_per_step'], 'steps': o['steps'],
+            'warmup': o['warmup'], 'kernel_ms_per_step': o['kernel_ms_per_step'], 'batch_lanes': o['config']['batch_lanes'],
+            'launches_per_lane': o['launches_per_lane'], 'workload': o['config']['workload'], 'nms_p50_ms': o['nms_p50_ms'],
+            'roofline': {k: o['roofline'][k] for k in keep if k in o['roofline']},
+            'parity_check': o['parity_check'], 'wall_s': round(wall_s, 1)}
+
+
+def measure(args, ctx):
+    """One configuration measured as the module docstring says: returns (the JSON line as a dict or None on ranks > 0 and in
+    --profile mode, exit code: 0, 3 = --verify failed, 4 = the parity check failed)."""
+    import torch
+    dev, world, rank, dist_on, rehearse = ctx['dev'], ctx['world'], ctx['rank'], ctx['dist_on'], ctx['rehearse']
+    from mydetection_amd import _lib, ops, parallel, synth
+    from mydetection_amd.models.general import name_to_model
+    from mydetection_amd.utils.structures import batched_post_process
     import contextlib
     import io
     with contextlib.redirect_stdout(io.StringIO()):
@@ -313,7 +400,7 @@ def main():
                 n_l = 1
             lanes_rule = ('--lanes' if args.lanes is not None and str(want).isdigit() else
                           'MYDET_LANES' if str(want).isdigit() else 'model.batch_lanes_hint')
-            n_l, lanes_per_rank = parallel.agree_on_lanes(n_l, device=dev)     # (all ranks computed the same rule: a check)
+            n_l, lanes_per_rank = parallel.agree_on_lanes(n_l, device=dev)     # every rank applied the rule itself: a differing rank raises
             graphed = GraphedPath(model, x, conf, nms, lanes=n_l)
         assert graphed.lanes == n_l
 
@@ -334,8 +421,18 @@ def main():
             bb, ci, sc = model.forward_candidates(src)
             return batched_post_process(bb, ci, sc, conf, nms)
 
+    exchange = []                          # (start, end) HIP events around the all-gather of every step, on the launch stream
+
     def step():
-        return parallel.gather_detections(local_records(), always=rehearse, total=total)
+        local = local_records()
+        if not dist_on:
+            return local
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = parallel.gather_detections(local, always=rehearse, total=total)
+        e1.record()                        # the launch stream has waited for RCCL's stream here (blocking collective semantics)
+        exchange.append((e0, e1))
+        return out
 
     def barrier():
         if dist_on:
@@ -347,6 +444,7 @@ def main():
 
     if graphed is None:
         ops.TIMER = ops.KernelTimer(chain=True)                  # HIP events on the launch stream; one event per launch boundary
+    exchange.clear()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -376,12 +474,10 @@ def main():
                               'passes': passes, 'batch_lanes': graphed.lanes if graphed is not None else 1,
                               'mode': 'hipGraph replay' if graphed is not None else 'eager',
                               'note': 'profile run: every kernel of the step appears launches-per-step x passes times in the trace'}))
-        if dist_on:
-            torch.distributed.destroy_process_group()
-        return
+        return None, 0
 
     # the parity check's GPU side: the candidates and records of the LAST TIMED STEP (first images of this rank's shard)
-    n_pc = min(args.cpu_sample_batch, batch)
+    n_pc = max(1, min(args.parity_images, batch))
     with torch.no_grad():
         if graphed is not None:
             pc_cand = tuple(t[:n_pc].clone() for t in graphed.cand)
@@ -565,23 +661,40 @@ def main():
         'stages': stages,
         'nms_p50_ms': stages['postprocess']['p50_ms'],
     }
+    n_lanes = graphed.lanes if graphed is not None else 1
+    out['launches_per_lane'] = round(sum(v[0] for v in summ.values()) / args.steps / n_lanes, 1)
+    if dist_on:
+        out['rccl_ranks'] = torch.distributed.get_world_size()
+        out['exchange_backend'] = str(torch.distributed.get_backend())
+        out['exchange_ms_per_step'] = round(sum(a.elapsed_time(b) for a, b in exchange) / max(1, len(exchange)), 4)
+        out['exchange_note'] = ('HIP events on the launch stream around the one all_gather_into_tensor of the step (rank 0; it includes '
+                                'waiting for the slowest rank to arrive)')
     if verify is not None:
         out['verify'] = verify
     oracle_cand = None
+    code = 0
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'], oracle_cand = cpu_baseline(args.config, cfg, args.size, args.cpu_sample_batch, args.cpu_repeats, args.cpu_threads)
         out['cpu_baseline']['gpu_over_cpu'] = round(out['value'] / out['cpu_baseline']['value'], 1)
+    elif world > 1:
+        out['cpu_baseline'] = None
+        out['cpu_baseline_note'] = 'the CPU baseline is timed at N = 1 only (rank 0 of a 1-GPU run)'
     if rank == 0:
-        # parity gate of this very measurement: the timed step's records against the oracle
+        # parity gate of this very measurement: the timed step's records against the oracle.  The oracle's
+        # candidates of the first images: the CPU baseline's sample, then one more oracle forward for the remaining ones
+        import numpy as np
+        have = 0 if oracle_cand is None else min(oracle_cand[0].shape[0], n_pc)
+        more = oracle_candidates(args.config, cfg, args.size, lo + have, lo + n_pc, args.cpu_threads) if world == 1 else None
+        if world == 1:
+            parts = ([tuple(a[:have] for a in oracle_cand)] if have else []) + ([more] if more is not None else [])
+            oracle_cand = tuple(np.concatenate([p_[j] for p_ in parts]) for j in range(3))
         extra_conf = sorted({0.05, float(cfg.get('test.default_conf_thres', 0.5))} - {float(conf)})
         out['parity_check'] = parity_check(pc_cand, pc_rec, conf, nms, oracle_cand, images=n_pc, extra_conf=extra_conf)
-        print(json.dumps(out))
-    if dist_on:
-        torch.distributed.destroy_process_group()
     if verify is not None and rank == 0 and not verify['ok']:
-        sys.exit(3)
+        code = 3
     if rank == 0 and not out['parity_check']['ok']:
-        sys.exit(4)
+        code = code or 4
+    return (out if rank == 0 else None), code
 
 
 if __name__ == '__main__':

@@ -159,12 +159,20 @@ int mydet_upsample_concat_f32(const float *a, int64_t lda, int Ha, int Wa, int C
  * x_lo [B,H/2,W/2,ld_lo] (C_lo channels), x_hi [B,H,W,ld_hi] (C_hi channels), w [Cout][C_lo + C_hi] (OHWI, the
  * concatenation's channel order), y [B,H,W,ldy].  The concatenated tensor is never written; the sums run in the same k
  * order and tile shape as mydet_conv2d_igemm_f32 on the materialised tensor: bit-identical results.
- * workspace: as for mydet_conv2d_igemm_f32.  Needs H, W even, C_lo % 32 == 0, C_hi % 32 == 0, act == MYDET_ACT_LEAKY;
- * otherwise MYDET_E_UNSUPP and the caller uses mydet_upsample_concat_f32 + mydet_conv2d_igemm_f32. */
+ * workspace: as for mydet_conv2d_igemm_f32.  Needs H, W even, C_lo % 32 == 0, C_hi % 32 == 0, act == MYDET_ACT_LEAKY,
+ * AND a shape that mydet_conv2d_igemm_f32 itself would run on its 64 x 64 x 32 tile (the only tile this entry point is
+ * instantiated for: e.g. 64 < Cout, C_lo + C_hi <= 1024 or fewer than 1024 tiles of 128 x 128 -- YOLOv3's 768->256 and
+ * 384->128 layers); otherwise MYDET_E_UNSUPP and the caller uses mydet_upsample_concat_f32 + mydet_conv2d_igemm_f32,
+ * so the bit-identity above holds for every shape the call accepts. */
 int mydet_conv1x1_upcat_f32(const float *x_lo, int64_t ld_lo, int C_lo, const float *x_hi, int64_t ld_hi, int C_hi,
                             const float *w, const float *scale, const float *shift, void *workspace,
                             int64_t workspace_bytes, float *y, int64_t ldy, int B, int H, int W, int Cout, int act,
                             void *stream);
+
+/* Test / tuning hook: workgroups per CU the runtime reports (hipOccupancyMaxActiveBlocksPerMultiprocessor) for the
+ * base instance of conv_igemm tile configuration `cfg` (0, 1, 2, 3, 6, 8, 9); *assumed = the count the launch rule
+ * computes its rounds with.  Returns the count or a negative MYDET_E_*.  No reference counterpart. */
+int mydet_conv_igemm_occupancy(int cfg, int *assumed);
 
 /* Focus.forward of the Ultralytics backbone (external/ultralytics/common.py:79-86): 2x2 space-to-depth,
  *   y[b, yo, xo, g*C + c] = x[b, c, 2*yo + dy, 2*xo + dx],  g = 0:(dy 0, dx 0) 1:(dy 1, dx 0) 2:(dy 0, dx 1) 3:(dy 1, dx 1)
@@ -265,7 +273,7 @@ int mydet_postprocess_records_f32(const float *bbox, const int64_t *class_idx, c
 /* Winograd F(4x4,3x3) form of the same 3x3 stride-1 pad-1 conv + BN + act (+ residual) as mydet_conv2d_wino_f32
  * (4x fewer multiplies than the direct form; used for the deep layers with chip-filling grids).  `u` = the
  * transform-domain weights made by mydet_wino4_weights_f32 from the OHWI weight (mydet_wino4_weights_floats(Cout, Cin)
- * floats; Cin % 4 == 0).  `ws` = device scratch of at least mydet_wino4_workspace_bytes(B, H, W, Cin) bytes
+ * floats; Cin % 4 == 0).  `ws` = device scratch of at least mydet_wino4_workspace_bytes(B, H, W, Cin, Cout) bytes
  * (36 floats per 4x4-output tile and input channel: the transform-domain input, written by a first launch and
  * streamed by the second, plus 64 MiB for the partial tiles of the K-cut tail: when the workgroup count is whole rounds
  * of the chip plus a small remainder, the remainder runs as K pieces that a fourth launch sums in K order -- deterministic);
@@ -274,7 +282,9 @@ int mydet_postprocess_records_f32(const float *bbox, const int64_t *class_idx, c
  * Replaces the same reference code as mydet_conv2d_igemm_f32 (models/modules.py:69-73,94-95). */
 int64_t mydet_wino4_weights_floats(int Cout, int Cin);
 int mydet_wino4_weights_f32(const float *w, int Cout, int Cin, float *u, void *stream);
-int64_t mydet_wino4_workspace_bytes(int B, int H, int W, int Cin);
+int64_t mydet_wino4_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+/* Re-reads the MYDET_W4_TAIL* tuning variables (they are read once per process otherwise): tests and in-process sweeps. */
+int mydet_wino4_reload_tuning(void);
 int mydet_conv2d_wino4_f32(const float *x, int64_t ldx, const float *u, const float *scale, const float *shift,
                            const float *residual, int64_t ldr, float *ws, int64_t ws_bytes, float *y, int64_t ldy,
                            int B, int H, int W, int Cin, int Cout, int act, void *stream);

@@ -23,7 +23,9 @@ SIGNATURES = {
     + [c_ptr],
     'mydet_wino4_weights_floats': [c_int, c_int],
     'mydet_wino4_weights_f32': [c_ptr, c_int, c_int, c_ptr, c_ptr],
-    'mydet_wino4_workspace_bytes': [c_int, c_int, c_int, c_int],
+    'mydet_wino4_workspace_bytes': [c_int, c_int, c_int, c_int, c_int],
+    'mydet_wino4_reload_tuning': [],
+    'mydet_conv_igemm_occupancy': [c_int, c_ptr],
     'mydet_wino4_tail_plan': [c_int, c_int, c_int, c_int, c_int, c_int, c_ptr],
     'mydet_conv2d_wino4_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64] + [c_int] * 6 + [c_ptr],
     'mydet_dwconv_slices': [c_int, c_int, c_int, c_int, c_int],

@@ -37,6 +37,19 @@ static inline bool mydet_first_on_device(unsigned long long &mask) {
     return true;
 }
 
+// The > 64 KiB dynamic-LDS opt-in of `kern`, once per device (`mask` as above): 0, or MYDET_E_UNSUPP when the runtime
+// refuses it -- the device is then forgotten again, so the next call retries instead of launching into a later
+// "invalid value" error.
+template <typename K>
+static inline int mydet_lds_opt_in(unsigned long long &mask, K kern, int bytes) {
+    if (!mydet_first_on_device(mask)) return 0;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess) return 0;
+    (void)hipGetLastError();                                   // the failure is reported by the return code, not left sticky
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) mask &= ~(1ull << dev);
+    return MYDET_E_UNSUPP;
+}
+
 __device__ __forceinline__ float mydet_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
 
 // Logistic for the swish epilogues of the conv / depthwise / fusion kernels: v_exp_f32 on -v*log2(e) (product formed

@@ -382,10 +382,7 @@ template <int BM, int BN, int WM, int WN, int BK, bool CIN32, int ACT, bool RES,
 int launch_inst(const ConvArgs &a, size_t lds, hipStream_t stream) {
     auto kern = &conv_igemm_kernel<BM, BN, WM, WN, BK, CIN32, ACT, RES, GATE, SPLIT, CAT>;
     static unsigned long long attr_set = 0;                  // > 64 KiB of dynamic LDS needs the opt-in once per device
-    if (mydet_first_on_device(attr_set)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-    }
+    if (const int e = mydet_lds_opt_in(attr_set, kern, (int)lds)) return e;
     hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(WM * WN * 64), lds, stream, a);
     return mydet_launch_status();
 }
@@ -520,6 +517,35 @@ bool pw_skinny_on() {   // MYDET_PW_SKINNY=0: tuning only (A/B against the tiled
     return !(e && *e == '0');
 }
 
+// Tile configuration of a layer (ids of launch_cfg) -- one rule for mydet_conv2d_igemm_f32 and for the fused
+// upsample-concat entry point, which only exists for configuration 3 and must say so for every other shape.
+int choose_cfg(int64_t M64, int Cin, int Cout, int taps) {
+    // Tile choice, from the per-shape sweep in profiles/ (tools/sweep_conv_cfg.sh):
+    //   narrow outputs take a narrow N tile; short-K layers (1x1 convs, prologue/epilogue-bound) and
+    //   grids under ~4 blocks per CU do best with 64x64 tiles at 4 workgroups/CU; the long-K 3x3
+    //   layers with big grids take 128x128 tiles on 8 waves (wave tile 64x32, 4 waves per SIMD).
+    const int64_t blocks128 = ((M64 + 127) / 128) * ((Cout + 127) / 128);
+    const int K = taps * Cin;
+    // short generic-K pointwise convs (EfficientNet expand/project, BiFPN, heads): BK = 16 wastes no staging on
+    // K = 16/24/40/88... and five 30 KB workgroups fit a CU
+    if ((Cin % 32) != 0 && K <= 256) return 6;
+    if (Cout <= 32) return 2;
+    // 80 / 88 output channels behind a long K (480->80 project convs): a 96-wide tile instead of two 64-wide ones
+    // (tools/sweep_pointwise.py, batch 32: 67 -> 57 us; a tie at batch 16 and a loss at batch 8 -- 12 800 rows:
+    // 36 vs 24 us -- where the 64 x 64 tiles with the split-K tail fill the chip better)
+    if (taps == 1 && Cout > 64 && Cout <= 96 && K >= 384 && M64 >= 40000) return 9;
+    // short-K, very wide outputs (EfficientNet expand convs at 20^2: 192->1152, 320->1920): the 8-wave 128x128 tile
+    // (tools/sweep_pointwise.py: 79 -> 73 us, 35.7 -> 32.9 us at batch 16; under 4 800 rows -- batch 8 at 20^2 -- the
+    // 64 x 64 tiles are ahead again: 320->1920 47 -> 44 us)
+    if (taps == 1 && K <= 512 && Cout >= 1024 && (M64 >= 4800 || K <= 256)) return 8;
+    // (1x1 with 33..64 outputs behind a long K -- YOLOv3's 128->64 @160^2 -- also does better with BK = 16 and five workgroups
+    // per CU: 0.172 -> 0.156 ms in the model, round 4)
+    if (Cout <= 64) return taps > 1 || K >= 96 ? 6 : 1;
+    // (3x3 layers with K >= 512 and a big grid already prefer the 8-wave tile: 64->128 stride 2 @320^2 +7 %)
+    if ((K <= 1024 && !(taps > 1 && K >= 512)) || blocks128 < 1024) return 3;
+    return 8;
+}
+
 }  // namespace
 
 extern "C" int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *w, const float *scale,
@@ -566,30 +592,36 @@ extern "C" int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *
         const int rc = mydet_pw_skinny(x, ldx, w, scale, shift, residual, ldr, a_gate, y, ldy, B, H * W, Cin, Cout, act, stream);
         if (rc != MYDET_E_UNSUPP) return rc;
     }
-    // Tile choice, from the per-shape sweep in profiles/ (tools/sweep_conv_cfg.sh):
-    //   narrow outputs take a narrow N tile; short-K layers (1x1 convs, prologue/epilogue-bound) and
-    //   grids under ~4 blocks per CU do best with 64x64 tiles at 4 workgroups/CU; the long-K 3x3
-    //   layers with big grids take 128x128 tiles on 8 waves (wave tile 64x32, 4 waves per SIMD).
-    const int64_t blocks128 = ((M64 + 127) / 128) * ((Cout + 127) / 128);
-    const int K = KH * KW * Cin;
-    // short generic-K pointwise convs (EfficientNet expand/project, BiFPN, heads): BK = 16 wastes no staging on
-    // K = 16/24/40/88... and five 30 KB workgroups fit a CU
-    if ((Cin % 32) != 0 && K <= 256) return launch_cfg(6, a, s);
-    if (Cout <= 32) return launch_cfg(2, a, s);
-    // 80 / 88 output channels behind a long K (480->80 project convs): a 96-wide tile instead of two 64-wide ones
-    // (tools/sweep_pointwise.py, batch 32: 67 -> 57 us; a tie at batch 16 and a loss at batch 8 -- 12 800 rows:
-    // 36 vs 24 us -- where the 64 x 64 tiles with the split-K tail fill the chip better)
-    if (KH * KW == 1 && Cout > 64 && Cout <= 96 && K >= 384 && M64 >= 40000) return launch_cfg(9, a, s);
-    // short-K, very wide outputs (EfficientNet expand convs at 20^2: 192->1152, 320->1920): the 8-wave 128x128 tile
-    // (tools/sweep_pointwise.py: 79 -> 73 us, 35.7 -> 32.9 us at batch 16; under 4 800 rows -- batch 8 at 20^2 -- the
-    // 64 x 64 tiles are ahead again: 320->1920 47 -> 44 us)
-    if (KH * KW == 1 && K <= 512 && Cout >= 1024 && (M64 >= 4800 || K <= 256)) return launch_cfg(8, a, s);
-    // (1x1 with 33..64 outputs behind a long K -- YOLOv3's 128->64 @160^2 -- also does better with BK = 16 and five workgroups
-    // per CU: 0.172 -> 0.156 ms in the model, round 4)
-    if (Cout <= 64) return launch_cfg(KH * KW > 1 || K >= 96 ? 6 : 1, a, s);
-    // (3x3 layers with K >= 512 and a big grid already prefer the 8-wave tile: 64->128 stride 2 @320^2 +7 %)
-    if ((K <= 1024 && !(KH * KW > 1 && K >= 512)) || blocks128 < 1024) return launch_cfg(3, a, s);
-    return launch_cfg(8, a, s);
+    return launch_cfg(choose_cfg(M64, Cin, Cout, KH * KW), a, s);
+}
+
+/* Test / tuning hook: workgroups per CU the runtime reports for the base instance of tile configuration `cfg`
+ * (hipOccupancyMaxActiveBlocksPerMultiprocessor), next to the count launch_cfg assumes; < 0 = MYDET_E_*. */
+extern "C" int mydet_conv_igemm_occupancy(int cfg, int *assumed) {
+    int n = 0, as = 0;
+    hipError_t e = hipErrorInvalidValue;
+#define MYDET_OCC(BM, BN, WM, WN, BK, PER_CU)                                                                                       \
+    {                                                                                                                                \
+        auto kern = &conv_igemm_kernel<BM, BN, WM, WN, BK, true, MYDET_ACT_LEAKY, false, false, false, false>;                        \
+        const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);                                                          \
+        static unsigned long long m = 0;                                                                                             \
+        if (const int rc = mydet_lds_opt_in(m, kern, (int)lds)) return rc;                                                            \
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, WM * WN * 64, lds);                                                \
+        as = PER_CU;                                                                                                                 \
+    }
+    switch (cfg) {
+        case 0: MYDET_OCC(128, 128, 2, 2, 32, 2) break;
+        case 1: MYDET_OCC(128, 64, 2, 2, 32, 2) break;
+        case 2: MYDET_OCC(128, 32, 4, 1, 32, 3) break;
+        case 3: MYDET_OCC(64, 64, 2, 2, 32, 4) break;
+        case 6: MYDET_OCC(128, 64, 2, 2, 16, 5) break;
+        case 9: MYDET_OCC(128, 96, 4, 1, 32, 2) break;
+        case 8: MYDET_OCC(128, 128, 2, 4, 32, 2) break;
+        default: return MYDET_E_BADARG;
+    }
+#undef MYDET_OCC
+    if (assumed) *assumed = as;
+    return e == hipSuccess ? n : MYDET_E_UNSUPP;
 }
 
 extern "C" int mydet_conv1x1_upcat_f32(const float *x_lo, int64_t ld_lo, int C_lo, const float *x_hi, int64_t ld_hi, int C_hi,
@@ -604,6 +636,10 @@ extern "C" int mydet_conv1x1_upcat_f32(const float *x_lo, int64_t ld_lo, int C_l
     if ((H & 1) || (W & 1) || (C_lo & 31) || (C_hi & 31) || act != MYDET_ACT_LEAKY) return MYDET_E_UNSUPP;
     const int64_t M64 = (int64_t)B * H * W;
     const int Cin = C_lo + C_hi;
+    // only where the two-launch path would run the same 64 x 64 x 32 tile (same k order, same cuts: bit-identical results);
+    // a shape the regular rule sends to another tile -- or to the skinny kernel -- is the caller's two launches
+    if (forced_cfg() >= 0 ? forced_cfg() != 3 : (choose_cfg(M64, Cin, Cout, 1) != 3 || (Cout <= 48 && M64 >= 65536 && pw_skinny_on())))
+        return MYDET_E_UNSUPP;
     if (M64 > (int64_t)1 << 30 || M64 * ldy * 4 >= 0x7FFFFFF0ll) return MYDET_E_UNSUPP;
     const int64_t span_imgs = 256 / ((int64_t)H * W) + 2;
     if ((int64_t)H * W * ld_hi * 4 * span_imgs >= 0x7FFFFFF0ll || (int64_t)(H >> 1) * (W >> 1) * ld_lo * 4 * span_imgs >= 0x7FFFFFF0ll ||

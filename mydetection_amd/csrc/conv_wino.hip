@@ -465,13 +465,9 @@ template <int ACT, bool RES, int NW>
 int launch_nw(WinoArgs a, hipStream_t stream) {
     constexpr int TILES = 8 * NW, NT = 64 * NW;
     constexpr int LDS = (U_BYTES + 8 * 4 * TILES * 16) * (NW == 8 ? 2 : 1);
-    static unsigned long long attr_set = 0;                  // > 64 KiB of dynamic LDS needs the opt-in once per device
-    if (mydet_first_on_device(attr_set)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino_kernel<ACT, RES, NW, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino_kernel<ACT, RES, NW, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    }
+    static unsigned long long attr_set = 0, attr_set_sk = 0;  // > 64 KiB of dynamic LDS needs the opt-in once per device
+    if (const int e = mydet_lds_opt_in(attr_set, &conv_wino_kernel<ACT, RES, NW, false>, LDS)) return e;
+    if (const int e = mydet_lds_opt_in(attr_set_sk, &conv_wino_kernel<ACT, RES, NW, true>, LDS)) return e;
     a.nblk = (int)(((int64_t)a.MT + TILES - 1) / TILES) * a.ntn;
     a.nk = a.Cin >> 3;
     // stream-K when the grid is at least two resident rounds (below that the plain grid is already one round or

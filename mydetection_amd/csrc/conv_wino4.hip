@@ -459,12 +459,28 @@ __global__ void wino4_weights_kernel(const float *w, int Cout, int Cin, int Cout
 // replace, or there are more than four whole rounds.
 struct TailGroup { int id0, blocks, stride, splits; int64_t part_bytes; };
 
-int plan_tail(int nmb, int ntn, int nbn, int rn_log2, int Cin, int slots, TailGroup *groups) {
+// Tuning knobs of the tail plan, read from the environment ONCE per process (they used to be four getenv + atoi per
+// F(4x4) layer per eager call, and a graph capture froze whatever they said at that moment anyway):
+//   MYDET_W4_TAIL         minimum cut count of the last group (default 4), 0 = no tail
+//   MYDET_W4_TAIL_GROUPS  most groups (default 2)      MYDET_W4_TAIL_MAXR  most whole rounds before a tail (default 4)
+//   MYDET_W4_TAIL_COST    largest admissible cost in rounds (default 0.9)
+// mydet_wino4_reload_tuning() reads them again (tests and sweeps that change them inside one process).
+struct TailKnobs { int min_cuts, max_groups, max_rounds; double max_cost; };
+TailKnobs read_tail_knobs() {
+    const char *te = getenv("MYDET_W4_TAIL"), *ge = getenv("MYDET_W4_TAIL_GROUPS");
+    const char *re = getenv("MYDET_W4_TAIL_MAXR"), *ce = getenv("MYDET_W4_TAIL_COST");
+    return TailKnobs{te ? atoi(te) : 4, ge ? atoi(ge) : 2, re ? atoi(re) : 4, ce ? atof(ce) : 0.9};
+}
+TailKnobs &tail_knobs() {
+    static TailKnobs k = read_tail_knobs();
+    return k;
+}
+
+int plan_tail(int nmb, int ntn, int nbn, int rn_log2, int Cin, int slots, TailGroup *groups, int64_t *scratch_bytes = nullptr) {
     int ngroups = 0;
-    const char *te = getenv("MYDET_W4_TAIL");         // tuning / tests: minimum cut count of the last group, 0 = no tail (read per call)
-    const int tail_on = te ? atoi(te) : 4;
-    const char *ge = getenv("MYDET_W4_TAIL_GROUPS");
-    const int max_groups = ge ? atoi(ge) : 2;
+    if (scratch_bytes) *scratch_bytes = 0;
+    const TailKnobs &knobs = tail_knobs();
+    const int tail_on = knobs.min_cuts, max_groups = knobs.max_groups;
     const int64_t T = (int64_t)nmb * ntn;
     const int64_t whole = T / slots * slots;
     const int RM = 64 >> rn_log2, RN = 1 << rn_log2, nk = Cin >> 2;
@@ -483,8 +499,7 @@ int plan_tail(int nmb, int ntn, int nbn, int rn_log2, int Cin, int slots, TailGr
     };
     // (after many whole rounds the workgroups no longer finish together and the last partial round is cheap already:
     // 128->256 @80^2, 6.25 rounds, ran 0.6 % of the headline FASTER without its tail -- up to four whole rounds only)
-    const char *re = getenv("MYDET_W4_TAIL_MAXR");
-    if (!(tail_on > 0 && whole > 0 && T > whole && nk >= 8 && whole / slots <= (re ? atoi(re) : 4))) return 0;
+    if (!(tail_on > 0 && whole > 0 && T > whole && nk >= 8 && whole / slots <= knobs.max_rounds)) return 0;
     int64_t cut = 0;
     int64_t first = NB;                                // first block of the tail: the fewest blocks that leave whole rounds
     while (T - cut > whole && first > 0) cut += items_of(--first);
@@ -514,22 +529,16 @@ int plan_tail(int nmb, int ntn, int nbn, int rn_log2, int Cin, int slots, TailGr
         blk += nb; left -= n;
     }
     // (0.9 admits a two-way group + an eight-way group = 0.865: 512->1024 @20^2, 800 items = one round + 256 + 32)
-    const char *ce = getenv("MYDET_W4_TAIL_COST");
-    return cost > (ce ? atof(ce) : 0.9) ? 0 : ngroups;
+    if (cost > knobs.max_cost) return 0;
+    if (scratch_bytes) *scratch_bytes = used;
+    return ngroups;
 }
 
 template <int ACT, bool RES>
 int launch_w4(W4Args a, const W4Args *groups, int ngroups, hipStream_t stream) {
-    static unsigned long long attr_set = 0;                      // > 64 KiB of dynamic LDS needs the opt-in once per device
-    if (mydet_first_on_device(attr_set)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino4_kernel<ACT, RES>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    }
-    static unsigned long long attr_set_p = 0;
-    if (mydet_first_on_device(attr_set_p)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino4_kernel<MYDET_ACT_NONE, false, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    }
+    static unsigned long long attr_set = 0, attr_set_p = 0;     // > 64 KiB of dynamic LDS needs the opt-in once per device
+    if (const int e = mydet_lds_opt_in(attr_set, &conv_wino4_kernel<ACT, RES>, LDS_BYTES)) return e;
+    if (const int e = mydet_lds_opt_in(attr_set_p, &conv_wino4_kernel<MYDET_ACT_NONE, false, true>, LDS_BYTES)) return e;
     hipLaunchKernelGGL(wino4_input_kernel, dim3((a.MT + TILES - 1) / TILES, (a.Cin + 31) / 32), dim3(256), 0, stream, a);
     if (ngroups > 0) {
         // whole rounds of whole items, then the remainder in groups cut along K (each about one short round), then their sums
@@ -553,6 +562,11 @@ int launch_w4(W4Args a, const W4Args *groups, int ngroups, hipStream_t stream) {
 
 }  // namespace
 
+extern "C" int mydet_wino4_reload_tuning(void) {
+    tail_knobs() = read_tail_knobs();
+    return 0;
+}
+
 extern "C" int64_t mydet_wino4_weights_floats(int Cout, int Cin) {
     if (Cout <= 0 || Cin <= 0 || (Cin & 3)) return 0;
     return (int64_t)36 * Cin * ((Cout + COUT_PAD - 1) / COUT_PAD * COUT_PAD);
@@ -568,10 +582,30 @@ extern "C" int mydet_wino4_weights_f32(const float *w, int Cout, int Cin, float 
     return mydet_launch_status();
 }
 
-extern "C" int64_t mydet_wino4_workspace_bytes(int B, int H, int W, int Cin) {
-    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3)) return 0;
+namespace {
+// The launch geometry both the workspace size and the launch derive from the shape: item grid and tail plan.
+struct W4Geom { int ntn, nmb, rn_log2, nbn; int64_t nbm, v_bytes, tail_bytes; int ngroups; TailGroup plan[3]; };
+int w4_geometry(int B, int H, int W, int Cin, int Cout, int slots, W4Geom &g) {
     const int64_t MT = (int64_t)B * ((H + 3) / 4) * ((W + 3) / 4);
-    return (MT + TILES - 1) / TILES * (Cin >> 2) * V_BYTES + TAIL_BYTES;
+    if (MT > (int64_t)1 << 30) return MYDET_E_UNSUPP;
+    g.ntn = (Cout + CH - 1) / CH;
+    g.nmb = (int)((MT + TILES - 1) / TILES);
+    g.rn_log2 = 0;
+    while ((1 << g.rn_log2) < g.ntn && g.rn_log2 < 3) ++g.rn_log2;
+    g.nbn = (g.ntn + (1 << g.rn_log2) - 1) >> g.rn_log2;
+    g.nbm = (g.nmb + (64 >> g.rn_log2) - 1) / (64 >> g.rn_log2);
+    if (g.nbm * g.nbn * 64 > 0x7FFFFFFF) return MYDET_E_UNSUPP;
+    g.v_bytes = (MT + TILES - 1) / TILES * (Cin >> 2) * V_BYTES;
+    g.ngroups = plan_tail(g.nmb, g.ntn, g.nbn, g.rn_log2, Cin, slots, g.plan, &g.tail_bytes);
+    return 0;
+}
+}  // namespace
+
+extern "C" int64_t mydet_wino4_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 3)) return 0;
+    W4Geom g;
+    if (w4_geometry(B, H, W, Cin, Cout, 2 * mydet_cu_count(), g) != 0) return 0;
+    return g.v_bytes + g.tail_bytes;            // V, then the partial tiles of the K-cut tail where the plan has one
 }
 
 /* Test hook (host only, no GPU call): the K-cut tail plan mydet_conv2d_wino4_f32 would use on a chip of `slots` resident
@@ -579,16 +613,12 @@ extern "C" int64_t mydet_wino4_workspace_bytes(int B, int H, int W, int Cin) {
  * scratch offset in KiB}; returns the number of groups or a negative MYDET_E_*. */
 extern "C" int mydet_wino4_tail_plan(int B, int H, int W, int Cin, int Cout, int slots, int32_t *out) {
     if (!out || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || slots <= 0 || (Cin & 3) || (Cout & 3)) return MYDET_E_BADARG;
-    const int64_t MT = (int64_t)B * ((H + 3) / 4) * ((W + 3) / 4);
-    if (MT > (int64_t)1 << 30) return MYDET_E_UNSUPP;
-    const int ntn = (Cout + CH - 1) / CH, nmb = (int)((MT + TILES - 1) / TILES);
-    int rn_log2 = 0;
-    while ((1 << rn_log2) < ntn && rn_log2 < 3) ++rn_log2;
-    const int nbn = (ntn + (1 << rn_log2) - 1) >> rn_log2;
-    const int64_t nbm = (nmb + (64 >> rn_log2) - 1) / (64 >> rn_log2);
-    if (nbm * nbn * 64 > 0x7FFFFFFF) return MYDET_E_UNSUPP;
-    TailGroup plan[3];
-    const int ng = plan_tail(nmb, ntn, nbn, rn_log2, Cin, slots, plan);
+    W4Geom geo;
+    if (const int e = w4_geometry(B, H, W, Cin, Cout, slots, geo)) return e;
+    const TailGroup *plan = geo.plan;
+    const int ng = geo.ngroups;
+    const int64_t nbm = geo.nbm;
+    const int nbn = geo.nbn;
     out[0] = ng ? plan[0].id0 : (int)(nbm * nbn * 64);
     out[1] = ng;
     for (int g = 0; g < ng; ++g) {
@@ -607,7 +637,6 @@ extern "C" int mydet_conv2d_wino4_f32(const float *x, int64_t ldx, const float *
         (residual && ((uintptr_t)residual & 15)) || (scale && ((uintptr_t)scale & 15)) || (shift && ((uintptr_t)shift & 15)))
         return MYDET_E_BADARG;
     if ((Cin & 3) || (Cout & 3) || (ldy & 3) || (residual && (ldr & 3))) return MYDET_E_UNSUPP;
-    if (ws_bytes < mydet_wino4_workspace_bytes(B, H, W, Cin)) return MYDET_E_BADARG;
     W4Args a;
     a.x = x; a.u = u; a.scale = scale; a.shift = shift; a.res = residual; a.y = y; a.v = ws;
     a.ldx = ldx; a.ldr = residual ? ldr : ldy; a.ldy = ldy;
@@ -623,20 +652,17 @@ extern "C" int mydet_conv2d_wino4_f32(const float *x, int64_t ldx, const float *
 #ifdef MYDET_DIAG
     { const char *e = getenv("MYDET_W4_DBG"); a.dbg = e && *e ? atoi(e) : 0; }
 #endif
-    a.ntn = (Cout + CH - 1) / CH;
-    a.nmb = (int)((MT + TILES - 1) / TILES);
-    a.rn_log2 = 0;
-    while ((1 << a.rn_log2) < a.ntn && a.rn_log2 < 3) ++a.rn_log2;
-    a.nbn = (a.ntn + (1 << a.rn_log2) - 1) >> a.rn_log2;
-    const int64_t nbm = (a.nmb + (64 >> a.rn_log2) - 1) / (64 >> a.rn_log2);
-    if (nbm * a.nbn * 64 > 0x7FFFFFFF) return MYDET_E_UNSUPP;
-    a.nblk = (int)(nbm * a.nbn * 64);
+    W4Geom geo;
+    if (const int e = w4_geometry(B, H, W, Cin, Cout, 2 * mydet_cu_count(), geo)) return e;
+    if (ws_bytes < geo.v_bytes + geo.tail_bytes) return MYDET_E_BADARG;
+    a.ntn = geo.ntn; a.nmb = geo.nmb; a.rn_log2 = geo.rn_log2; a.nbn = geo.nbn;
+    a.nblk = (int)(geo.nbm * geo.nbn * 64);
     if ((MT + TILES - 1) / TILES > 0x7FFFFFFF || (Cin + 31) / 32 > 65535) return MYDET_E_UNSUPP;
-    // K-cut tail (plan_tail)
+    // K-cut tail (plan_tail): its partial tiles live behind V
     a.tail_id0 = a.nblk; a.tail_blocks = 0; a.tail_stride = 64; a.splits = 1;
-    a.part = ws + (mydet_wino4_workspace_bytes(B, H, W, Cin) - TAIL_BYTES) / 4;
-    TailGroup plan[3];
-    const int ngroups = plan_tail(a.nmb, a.ntn, a.nbn, a.rn_log2, Cin, 2 * mydet_cu_count(), plan);
+    a.part = ws + geo.v_bytes / 4;
+    const TailGroup *plan = geo.plan;
+    const int ngroups = geo.ngroups;
     W4Args groups[3];
     for (int g = 0; g < ngroups; ++g) {
         groups[g] = a;

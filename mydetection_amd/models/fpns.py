@@ -51,11 +51,7 @@ class YOLOBranch(nn.Module):
     def forward(self, x, previous=None):
         if previous is not None:
             pre = self.process(previous)
-            y = self.cbl_0.forward_upcat(pre, x)                      # cbl_0(cat((up2x(pre), x), 1)) in one launch ...
-            if y is None:                                             # ... or, for shapes that launch does not cover, in two
-                x = ops.upsample_concat(pre, tuple(x.shape[2:4]), x)  # cat((pre, x), dim=1)
-                y = self.cbl_0(x)
-            x = y
+            x = self.cbl_0(x, upcat_lo=pre)           # cbl_0(cat((up2x(pre), x), 1)): one launch where the shape allows, else two
         else:
             x = self.cbl_0(x)
         x = self.cbl_1(x)

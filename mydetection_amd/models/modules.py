@@ -83,26 +83,26 @@ class ConvBnLeaky(nn.Module, FusedConvMixin):
         self.conv = nn.Conv2d(c1, c2, k, s, padding=(k - 1) // 2, bias=False)
         self.bn = nn.BatchNorm2d(c2, eps=1e-5, momentum=0.01)
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, upcat_lo=None):
+        """upcat_lo: a half-resolution map; the layer then computes self(cat((nearest_2x(upcat_lo), x), 1)) (reference:
+        models/fpns.py:62-66) -- for the 1x1 shapes the fused launch covers without ever writing the concatenated tensor
+        (ops.conv1x1_upcat), otherwise through ops.upsample_concat.  Passed through __call__, so module hooks fire on
+        either path."""
         if self.training:
             raise NotImplementedError('mydetection_amd implements the inference path only; call model.eval()')
         w, scale, shift = self._prepared(self.conv, self.bn)
         p = (self.k - 1) // 2
+        if upcat_lo is not None:
+            assert residual is None
+            if self.k == 1 and self.s == 1:
+                y = ops.conv1x1_upcat(upcat_lo, x, w, scale, shift, ops.ACT_LEAKY)
+                if y is not None:
+                    return y
+            x = ops.upsample_concat(upcat_lo, tuple(x.shape[2:4]), x)        # cat((up(lo), x), dim=1), then the plain layer
         if w.shape[3] == 3 and self.k == 3 and w.shape[0] == 32 and residual is None:
             return ops.conv2d_stem(x, w, scale, shift, self.s, (p, p, p, p), ops.ACT_LEAKY)
         u, u4 = prepare_wino(self, 'wino', w) if self.k == 3 and self.s == 1 else (None, None)
         return ops.conv2d(x, w, scale, shift, self.k, self.s, (p, p, p, p), ops.ACT_LEAKY, residual=residual, wino=u, wino4=u4)
-
-
-    def forward_upcat(self, lo, hi):
-        """self(cat((nearest_2x(lo), hi), 1)) without the concatenated tensor (1x1 layers; reference: models/fpns.py:62-66);
-        None when the fused launch does not cover the shape."""
-        if self.training:
-            raise NotImplementedError('mydetection_amd implements the inference path only; call model.eval()')
-        if self.k != 1 or self.s != 1:
-            return None
-        w, scale, shift = self._prepared(self.conv, self.bn)
-        return ops.conv1x1_upcat(lo, hi, w, scale, shift, ops.ACT_LEAKY)
 
 
 class DarkBlock(nn.Module):

@@ -247,7 +247,7 @@ def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None
         assert residual.shape == out.shape
     if (wino4 is not None and WINOGRAD and WINOGRAD4 and gate is None and k == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1)
             and ldy % 4 == 0 and ldr % 4 == 0 and (wino is None or wino4_items(B, H, W, Cout) >= WINO4_MIN_ITEMS)):
-        ws = wino4_workspace(x.device, _lib.lib().mydet_wino4_workspace_bytes(B, H, W, Cin))
+        ws = wino4_workspace(x.device, _lib.lib().mydet_wino4_workspace_bytes(B, H, W, Cin, Cout))
         t0 = TIMER.start() if TIMER else None
         code = _lib.lib().mydet_conv2d_wino4_f32(_ptr(x), ldx, _ptr(wino4), _ptr(scale), _ptr(shift), _ptr(residual), ldr,
                                                  _ptr(ws), ws.numel() * 4, _ptr(out), ldy, B, H, W, Cin, Cout, act, _stream())
@@ -645,8 +645,10 @@ FUSED_UPCAT = os.environ.get('MYDET_FUSED_UPCAT', '1') != '0'
 
 def conv1x1_upcat(a, b, w_ohwi, scale, shift, act):
     """act(conv1x1(cat((nearest_2x(a), b), dim=1)) * scale + shift) in ONE launch -- the concatenated tensor is read on the
-    fly, never written; bit-identical to `upsample_concat` + `conv2d`.  a [B,C1,H/2,W/2], b [B,C2,H,W].  Returns None when
-    the shape is not covered (the caller then runs the two launches)."""
+    fly, never written; bit-identical to `upsample_concat` + `conv2d` for every shape it accepts.  a [B,C1,H/2,W/2],
+    b [B,C2,H,W].  Returns None when the shape is not covered -- channel counts not multiples of 32, or a shape `conv2d` would
+    not run on the 64 x 64 x 32 tile the fused launch is instantiated for (include/mydet.h) -- and the caller then runs the two
+    launches."""
     require_gpu(a, 'conv1x1_upcat')
     B, C1, Ha, Wa = a.shape
     _, C2, H, W = b.shape

@@ -75,21 +75,24 @@ def gather_detections(rec, group=None, always=False, total=None):
 
 
 def agree_on_lanes(choice, device=None, group=None):
-    """One batch-lane count for every rank: rank 0's `choice` is broadcast (other ranks pass None, or their own wish, which is
-    ignored) and every rank gets (lanes, [lanes of each rank after the broadcast]).  Lanes change the last float bits of a
-    result (graph.GraphedPath), so ranks that each timed their own choice could disagree bit for bit with a 1-GPU
-    recomputation; the list lets the caller assert that they do not.  No process group: (choice, [choice])."""
+    """One batch-lane count for every rank.  Every rank passes what it would replay with (its own application of the
+    shared rule) or None when it has no opinion (`--lanes auto`: only rank 0 timed anything); the wishes are
+    all-gathered, rank 0's counts, and a rank whose own wish differs raises -- on every rank, so nobody is left
+    waiting in a later collective.  Lanes change the last float bits of a result (graph.GraphedPath), so ranks that
+    replayed different counts would disagree bit for bit with a 1-GPU recomputation (`bench.py --verify`).
+    Returns (lanes, [wish of each rank, 0 = none]).  No process group: (choice, [choice])."""
     if not (dist.is_available() and dist.is_initialized()):
         return int(choice), [int(choice)]
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    pick = torch.tensor([int(choice) if (rank == 0 and choice is not None) else 0], dtype=torch.int32, device=device)
-    dist.broadcast(pick, src=0, group=group)
+    world = dist.get_world_size(group)
+    mine = torch.tensor([0 if choice is None else int(choice)], dtype=torch.int32, device=device)
     got = [torch.zeros(1, dtype=torch.int32, device=device) for _ in range(world)]
-    dist.all_gather(got, pick.clone(), group=group)
-    per_rank = [int(t.item()) for t in got]
-    if len(set(per_rank)) != 1 or per_rank[0] < 1:
-        raise RuntimeError(f'ranks disagree on the batch-lane count: {per_rank}')
-    return per_rank[0], per_rank
+    dist.all_gather(got, mine, group=group)
+    wishes = [int(t.item()) for t in got]
+    if wishes[0] < 1:
+        raise RuntimeError(f'rank 0 gave no batch-lane count: {wishes}')
+    if any(w not in (0, wishes[0]) for w in wishes):
+        raise RuntimeError(f'ranks disagree on the batch-lane count: {wishes} (MYDET_LANES / --lanes must be the same on every rank)')
+    return wishes[0], wishes
 
 
 def records_to_objects(rec, img_hw=None, bb_format='cxcywh'):

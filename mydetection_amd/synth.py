@@ -42,12 +42,38 @@ def _uniform(key, shape, lo, hi):
     return (a * np.float32(hi - lo) + np.float32(lo)).astype(np.float32)
 
 
-def _yolo_head(key, shape, n_cls=80, feature_rms=None):
+# Calibrated YOLO head (configs that ship per-channel head statistics, oracle/calibrate_yolo_head.py -> calib/<config>.npz):
+# (std, mean) of each kind of head logit over images and cells.  Objectness is wide and far below zero, so the score
+# sigmoid(conf) * max_c sigmoid(cls_c) has a long upper tail instead of a narrow band: at 640^2 some 170 of the 25 200
+# candidates pass 0.5 (~140 detections in ~20 classes), ~300 pass 0.05, 500-600 pass 0.005 (the top-512 cut applies on
+# most images; ~390 detections in ~55 classes), and the winning class changes from cell to cell.
+_YOLO_TARGETS = {'xy': (1.0, 0.0), 'wh': (0.35, 0.0), 'conf': (6.4, -20.0), 'class': (2.0, -2.0)}
+
+
+def yolo_head_unit_weight(key, shape):
+    """Head conv weight before any gain: N(0, 1 / fan_in) per element, a pure function of the key."""
+    fan_in = shape[1] * shape[2] * shape[3]
+    return (_normal(key, shape) / np.float32(np.sqrt(fan_in))).astype(np.float32)
+
+
+def _yolo_head(key, shape, n_cls=80, feature_rms=None, calib=None):
     """rpn.heads.conv_{i}.{weight,bias}: row o = a*(5+n_cls) + c  (models/rpns.py:27-33)."""
     feature_rms = _YOLO_HEAD_FEATURE_RMS if feature_rms is None else feature_rms
     level = int(key.split('conv_')[1].split('.')[0])
     rows = shape[0]
     c = np.arange(rows) % (5 + n_cls)
+    module = key.rsplit('.', 1)[0]
+    rowstd = (calib or {}).get('__rowstd__/' + module)
+    if rowstd is not None and rowstd.shape[0] == rows:
+        # every output channel normalised with its measured unit-gain statistics, then given its kind's target
+        kind = np.where(c < 2, 0, np.where(c < 4, 1, np.where(c == 4, 2, 3)))
+        tstd = np.array([_YOLO_TARGETS[k][0] for k in ('xy', 'wh', 'conf', 'class')], np.float32)[kind]
+        tmean = np.array([_YOLO_TARGETS[k][1] for k in ('xy', 'wh', 'conf', 'class')], np.float32)[kind]
+        gain = (tstd / rowstd.astype(np.float32)).astype(np.float32)
+        if key.endswith('.bias'):
+            rowmean = calib['__rowmean__/' + module].astype(np.float32)
+            return (tmean - gain * rowmean + _normal(key, (rows,), std=0.05)).astype(np.float32)
+        return yolo_head_unit_weight(key, shape) * gain.reshape(-1, 1, 1, 1)
     # target logit std per row kind: xy 1.0, wh 0.35, conf 2.5, class 2.0
     tgt = np.where(c < 2, 1.0, np.where(c < 4, 0.35, np.where(c == 4, 2.5, 2.0))).astype(np.float32)
     if key.endswith('.bias'):
@@ -199,6 +225,13 @@ def load_calibration(config_name, recipe='conditioned'):
     return _CALIB_CACHE[ck]
 
 
+def is_yolov3_80(template):
+    """True for the state_dict of configs/yolov3_80.json: Darknet-53 (29-entry netlist) + YOLOv3 pyramid + 255-row heads."""
+    w = template.get('rpn.heads.conv_0.weight')
+    return ('backbone.netlist.28.cbl_1.conv.weight' in template and 'fpn.branch_P3.cbl_0.conv.weight' in template
+            and w is not None and tuple(w.shape) == (255, 256, 1, 1))
+
+
 def is_ultralytics(template):
     """True for the state_dict of a model on the Ultralytics trunk (its first module is Focus: netlist.0.conv.conv)."""
     return 'backbone.netlist.0.conv.conv.weight' in template
@@ -223,7 +256,7 @@ def make_tensor(key: str, shape, dtype=torch.float32, calib=None, damped=(), hea
         return torch.zeros(shape, dtype=torch.int64)
     effdet = is_efficientdet_key(key)
     if key.startswith('rpn.heads.conv_'):
-        arr = _yolo_head(key, shape, feature_rms=head_rms)
+        arr = _yolo_head(key, shape, feature_rms=head_rms, calib=calib)
     elif effdet and _efdet_last_kind(key) is not None:
         arr = _efdet_last(key, shape, _efdet_last_kind(key), calib or {})
     elif effdet and len(shape) == 1 and key.endswith(('.weight', '.bias')) and _is_bn_key(key):
@@ -266,6 +299,8 @@ def make_state_dict(template, config_name=None, recipe='conditioned') -> dict:
     recipe: 'conditioned' (default; every fixture and benchmark) or 'stiff' (EfficientDet family only: the
     ill-conditioned set described at _STIFF)."""
     assert recipe in ('conditioned', 'stiff')
+    if config_name is None and is_yolov3_80(template):
+        config_name = 'yolov3_80'                 # its head calibration is part of the recipe, named or not
     calib = load_calibration(config_name, recipe) if config_name else {}
     damped = residual_project_bns(template)
     head_rms = None

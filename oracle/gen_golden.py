@@ -100,7 +100,7 @@ def _gen_yolov3(model, cfg, batch, size, name, seed, thresholds):
             out[f'pp_{tag}_cats_{b}'] = _np(d.cats)
             out[f'pp_{tag}_scores_{b}'] = _np(d.scores)
             from oracle.postprocess import decision_margins
-            safe = [e for e in (2e-5, 1e-5, 5e-6, 2e-6, 1e-6, 5e-7, 2e-7)
+            safe = [e for e in (1e-4, 5e-5, 2e-5, 1e-5, 5e-6, 2e-6, 1e-6, 5e-7, 2e-7)
                     if decision_margins(out[f'scores_{b}'], out[f'cats_{b}'], conf, eps=e) is None]
             out[f'pp_{tag}_margin'] = np.float64(min(float(out.get(f'pp_{tag}_margin', 1.0)), safe[0] if safe else 0.0))
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
@@ -389,9 +389,10 @@ if __name__ == '__main__':
         gen_postprocess()
     if 'detlayers' in which:
         gen_detlayers()
-    if 'yolov3' in which:               # BASELINE configs[0] shape; seed 14: the widest post-processing margins (2e-6 at all
-                                        # three settings) of the first seventy image seeds ('yolov3_512_scan' lists them)
-        gen_yolov3(1, 512, 'yolov3_b1_512', seed=14)
+    if 'yolov3' in which:               # BASELINE configs[0] shape; seed 2: of the first forty image seeds the one whose
+                                        # post-processing margins are widest (1e-5 / 5e-5 / 5e-5) among those where more than
+                                        # 512 candidates pass 0.005 (the top-512 cut applies) -- 'yolov3_512_scan' lists them
+        gen_yolov3(1, 512, 'yolov3_b1_512', seed=2)
     if 'yolov3_512_scan' in which:      # prints the margins of the candidate seeds (writes scratch files only)
         lo, hi = (int(v) for v in os.environ.get('SCAN_SEEDS', '0,10').split(','))
         for sd in range(lo, hi):

@@ -72,11 +72,16 @@ def test_conv_igemm_vs_fp64(dev, case):
     _conv_case(dev, **case)
 
 
-@pytest.mark.parametrize('shape', [(2, 256, 512, 256, 20, 20), (1, 128, 256, 128, 32, 32), (3, 64, 32, 255, 6, 10), (32, 128, 256, 128, 40, 40)])
+@pytest.mark.parametrize('shape', [(2, 256, 512, 256, 20, 20),      # 28 x 4 tiles, K = 24 slabs: the small-grid K cut + CAT
+                                   (1, 256, 512, 256, 10, 10),      # the same layer at batch 1 (7 x 4 tiles cut along K)
+                                   (1, 128, 256, 128, 32, 32),      # batch 1, 12 slabs: uncut
+                                   (3, 64, 32, 255, 6, 10),         # ragged rows and channels
+                                   (32, 128, 256, 128, 40, 40)])    # the headline's P3 layer: big grid
 def test_conv1x1_upcat_equals_two_launches(dev, shape):
     """cbl_0(cat((up2x(pre), x), 1)) of YOLOBranch in ONE launch (mydet_conv1x1_upcat_f32: the concatenation is read on the fly)
-    == upsample_concat + conv2d bit for bit (same k order, same tile shape) -- big grids, the batch-1 K-cut path, ragged
-    rows and channels -- and within round-off of float64; shapes it does not cover return None."""
+    == upsample_concat + conv2d bit for bit (same k order, same tile shape) -- big grids, the small-grid K-cut path at batch
+    1 and 2, ragged rows and channels -- and within round-off of float64; shapes it does not cover return None, among them
+    every shape the regular dispatch rule would not run on the 64 x 64 x 32 tile the fused launch exists for."""
     from mydetection_amd import ops
     B, C1, C2, Cout, Ha, Wa = shape
     g = torch.Generator().manual_seed(21)
@@ -95,6 +100,9 @@ def test_conv1x1_upcat_equals_two_launches(dev, shape):
     assert (y.double().cpu() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
     assert ops.conv1x1_upcat(lo[:, :24], hi, w[..., :24 + C2].contiguous(), sc, sh, ops.ACT_LEAKY) is None      # C1 % 32 != 0
     assert ops.conv1x1_upcat(lo, hi, w, sc, sh, ops.ACT_SWISH) is None
+    # <= 64 output channels: conv2d takes its 128 x 64 tile there, so the fused launch declines (the caller's two launches
+    # then ARE the result; ConvBnLeaky(upcat_lo=...) does exactly that)
+    assert ops.conv1x1_upcat(lo, hi, w[:64].contiguous(), sc[:64].contiguous(), sh[:64].contiguous(), ops.ACT_LEAKY) is None
 
 
 @pytest.mark.parametrize('case', [
@@ -181,9 +189,14 @@ def test_conv_winograd4_kcut_tail(dev, case, monkeypatch):
     def run():
         return ops.conv2d(x, w, scale, shift, 3, 1, (1, 1, 1, 1), case['act'], residual=res, wino4=u4).clone()
     cut = [run() for _ in range(4)]
+    from mydetection_amd import _lib
     monkeypatch.setenv('MYDET_W4_TAIL', '0')
-    plain = run()
-    monkeypatch.delenv('MYDET_W4_TAIL')
+    _lib.lib().mydet_wino4_reload_tuning()                # (the knobs are read once per process otherwise)
+    try:
+        plain = run()
+    finally:
+        monkeypatch.delenv('MYDET_W4_TAIL')
+        _lib.lib().mydet_wino4_reload_tuning()
     for o in cut[1:]:
         assert torch.equal(o, cut[0])
     assert not torch.equal(cut[0], plain), 'the tail rule did not trigger on a shape chosen to trigger it'

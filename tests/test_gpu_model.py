@@ -53,12 +53,15 @@ def _class_ids_exact_where_safe(got, ref, margin, what):
     np.testing.assert_array_equal(got[safe], ref[safe], err_msg=what)
 
 
-def _check_yolo_golden(m, g, what):
+def _check_yolo_golden(m, g, what, strict=False):
     """Candidates and detections of a YOLO-head model against a fixture made by the imported reference: every candidate
     within north_star's 1e-4, class ids exact where the fixture says they are well defined, detections at the three
     settings exact (count, class ids, order; scores / boxes 1e-4) whenever the fixture's decision margin exceeds twice
     the score error observed here -- thousands of long-tailed scores pass 0.005, so gaps at the top-512 cut are ~1e-6
-    (oracle/gen_golden.py:gen_yolov3) -- and in every case equal to the oracle's post_process of THESE candidates."""
+    (oracle/gen_golden.py:gen_yolov3) -- and in every case equal to the oracle's post_process of THESE candidates.
+    strict (the yolov3_80 fixtures, whose calibrated head gives non-trivial, different detection sets at all three
+    settings with margins of 1e-5 and more): every setting must keep >= 50 detections in >= 10 classes, the fixture's
+    margin must exceed twice the score error observed here, and the detections must equal the reference's at all three."""
     from mydetection_amd import synth
     from oracle import postprocess as opp
     x = synth.make_images(int(g['batch']), int(g['size']), seed=int(g['image_seed'])).cuda()
@@ -94,6 +97,9 @@ def _check_yolo_golden(m, g, what):
         np.testing.assert_array_equal(r.bboxes.cpu().numpy(), ob)
         ref_c, ref_s, ref_b = g[f'pp_{tag}_cats_0'], g[f'pp_{tag}_scores_0'], g[f'pp_{tag}_bboxes_0']
         same = len(r) == len(ref_c) and np.array_equal(r.cats.cpu().numpy(), ref_c)
+        if strict:
+            assert len(ref_c) >= 50 and len(np.unique(ref_c)) >= 10, f'{what} {tag}: vacuous fixture ({len(ref_c)} detections)'
+            assert float(g[f'pp_{tag}_margin']) > 2 * err, f'{what} {tag}: score error {err:.1e} is not inside the fixture margin'
         if float(g[f'pp_{tag}_margin']) > 2 * err:
             assert same, f'{what} {tag}: decisions differ from the reference although its margin {float(g[f"pp_{tag}_margin"]):.1e} > 2 x {err:.1e}'
         if same:
@@ -101,15 +107,18 @@ def _check_yolo_golden(m, g, what):
             np.testing.assert_allclose(r.scores.cpu().numpy(), ref_s, rtol=RTOL, atol=ATOL)
             np.testing.assert_allclose(r.bboxes.cpu().numpy(), ref_b, rtol=RTOL, atol=ATOL)
         else:       # a decision inside the round-off band flipped: the detection sets may differ by the candidates involved
-            assert abs(len(r) - len(ref_c)) <= 4, f'{what} {tag}: {len(r)} vs {len(ref_c)} detections'
-    assert exact_tags >= 2, f'{what}: detections equal the reference\'s at only {exact_tags} of 3 settings'
+            assert not strict and abs(len(r) - len(ref_c)) <= 4, f'{what} {tag}: {len(r)} vs {len(ref_c)} detections'
+    assert exact_tags >= (3 if strict else 2), f'{what}: detections equal the reference\'s at only {exact_tags} of 3 settings'
+    if strict:      # the three settings decide different things: the top-512 cut applies at the first, not at the others
+        n_ap, n_mid, n_demo = (len(g[f'pp_{t}_cats_0']) for t in ('ap', 'mid', 'demo'))
+        assert n_ap > n_mid > n_demo and int((g['scores_0'] >= float(g['pp_ap_conf'])).sum()) > 512 > int((g['scores_0'] >= float(g['pp_mid_conf'])).sum())
     return err
 
 
 def test_end_to_end_vs_reference_golden(model, golden):
     """BASELINE configs[0] shape (batch 1, 512 x 512) against the imported reference."""
     m, cfg = model
-    _check_yolo_golden(m, golden('yolov3_b1_512'), 'yolov3 512')
+    _check_yolo_golden(m, golden('yolov3_b1_512'), 'yolov3 512', strict=True)
 
 
 def test_end_to_end_vs_reference_golden_640(model, golden):
@@ -133,7 +142,7 @@ def test_end_to_end_vs_reference_golden_640(model, golden):
         head = raw.packed['box'][0].contiguous().cpu().numpy()
         np.testing.assert_allclose(head.reshape(-1)[g[f'head_{lvl}_idx']], g[f'head_{lvl}_val'], rtol=RTOL, atol=ATOL)
     assert g['bboxes_0'].shape == (25200, 4)
-    _check_yolo_golden(m, g, 'yolov3 640')
+    _check_yolo_golden(m, g, 'yolov3 640', strict=True)
 
 
 def test_ultralytics_plugins_vs_reference_golden(golden):
@@ -337,6 +346,53 @@ def _check_effdet_golden(name, m, g):
         np.testing.assert_array_equal(r.cats.cpu().numpy(), ref_c)
         np.testing.assert_allclose(r.scores.cpu().numpy(), ref_s, rtol=RTOL, atol=ATOL)
         np.testing.assert_allclose(r.bboxes.cpu().numpy(), ref_b, rtol=RTOL, atol=ATOL)
+
+
+def _wino4_launches(fn):
+    """Run fn() with the per-launch timer on; returns (result, number of F(4x4) conv launches it issued)."""
+    from mydetection_amd import ops
+    ops.TIMER = ops.KernelTimer()
+    try:
+        out = fn()
+    finally:
+        timer, ops.TIMER = ops.TIMER, None
+    torch.cuda.synchronize()
+    return out, len(timer.spans.get('conv_wino4', []))
+
+
+def test_f4x4_kernels_vs_reference_goldens(model, golden, monkeypatch):
+    """The F(4x4,3x3) pair (wino4_input_kernel + conv_wino4_kernel: half of the headline step) against the imported
+    reference end to end.  ops.conv2d hands a layer to F(4x4) only from 512 workgroups up, so at the fixtures' batch 1
+    every 3x3 layer runs F(2x2); with WINO4_MIN_ITEMS = 1 every 3x3 stride-1 layer with Cin >= 64 takes the F(4x4) pair
+    instead (31 of YOLOv3's 32; the C6 / C7 convs and the dense class layer of D1-FCOS-ATSS) and the same reference
+    gates apply: stage samples, all candidates within 1e-4, class ids, detections at three settings
+    (reference: models/modules.py:56-95, models/backbones.py:6-57, 183-200, models/rpns.py:155-158)."""
+    from mydetection_amd import ops, synth
+    from mydetection_amd.models.general import name_to_model
+    m, cfg = model
+    monkeypatch.setattr(ops, 'WINO4_MIN_ITEMS', 1)
+    g = golden('yolov3_b1_640')
+    x = synth.make_images(1, 640, seed=int(g['image_seed'])).cuda()
+    with torch.no_grad():
+        (c, p), n4 = _wino4_launches(lambda: (lambda c: (c, m.fpn(c)))(m.backbone(x)))
+    assert n4 == 31, f'{n4} F(4x4) launches in the YOLOv3 forward, expected 31'
+    for key, feats in (('backbone', c), ('fpn', p)):
+        for lvl, f in enumerate(feats):
+            f = f.contiguous().cpu().numpy()
+            np.testing.assert_allclose(f.reshape(-1)[g[f'{key}_{lvl}_idx']], g[f'{key}_{lvl}_val'], rtol=RTOL, atol=ATOL)
+            np.testing.assert_allclose(np.sqrt((f.astype(np.float64) ** 2).sum()), g[f'{key}_{lvl}_l2'], rtol=1e-5)
+    _check_yolo_golden(m, g, 'yolov3 640 on F(4x4)', strict=True)
+    _check_yolo_golden(m, golden('yolov3_b1_512'), 'yolov3 512 on F(4x4)', strict=True)
+    name = 'd1_fcs2_atss'
+    m2, _ = name_to_model(name)
+    m2.load_state_dict(synth.make_state_dict(m2.state_dict(), name), strict=True)
+    m2 = m2.eval().cuda()
+    g2 = golden('d1_fcs2_atss_b1_640')
+    x2 = synth.make_normalized_images(1, 640, seed=int(g2['image_seed'])).cuda()
+    with torch.no_grad():
+        _, n4 = _wino4_launches(lambda: m2.forward_candidates(x2))
+    assert n4 >= 7, f'{n4} F(4x4) launches in the D1-FCOS-ATSS forward (C6, C7 and five dense class layers expected)'
+    _check_effdet_golden(name, m2, g2)
 
 
 def test_effdet_family_vs_oracle_640(effdet):
@@ -703,6 +759,36 @@ def test_full_size_properties_batch32_640(model):
         k = int(cnt[i])
         assert k == len(src)
         np.testing.assert_array_equal(rec['index'][i, :k].cpu().numpy().astype(np.int64), src)
+    # images 0 and 31 of THIS production batch (F(4x4) on 31 layers, K-cut tails, the 128 x 128 tiles) against the CPU
+    # oracle forward: every candidate within north_star's 1e-4, class ids exact where the oracle's two best classes are
+    # further apart than round-off, and the detection sets equal wherever no decision sits inside the observed error
+    from oracle import yolov3 as oy
+    sd_cpu = {k: v.cpu() for k, v in m.state_dict().items()}
+    pick = [0, 31]
+    with torch.no_grad():
+        ob, oc, os_, raws = oy.forward(x[pick].cpu(), sd_cpu, return_raw=True)
+    got_s, got_b, got_c = sc[pick].cpu().numpy(), bb[pick].cpu().numpy(), ci[pick].cpu().numpy()
+    np.testing.assert_allclose(got_s, os_.numpy(), rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(got_b, ob.numpy(), rtol=RTOL, atol=ATOL)
+    margin = []
+    for r in raws:
+        t = torch.sigmoid(r.view(2, 3, 85, *r.shape[2:])[:, :, 5:].permute(0, 1, 3, 4, 2)).reshape(2, -1, 80).topk(2, dim=-1).values
+        margin.append(t[..., 0] - t[..., 1])
+    margin = torch.cat(margin, dim=1).numpy()
+    err = float(np.abs(got_s - os_.numpy()).max())
+    n_safe = 0
+    for j, i in enumerate(pick):
+        _class_ids_exact_where_safe(got_c[j], oc[j].numpy(), margin[j], f'batch-32 image {i}')
+        for t in (conf, 0.05, 0.5):
+            if pp.decision_margins(os_[j].numpy(), oc[j].numpy(), t, eps=max(2.0 * err, 2e-6)) is None:
+                n_safe += 1
+                _, rc, _, ri = pp.post_process(ob[j].numpy(), oc[j].numpy(), os_[j].numpy(), t, thr)
+                r_t = batched_post_process(bb[i:i + 1], ci[i:i + 1], sc[i:i + 1], t, thr)
+                k = int(r_t['count'][0])
+                assert k == len(ri) and k >= 20, f'image {i} conf {t}: {k} vs {len(ri)} detections'
+                np.testing.assert_array_equal(r_t['index'][0, :k].cpu().numpy().astype(np.int64), ri)
+                np.testing.assert_array_equal(r_t['class_idx'][0, :k].cpu().numpy(), rc)
+    assert n_safe >= 3, f'only {n_safe} of 6 (image, threshold) pairs are margin-safe at score error {err:.1e}'
 
 
 def test_hipgraph_replay_equals_eager(model):

@@ -475,6 +475,31 @@ def test_bench_parity_check_logic():
         assert not bench.parity_check(cand, r2, conf, nms, oracle_cand=None, images=B)['ok'], tamper
 
 
+def test_bench_multi_gpu_launch_guard():
+    """`python bench.py --gpus 8` on a machine without eight GPUs (this container has none): the launcher command is the
+    driver's (`torch.distributed.run`, one rank per GPU, rendezvous on 127.0.0.1) and is built before anything touches a
+    GPU; with fewer GPUs visible the process exits 2 with a one-line message and starts nothing."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(root, 'bench.py')
+    dry = subprocess.run([sys.executable, bench, '--gpus', '8', '--steps', '3', '--dry-run-launch'], capture_output=True, text=True,
+                         timeout=120, env={k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')})
+    assert dry.returncode == 0, dry.stderr
+    cmd = json.loads(dry.stdout.strip().splitlines()[-1])['launch']
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and '--nproc-per-node=8' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[cmd.index('--master-port') + 1].isdigit()
+    assert cmd[cmd.index(bench) + 1:] == ['--gpus', '8', '--steps', '3', '--dry-run-launch']
+    if torch.cuda.device_count() >= 8:
+        return                                     # an 8-GPU node would really start the ranks: nothing more to check here
+    run = subprocess.run([sys.executable, bench, '--gpus', '8', '--steps', '3'], capture_output=True, text=True, timeout=120,
+                         env={k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')})
+    assert run.returncode == 2 and run.stdout.strip() == ''
+    lines = [ln for ln in run.stderr.strip().splitlines() if ln.startswith('bench.py:')]
+    assert len(lines) == 1 and '--gpus 8' in lines[0] and 'nothing was run' in lines[0]
+
+
 def _w4_items(B, H, W, Cout):
     """(item validity by id, ids) of the F(4x4) GEMM launch, as conv_wino4.hip maps ids to (tile block, channel block)."""
     MT = B * ((H + 3) // 4) * ((W + 3) // 4)

@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: the multi-GPU exchange (shard -> ONE all-gather of the fixed-size records -> views)."""
+"""CPU, world_size 2 and 8 over gloo: the multi-GPU exchange (shard -> ONE all-gather of the fixed-size records -> views)."""
 import os
 import socket
 
@@ -41,11 +41,18 @@ def _worker(rank, world, port, total, q):
         ok = False
     except ValueError:
         pass
-    # the lane count bench.py --gpus N replays with: rank 0's choice reaches every rank, whatever the others wished for
-    lanes, per_rank = parallel.agree_on_lanes(2 if rank == 0 else 1)
+    # the lane count bench.py --gpus N replays with: every rank's own application of the rule is compared -- the same
+    # wish everywhere passes, ranks without an opinion (--lanes auto: only rank 0 timed anything) take rank 0's, and a
+    # rank that wishes for something else makes EVERY rank raise (nobody is left waiting in the next collective)
+    lanes, per_rank = parallel.agree_on_lanes(2)
     ok = ok and lanes == 2 and per_rank == [2] * world
     lanes, per_rank = parallel.agree_on_lanes(1 if rank == 0 else None)
-    ok = ok and lanes == 1 and per_rank == [1] * world
+    ok = ok and lanes == 1 and per_rank == [1] + [0] * (world - 1)
+    try:
+        parallel.agree_on_lanes(2 if rank != world - 1 else 1)
+        ok = False
+    except RuntimeError as e:
+        ok = ok and 'disagree' in str(e)
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
@@ -71,6 +78,16 @@ def test_gather_detections_world2():
 def test_gather_detections_world2_uneven():
     """7 images over 2 ranks (4 + 3): the short shard is padded for the collective and the padding dropped."""
     _run_world(2, 7)
+
+
+def test_gather_detections_world8_batch256():
+    """BASELINE configs[4]'s exchange shape on CPU: 256 images over 8 ranks (8 x 32), one all-gather of 16 400-B records."""
+    _run_world(8, 256)
+
+
+def test_gather_detections_world8_uneven_250():
+    """250 images over 8 ranks (two shards of 32, six of 31): padded for the collective, padding rows dropped."""
+    _run_world(8, 250)
 
 
 def test_pack_unpack_roundtrip_and_sharding():
