@@ -69,7 +69,7 @@ def parse_args(argv=None):
     ap.add_argument('--cpu-sample-batch', type=int, default=2)
     ap.add_argument('--cpu-repeats', type=int, default=5)
     ap.add_argument('--cpu-threads', type=int, default=16)
-    ap.add_argument('--parity-images', type=int, default=4,
+    ap.add_argument('--parity-images', type=int, default=6,
                     help='images of the timed batch the parity check compares with the CPU oracle forward (the CPU baseline sample '
                          'covers the first --cpu-sample-batch of them; the rest cost one more oracle forward each)')
     ap.add_argument('--dry-run-launch', action='store_true', help='with --gpus N > 1: print the launcher command as JSON and exit')

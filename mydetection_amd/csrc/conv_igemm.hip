@@ -486,6 +486,13 @@ int launch(const ConvArgs &a0, int slots, hipStream_t stream) {
     return launch_fixup_act<BM, BN, WM, WN>(a, rem, stream);
 }
 
+// Workgroups per CU assumed for tile configuration 6: the runtime reports 4 (mydet_conv_igemm_occupancy; the two-slab
+// register prefetch of round 4 took the fifth); MYDET_CFG6_PER_CU overrides (A/B), read once.
+int cfg6_per_cu() {
+    static const int v = [] { const char *e = getenv("MYDET_CFG6_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 5; }();
+    return v;
+}
+
 // Tile configurations (id -> BM x BN, wave grid, BK).  MYDET_CONV_CFG=<id> forces one (tuning only).
 int launch_cfg(int id, const ConvArgs &a, hipStream_t s) {
     const int cus = mydet_cu_count();
@@ -495,7 +502,7 @@ int launch_cfg(int id, const ConvArgs &a, hipStream_t s) {
         case 1: return launch<128, 64, 2, 2, 32>(a, 2 * cus, s);
         case 2: return launch<128, 32, 4, 1, 32>(a, 3 * cus, s);
         case 3: return launch<64, 64, 2, 2, 32>(a, 4 * cus, s);
-        case 6: return launch<128, 64, 2, 2, 16>(a, 5 * cus, s);
+        case 6: return launch<128, 64, 2, 2, 16>(a, cfg6_per_cu() * cus, s);
         case 9: return launch<128, 96, 4, 1, 32>(a, 2 * cus, s);       // Cout in (64, 96]: 80 / 88 channels
         case 8: return launch<128, 128, 2, 4, 32>(a, 2 * cus, s);     // 8 waves, wave tile 64x32
         default: return MYDET_E_BADARG;
@@ -614,7 +621,7 @@ extern "C" int mydet_conv_igemm_occupancy(int cfg, int *assumed) {
         case 1: MYDET_OCC(128, 64, 2, 2, 32, 2) break;
         case 2: MYDET_OCC(128, 32, 4, 1, 32, 3) break;
         case 3: MYDET_OCC(64, 64, 2, 2, 32, 4) break;
-        case 6: MYDET_OCC(128, 64, 2, 2, 16, 5) break;
+        case 6: MYDET_OCC(128, 64, 2, 2, 16, cfg6_per_cu()) break;
         case 9: MYDET_OCC(128, 96, 4, 1, 32, 2) break;
         case 8: MYDET_OCC(128, 128, 2, 4, 32, 2) break;
         default: return MYDET_E_BADARG;

@@ -33,7 +33,7 @@ def gen_yolov3(batch=1, size=512, name='yolov3_b1_512', config='yolov3_80', seed
     only defined where that gap exceeds round-off) and, per threshold, `pp_<tag>_margin`: the largest eps for which
     oracle.postprocess.decision_margins finds no post-processing decision within eps of flipping (0 = exact score ties,
     broken by candidate index).  Thousands of long-tailed scores pass 0.005, so gaps at the top-512 cut are ~1e-6 at
-    best: `seed` is the image seed with the widest margin among the first ten (512: seed 14 of seventy, 640: seed 1, u5m 256: seed 4 -- see
+    best: `seed` is the image seed with the widest margin among the first tens (512: seed 2 of forty, 640: seed 13 of thirty, u5m 256: seed 4 -- see
     DESIGN.md section 2), and the GPU tests demand exact decisions only when their own score error is inside it."""
     model, cfg = _refimport.build_reference_model(config)
     return _gen_yolov3(model, cfg, batch, size, name, seed, thresholds)
@@ -389,17 +389,18 @@ if __name__ == '__main__':
         gen_postprocess()
     if 'detlayers' in which:
         gen_detlayers()
-    if 'yolov3' in which:               # BASELINE configs[0] shape; seed 2: of the first forty image seeds the one whose
-                                        # post-processing margins are widest (1e-5 / 5e-5 / 5e-5) among those where more than
-                                        # 512 candidates pass 0.005 (the top-512 cut applies) -- 'yolov3_512_scan' lists them
+    if 'yolov3' in which:               # BASELINE configs[0] shape; seed 2: of the first forty image seeds the one with the
+                                        # widest post-processing margins (5e-5 / 5e-5 / 1e-4 at the three settings; 699
+                                        # candidates pass 0.005, so the top-512 cut applies) -- 'yolov3_512_scan' lists them
         gen_yolov3(1, 512, 'yolov3_b1_512', seed=2)
     if 'yolov3_512_scan' in which:      # prints the margins of the candidate seeds (writes scratch files only)
         lo, hi = (int(v) for v in os.environ.get('SCAN_SEEDS', '0,10').split(','))
         for sd in range(lo, hi):
             gen_yolov3(1, 512, f'_scan_yolov3_b1_512_seed{sd}', seed=sd)
             os.remove(os.path.join(OUT, f'_scan_yolov3_b1_512_seed{sd}.npz'))
-    if 'yolov3_640' in which:           # BASELINE configs[1] resolution, pinned by the reference itself (batch 1)
-        gen_yolov3(1, 640, 'yolov3_b1_640', seed=1)
+    if 'yolov3_640' in which:           # BASELINE configs[1] resolution, pinned by the reference itself (batch 1); seed 13: margins
+                                        # 5e-5 at all three settings, the widest of the first thirty seeds (725 / 392 / 138 pass)
+        gen_yolov3(1, 640, 'yolov3_b1_640', seed=13)
     if 'ultralytics' in which:          # registry plug-ins 'ultralytics' backbone + FPN under the YOLO head
         gen_yolov3(1, 256, 'u5m_yv3_b1_256', config='u5m_yv3', seed=4,
                    thresholds=(('ap', 0.005, 0.45), ('mid', 0.05, 0.45), ('demo', 0.2, 0.45)))
