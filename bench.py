@@ -338,7 +338,8 @@ def main():
         print(json.dumps(out))
     if dist_on:
         torch.distributed.destroy_process_group()
-    sys.exit(code)
+    if code:
+        sys.exit(code)
 
 
 OTHER_CONFIGS = (('efficientdet-d1', 'efficientdet-d1_b16_640', 16, 640),        # BASELINE configs[2]

@@ -489,7 +489,7 @@ int launch(const ConvArgs &a0, int slots, hipStream_t stream) {
 // Workgroups per CU assumed for tile configuration 6: the runtime reports 4 (mydet_conv_igemm_occupancy; the two-slab
 // register prefetch of round 4 took the fifth); MYDET_CFG6_PER_CU overrides (A/B), read once.
 int cfg6_per_cu() {
-    static const int v = [] { const char *e = getenv("MYDET_CFG6_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 5; }();
+    static const int v = [] { const char *e = getenv("MYDET_CFG6_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 4; }();
     return v;
 }
 

@@ -164,11 +164,19 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs p) {
             if (best < 5.0f && best > -80.0f) {
                 cmax = mydet_sigmoid(best);
             } else {                                   // near saturation: compare the sigmoid values themselves
-                cmax = mydet_sigmoid(cl[0]);
+                // ... of the classes that can tie with the best one.  The logistic is monotonic, and a logit two below the best
+                // (or below 15 when the best one is past 17, where the float32 logistic is exactly 1) has a float32 logistic
+                // at least four ulps smaller: it can neither win nor tie, so its logistic is not evaluated (a wave in which ONE
+                // lane is saturated used to pay C logistics per lane: decode 0.059 -> 0.113 ms on a saturating head).
+                const float lim = best > -80.0f ? fminf(best - 2.0f, 15.0f) : -__builtin_inff();
+                cmax = -1.0f;
                 bi = 0;
-                for (int k = 1; k < p.C; ++k) {
-                    const float sv = mydet_sigmoid(cl[k]);
-                    if (sv > cmax) { cmax = sv; bi = k; }
+                for (int k = 0; k < p.C; ++k) {
+                    const float xk = cl[k];
+                    if (xk >= lim) {
+                        const float sv = mydet_sigmoid(xk);
+                        if (sv > cmax) { cmax = sv; bi = k; }
+                    }
                 }
             }
             if (part) continue;                        // lane 2c finishes the candidate
