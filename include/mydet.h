@@ -113,10 +113,28 @@ int mydet_conv2d_stem_f32(const float *x, int64_t sxb, int64_t sxc, int64_t sxh,
  * S must be mydet_dwconv_slices(Ho, Wo, C, K, stride): the number of slices the kernel chosen for the layer writes
  * (one per 8 x 16 output tile for the LDS-tiled stride-1 kernel, which takes the layers of 32 channels and more).
  */
+/* Squeeze-excite tail inside the launch that produces the depthwise output (optional last argument of mydet_dwconv_f32,
+ * mydet_mbconv_expand_dw_f32, mydet_stem_dw_f32; NULL = none).  The launch then also writes
+ *     gate[b][c] = sigmoid(W2 . swish(W1 . mean_pixels(y[b]) + b1) + b2)[c]          (external/efficientnet/model.py:80-83)
+ * -- what mydet_se_gate_f32 computes from se_partial in a launch of its own -- without that launch: every workgroup adds its
+ * channels' share of W1 . sums while it holds them and publishes it (fire and forget); the last workgroup of an image waits
+ * for the shares, sums them in a fixed order and runs the expand conv (csrc/se_tail.h).  Deterministic.
+ *   w1 [Cse][C], b1 [Cse], w2t [Cse][C] (the expand conv TRANSPOSED), b2 [C], gate [B][C]  (all 16-byte aligned);
+ *   hpart: B * groups * Cse floats, groups = mydet_dwconv_se_groups / mydet_mbconv_tiles of the layer, every 32-bit word
+ *   holding MYDET_SE_EMPTY before the launch; the launch leaves it that way (so one buffer, filled once, can serve every
+ *   layer of a stream).  Cse <= 96; MYDET_E_UNSUPP beyond.  se_partial may be NULL when the tail is given. */
+#define MYDET_SE_EMPTY_WORD 0x7FC5E5E5u
+typedef struct {
+    const float *w1, *b1, *w2t, *b2;
+    float *gate, *hpart;
+    int Cse;
+} mydet_se_tail;
 int mydet_dwconv_slices(int Ho, int Wo, int C, int K, int stride);
+/* workgroups per image of the kernel mydet_dwconv_f32 picks for the layer when it also emits the squeeze (sizes se->hpart) */
+int mydet_dwconv_se_groups(int Ho, int Wo, int C, int K, int stride);
 int mydet_dwconv_f32(const float *x, int64_t ldx, const float *w, const float *scale, const float *shift,
                      float *y, int64_t ldy, int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l,
-                     int Ho, int Wo, int act, float *se_partial, int S, void *stream);
+                     int Ho, int Wo, int act, float *se_partial, int S, const mydet_se_tail *se, void *stream);
 
 /* Per-image channel sums of x split over S pixel slices: partial[B][S+1][C], slices 0..S-1 (standalone squeeze). */
 int mydet_channel_sums_f32(const float *x, int64_t ldx, int B, int H, int W, int C, float *partial, int S,
@@ -331,7 +349,8 @@ int mydet_mbconv_tiles(int Ho, int Wo, int stride);
 int mydet_mbconv_expand_dw_f32(const float *x, int64_t ldx, const float *w_expand, const float *shift0,
                                const float *w_dw, const float *shift1,
                                float *y, int64_t ldy, int B, int H, int W, int Cin, int Cexp, int K, int stride,
-                               int pad_t, int pad_l, int Ho, int Wo, float *se_partial, int S, void *stream);
+                               int pad_t, int pad_l, int Ho, int Wo, float *se_partial, int S, const mydet_se_tail *se,
+                               void *stream);
 
 /* EfficientNet stem fused with the depthwise conv of the first MBConv block (which has expand_ratio 1):
  *     y = swish(BN1(depthwise3x3_s1_pad1( swish(BN0(conv3x3_s2(image))) )))      + per-tile channel sums of y
@@ -343,7 +362,8 @@ int mydet_mbconv_expand_dw_f32(const float *x, int64_t ldx, const float *w_expan
  * [B][S+1][32] with S == mydet_mbconv_tiles(Hs, Ws, 1).  C must be 32 (MYDET_E_UNSUPP otherwise). */
 int mydet_stem_dw_f32(const float *x, int64_t sxb, int64_t sxc, int64_t sxh, int64_t sxw, const float *w_stem,
                       const float *shift0, const float *w_dw, const float *shift1, float *y, int64_t ldy, int B, int H, int W,
-                      int C, int pad_t, int pad_l, int Hs, int Ws, float *se_partial, int S, void *stream);
+                      int C, int pad_t, int pad_l, int Hs, int Ws, float *se_partial, int S, const mydet_se_tail *se,
+                      void *stream);
 
 /* Fused separable-conv node of the 88-channel BiFPN / EfDetHead pyramid, several nodes per launch:
  *     y = act( pointwise1x1( depthwise3x3_pad1( pre(in...) ) ) * scale + shift )

@@ -29,7 +29,8 @@ SIGNATURES = {
     'mydet_wino4_tail_plan': [c_int, c_int, c_int, c_int, c_int, c_int, c_ptr],
     'mydet_conv2d_wino4_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64] + [c_int] * 6 + [c_ptr],
     'mydet_dwconv_slices': [c_int, c_int, c_int, c_int, c_int],
-    'mydet_dwconv_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64] + [c_int] * 11 + [c_ptr, c_int, c_ptr],
+    'mydet_dwconv_se_groups': [c_int, c_int, c_int, c_int, c_int],
+    'mydet_dwconv_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64] + [c_int] * 11 + [c_ptr, c_int, c_ptr, c_ptr],
     'mydet_channel_sums_f32': [c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr, c_int, c_ptr],
     'mydet_se_gate_f32': [c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
     'mydet_maxpool3s2_f32': [c_ptr, c_i64, c_ptr, c_i64] + [c_int] * 6 + [c_ptr],
@@ -50,10 +51,10 @@ SIGNATURES = {
                               c_ptr, c_ptr, c_ptr],
     'mydet_postprocess_records_f32': [c_ptr, c_ptr, c_ptr, c_int, c_i64, c_f32, c_f64, c_ptr, c_ptr, c_ptr],
     'mydet_mbconv_tiles': [c_int, c_int, c_int],
-    'mydet_mbconv_expand_dw_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64] + [c_int] * 11 + [c_ptr, c_int, c_ptr],
+    'mydet_mbconv_expand_dw_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64] + [c_int] * 11 + [c_ptr, c_int, c_ptr, c_ptr],
     'mydet_sepconv_nodes_f32': [c_int, c_ptr, c_int, c_int, c_ptr],
     'mydet_stem_dw_f32': [c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int,
-                          c_int, c_int, c_int, c_int, c_ptr, c_int, c_ptr],
+                          c_int, c_int, c_int, c_int, c_ptr, c_int, c_ptr, c_ptr],
     'mydet_sepconv_decode_retina_f32': [c_int, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_i64, c_ptr],
     'mydet_bboxes_iou_f32': [c_ptr, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr],
     'mydet_bboxes_to_original_batched_f32': [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr],
@@ -81,6 +82,14 @@ class DecodeLevel(ctypes.Structure):
     """mydet_decode_level (include/mydet.h)."""
     _fields_ = [('box', c_ptr), ('ldbox', c_i64), ('cls', c_ptr), ('ldcls', c_i64), ('anchors_wh', c_ptr),
                 ('H', c_int), ('W', c_int), ('stride', c_f32), ('n_off', c_i64)]
+
+
+class SeTail(ctypes.Structure):
+    """mydet_se_tail (include/mydet.h): the squeeze-excite tail finished inside the depthwise launch."""
+    _fields_ = [('w1', c_ptr), ('b1', c_ptr), ('w2t', c_ptr), ('b2', c_ptr), ('gate', c_ptr), ('hpart', c_ptr), ('Cse', c_int)]
+
+
+SE_EMPTY_WORD = 0x7FC5E5E5          # MYDET_SE_EMPTY_WORD of include/mydet.h
 
 
 class SepconvNode(ctypes.Structure):

@@ -14,8 +14,11 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "se_tail.h"
 
 namespace {
+
+const SeTail NO_SE_TAIL = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
 
 // --------------------------------------------------------------------------------------------- depthwise
 struct DwArgs {
@@ -23,6 +26,7 @@ struct DwArgs {
     float *y, *partial;       // partial != NULL: also emit per-slice channel sums [B][S][C] (SE squeeze)
     int64_t ldx, ldy, total;
     int C, H, W, Ho, Wo, pad_t, pad_l, act, S;
+    SeTail se;                // se.gate != NULL: the squeeze-excite gate is finished inside the launch (se_tail.h)
 };
 
 // TW consecutive outputs of one row for one channel quad: each input column and each weight is loaded once
@@ -153,6 +157,9 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const DwArgs p) {
 template <int K, int ST, int TW, int TH = 1>
 __global__ __launch_bounds__(256) void dwconv_sum_kernel(const DwArgs p) {
     __shared__ f32x4 red[256];
+    __shared__ float selds[MYDET_SE_LDS_FLOATS];
+    const bool se_on = p.se.gate != nullptr;
+    if (se_on && threadIdx.x < MYDET_SE_MAX_CSE) selds[threadIdx.x] = 0.f;      // (the first barrier below orders it)
     const int Q = p.C >> 2, WG = p.Wo / TW;
     const int b = blockIdx.y, s = blockIdx.x;
     const int NG = (p.Ho / TH) * WG;                   // TH = 2: a work item is a TW x 2 block (stride 1, Ho even)
@@ -197,17 +204,25 @@ __global__ __launch_bounds__(256) void dwconv_sum_kernel(const DwArgs p) {
             }
         red[threadIdx.x] = sum;
         __syncthreads();
+        f32x4 tot = {0.f, 0.f, 0.f, 0.f};
         if (threadIdx.x < nq) {
-            f32x4 tot = red[threadIdx.x];
+            tot = red[threadIdx.x];
             for (int k = 1; k < ph_n; ++k) {
                 const f32x4 o = red[threadIdx.x + k * nq];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) tot[j] += o[j];
             }
-            *reinterpret_cast<f32x4 *>(p.partial + ((int64_t)b * (p.S + 1) + s) * p.C + (qb + threadIdx.x) * 4) = tot;
+            if (p.partial) *reinterpret_cast<f32x4 *>(p.partial + ((int64_t)b * (p.S + 1) + s) * p.C + (qb + threadIdx.x) * 4) = tot;
         }
         __syncthreads();
+        if (se_on) {            // this slice's share of W1 . sums for the channels of this group (se_tail.h)
+            if (threadIdx.x < nq) red[threadIdx.x] = tot;
+            __syncthreads();
+            se_fc1_accumulate(p.se, p.C, reinterpret_cast<const float *>(red), qb * 4, nq * 4, selds);
+            __syncthreads();
+        }
     }
+    if (se_on) se_tail_finish(p.se, selds, p.C, p.Ho * p.Wo, b, s, p.S);
 }
 
 
@@ -224,6 +239,7 @@ struct DwTArgs {
     float *y, *partial;
     int64_t ldx, ldy;
     int C, H, W, Ho, Wo, pad_t, pad_l, act, S, tiles_x, nchunks;
+    SeTail se;
 };
 
 // CQ channel quads per workgroup: 8 (tile 8 x 16) for C >= 32, 4 (tile 8 x 32) for the 16-channel layer
@@ -323,15 +339,28 @@ __global__ __launch_bounds__(256, 4) void dwconv_tile_kernel(const DwTArgs p) {
     }
     if (SUM) {          // channel sums of the tile: the 32 (row, strip) threads of a quad, added in thread order
         red[tid] = sum;
-        __syncthreads();
-        if (tid < CQ && q0 + tid < Q) {
-            f32x4 tot = red[tid];
-            for (int k = 1; k < 256 / CQ; ++k) {
-                const f32x4 o = red[tid + k * CQ];
+        __syncthreads();                               // (every thread is done with `tile` here: the tail reuses it)
+        const bool se_on = p.se.gate != nullptr;
+        float *selds = tile, *tots = tile + MYDET_SE_LDS_FLOATS;      // NPIX * PS >= 6 480 floats
+        if (tid < CQ) {
+            f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+            if (q0 + tid < Q) {
+                tot = red[tid];
+                for (int k = 1; k < 256 / CQ; ++k) {
+                    const f32x4 o = red[tid + k * CQ];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) tot[e] += o[e];
+                    for (int e = 0; e < 4; ++e) tot[e] += o[e];
+                }
+                if (p.partial) *reinterpret_cast<f32x4 *>(p.partial + ((int64_t)b * (p.S + 1) + r) * p.C + (q0 + tid) * 4) = tot;
             }
-            *reinterpret_cast<f32x4 *>(p.partial + ((int64_t)b * (p.S + 1) + r) * p.C + (q0 + tid) * 4) = tot;
+            if (se_on) *reinterpret_cast<f32x4 *>(&tots[tid * 4]) = tot;
+        }
+        if (se_on) {    // this tile's share of W1 . sums for this chunk's channels, then the per-image hand-over (se_tail.h)
+            if (tid >= 64 && tid < 64 + MYDET_SE_MAX_CSE) selds[tid - 64] = 0.f;
+            __syncthreads();
+            se_fc1_accumulate(p.se, p.C, tots, q0 * 4, min(CQ * 4, p.C - q0 * 4), selds);
+            __syncthreads();
+            se_tail_finish(p.se, selds, p.C, p.Ho * p.Wo, b, r * p.nchunks + chunk, p.S * p.nchunks);
         }
     }
 }
@@ -739,7 +768,7 @@ int launch_dw(const DwArgs &p0, int B, hipStream_t stream) {
     DwArgs p = p0;
     const bool strip4 = (p.Wo % 4) == 0;
     const int TW = strip4 ? 4 : 1;
-    if (p.partial) {
+    if (p.partial || p.se.gate) {
         const dim3 grid(p.S, B);
         if (strip4 && ST == 1 && (p.Ho & 1) == 0 && block2())
             hipLaunchKernelGGL((dwconv_sum_kernel<K, 1, 4, 2>), grid, dim3(256), 0, stream, p);
@@ -765,9 +794,19 @@ extern "C" int mydet_dwconv_slices(int Ho, int Wo, int C, int K, int stride) {
     return s < 1 ? 1 : s;
 }
 
+// workgroups per image of the squeeze-emitting kernel mydet_dwconv_f32 picks (sizes the hpart scratch of an in-launch SE tail)
+extern "C" int mydet_dwconv_se_groups(int Ho, int Wo, int C, int K, int stride) {
+    const int S = mydet_dwconv_slices(Ho, Wo, C, K, stride);
+    if (S <= 0 || C <= 0 || (C & 3)) return 0;
+    if (stride == 1 && (K == 3 || K == 5) && dw_tiled() && C >= 16)
+        return S * (C < 32 ? ((C >> 2) + 3) / 4 : ((C >> 2) + 7) / 8);
+    return S;
+}
+
 template <int K>
 static int launch_dw_tile(const DwArgs &a, int B, hipStream_t stream) {
     DwTArgs p;
+    p.se = a.se;
     p.x = a.x; p.w = a.w; p.scale = a.scale; p.shift = a.shift; p.y = a.y; p.partial = a.partial; p.ldx = a.ldx; p.ldy = a.ldy;
     p.C = a.C; p.H = a.H; p.W = a.W; p.Ho = a.Ho; p.Wo = a.Wo; p.pad_t = a.pad_t; p.pad_l = a.pad_l; p.act = a.act;
     const bool narrow = a.C < 32;                            // 4 quads x (8 x 32) outputs instead of 8 quads x (8 x 16)
@@ -776,11 +815,12 @@ static int launch_dw_tile(const DwArgs &a, int B, hipStream_t stream) {
     p.nchunks = narrow ? ((a.C >> 2) + 3) / 4 : ((a.C >> 2) + 7) / 8;
     const int64_t grid = (int64_t)B * p.S * p.nchunks;      // one workgroup per (image, tile, chunk): a persistent form with a
     if (grid > 0x7fffffff) return MYDET_E_UNSUPP;           // register prefetch of the next tile measured 20 % slower (profiles/r03_mbconv_notes.md)
+    const bool sums = a.partial || a.se.gate;
     if (narrow) {
-        if (a.partial) hipLaunchKernelGGL((dwconv_tile_kernel<K, true, 4>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+        if (sums) hipLaunchKernelGGL((dwconv_tile_kernel<K, true, 4>), dim3((unsigned)grid), dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((dwconv_tile_kernel<K, false, 4>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     } else {
-        if (a.partial) hipLaunchKernelGGL((dwconv_tile_kernel<K, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+        if (sums) hipLaunchKernelGGL((dwconv_tile_kernel<K, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((dwconv_tile_kernel<K, false>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     }
     return mydet_launch_status();
@@ -788,7 +828,8 @@ static int launch_dw_tile(const DwArgs &a, int B, hipStream_t stream) {
 
 extern "C" int mydet_dwconv_f32(const float *x, int64_t ldx, const float *w, const float *scale, const float *shift,
                                 float *y, int64_t ldy, int B, int H, int W, int C, int K, int stride, int pad_t,
-                                int pad_l, int Ho, int Wo, int act, float *se_partial, int S, void *stream) {
+                                int pad_l, int Ho, int Wo, int act, float *se_partial, int S, const mydet_se_tail *se,
+                                void *stream) {
     if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0) return MYDET_E_BADARG;
     if ((C & 3) || (ldx & 3) || (ldy & 3) || ldx < C || ldy < C || !al16(x) || !al16(w) || !al16(y)) return MYDET_E_BADARG;
     if ((scale == nullptr) != (shift == nullptr) || (scale && (!al16(scale) || !al16(shift)))) return MYDET_E_BADARG;
@@ -797,8 +838,11 @@ extern "C" int mydet_dwconv_f32(const float *x, int64_t ldx, const float *w, con
     DwArgs p;
     p.x = x; p.w = w; p.scale = scale; p.shift = shift; p.y = y; p.partial = se_partial; p.ldx = ldx; p.ldy = ldy;
     p.C = C; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.pad_t = pad_t; p.pad_l = pad_l; p.act = act; p.S = S; p.total = 0;
+    p.se = se ? *se : NO_SE_TAIL;
+    if (const int e = mydet_se_tail_check(p.se, C)) return e;
+    if (p.se.gate && (S <= 0 || S > 4096 || B > 65535)) return MYDET_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
-    if (se_partial && S != mydet_dwconv_slices(Ho, Wo, C, K, stride)) return MYDET_E_BADARG;
+    if ((se_partial || p.se.gate) && S != mydet_dwconv_slices(Ho, Wo, C, K, stride)) return MYDET_E_BADARG;
     if (stride == 1 && dw_tiled() && C >= 16) return K == 3 ? launch_dw_tile<3>(p, B, st) : launch_dw_tile<5>(p, B, st);
     if (K == 3) return stride == 1 ? launch_dw<3, 1>(p, B, st) : launch_dw<3, 2>(p, B, st);
     return stride == 1 ? launch_dw<5, 1>(p, B, st) : launch_dw<5, 2>(p, B, st);

@@ -23,6 +23,7 @@
 // current 32 are in their depthwise phase.
 // Built with -ffp-contract=off like the other EfficientNet kernels.
 #include "common.h"
+#include "se_tail.h"
 
 namespace {
 
@@ -31,6 +32,7 @@ struct MbArgs {
     float *y, *partial;
     int64_t ldx, ldy;
     int H, W, Ho, Wo, Cin, Cexp, pad_t, pad_l, tiles_x, tiles_per_img, chunks, S;
+    SeTail se;                // se.gate != NULL: the squeeze-excite gate is finished inside the launch (se_tail.h)
 };
 
 template <int K, int ST>
@@ -51,6 +53,9 @@ __global__ __launch_bounds__(256, 2) void mbconv_expand_dw_kernel(const MbArgs p
     float *sval = se + NPIXP * 32;                    // [NPIXP]            1 inside the image, 0 outside
     float *swd = sval + NPIXP;                        // [K*K][32]          depthwise taps of the current chunk
     f32x4 *red = reinterpret_cast<f32x4 *>(swd + K * K * 32);   // [4][8]   SE partial sums per wave
+    float *selds = reinterpret_cast<float *>(red + 32);         // [MYDET_SE_LDS_FLOATS] in-launch SE tail (se_tail.h)
+    float *tots = selds + MYDET_SE_LDS_FLOATS;                  // [chunks * 32]  this tile's channel sums, all chunks
+    const bool se_on = p.se.gate != nullptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = blockIdx.x;
     const int b = t / p.tiles_per_img, r = t - b * p.tiles_per_img;
@@ -213,16 +218,27 @@ __global__ __launch_bounds__(256, 2) void mbconv_expand_dw_kernel(const MbArgs p
         for (int off = 8; off < 64; off <<= 1)
 #pragma unroll
             for (int e = 0; e < 4; ++e) sum[e] += __shfl_xor(sum[e], off);
-        if (p.partial && lane < 8) red[wave * 8 + lane] = sum;
+        if ((p.partial || se_on) && lane < 8) red[wave * 8 + lane] = sum;
         __syncthreads();                               // expanded tile and taps are free for the next chunk; red is visible
-        if (p.partial && tid < 8 && qv) {
-            f32x4 tot = red[tid];
+        if ((p.partial || se_on) && tid < 8) {
+            f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+            if (qv) {
+                tot = red[tid];
 #pragma unroll
-            for (int w = 1; w < 4; ++w)
+                for (int w = 1; w < 4; ++w)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) tot[e] += red[w * 8 + tid][e];
-            *reinterpret_cast<f32x4 *>(p.partial + ((int64_t)b * (p.S + 1) + r) * p.Cexp + cq) = tot;
+                    for (int e = 0; e < 4; ++e) tot[e] += red[w * 8 + tid][e];
+                if (p.partial) *reinterpret_cast<f32x4 *>(p.partial + ((int64_t)b * (p.S + 1) + r) * p.Cexp + cq) = tot;
+            }
+            if (se_on) *reinterpret_cast<f32x4 *>(&tots[c0 + tid * 4]) = tot;
         }
+    }
+    if (se_on) {        // this tile's share of W1 . sums over all its channels, once, then the per-image hand-over (se_tail.h)
+        if (tid < MYDET_SE_MAX_CSE) selds[tid] = 0.f;
+        __syncthreads();
+        se_fc1_accumulate(p.se, p.Cexp, tots, 0, p.Cexp, selds);
+        __syncthreads();
+        se_tail_finish(p.se, selds, p.Cexp, p.Ho * p.Wo, b, r, p.tiles_per_img);
     }
 }
 
@@ -233,9 +249,10 @@ int launch(MbArgs &p, int B, hipStream_t stream) {
     using G = MbGeom<K, ST>;
     p.tiles_x = (p.Wo + G::TW - 1) / G::TW;
     p.tiles_per_img = p.tiles_x * ((p.Ho + G::TH - 1) / G::TH);
-    if (p.partial && p.S != p.tiles_per_img) return MYDET_E_BADARG;
+    if ((p.partial || p.se.gate) && p.S != p.tiles_per_img) return MYDET_E_BADARG;
     p.chunks = (p.Cexp + 31) / 32;
-    const size_t lds = ((size_t)((G::NPIXP * (p.Cin + 1) + 3) & ~3) + (size_t)G::NPIXP * 33 + (size_t)K * K * 32 + 128) * sizeof(float);
+    const size_t lds = ((size_t)((G::NPIXP * (p.Cin + 1) + 3) & ~3) + (size_t)G::NPIXP * 33 + (size_t)K * K * 32 + 128 +
+                        (p.se.gate ? (size_t)MYDET_SE_LDS_FLOATS + (size_t)p.chunks * 32 : 0)) * sizeof(float);
     if (lds > 80 * 1024) return MYDET_E_UNSUPP;
     const int64_t grid = (int64_t)B * p.tiles_per_img;
     if (grid > 0x7fffffff) return MYDET_E_UNSUPP;
@@ -254,7 +271,7 @@ extern "C" int mydet_mbconv_tiles(int Ho, int Wo, int stride) {
 extern "C" int mydet_mbconv_expand_dw_f32(const float *x, int64_t ldx, const float *w_expand, const float *shift0,
                                           const float *w_dw, const float *shift1, float *y, int64_t ldy, int B, int H, int W, int Cin,
                                           int Cexp, int K, int stride, int pad_t, int pad_l, int Ho, int Wo,
-                                          float *se_partial, int S, void *stream) {
+                                          float *se_partial, int S, const mydet_se_tail *se, void *stream) {
     if (!x || !w_expand || !shift0 || !w_dw || !shift1 || !y) return MYDET_E_BADARG;
     if (B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cexp <= 0) return MYDET_E_BADARG;
     if ((Cin & 3) || (Cexp & 3) || (ldx & 3) || (ldy & 3) || ldx < Cin || ldy < Cexp) return MYDET_E_BADARG;
@@ -265,6 +282,9 @@ extern "C" int mydet_mbconv_expand_dw_f32(const float *x, int64_t ldx, const flo
     p.x = x; p.we = w_expand; p.shift0 = shift0; p.wd = w_dw; p.shift1 = shift1;
     p.y = y; p.partial = se_partial; p.ldx = ldx; p.ldy = ldy; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.Cin = Cin;
     p.Cexp = Cexp; p.pad_t = pad_t; p.pad_l = pad_l; p.S = S;
+    const SeTail none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    p.se = se ? *se : none;
+    if (const int e = mydet_se_tail_check(p.se, Cexp)) return e;
     hipStream_t st = (hipStream_t)stream;
     // the (kernel, stride, Cin) combinations of EfficientNet-B0..B2 stages 2-4 (external/efficientnet/utils.py:258-263)
     if (K == 3 && stride == 2 && Cin == 16) return launch<3, 2, 16>(p, B, st);

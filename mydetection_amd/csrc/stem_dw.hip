@@ -19,6 +19,7 @@
 //      chain per channel), swish, 128-byte-per-pixel stores, and the tile's channel sums (fixed order, no atomics).
 // Built with -ffp-contract=off like the other EfficientNet kernels.
 #include "common.h"
+#include "se_tail.h"
 
 namespace {
 
@@ -33,6 +34,7 @@ struct SdArgs {
     float *y, *partial;
     int64_t sxb, sxc, sxh, sxw, ldy;
     int H, W, Hs, Ws, pad_t, pad_l, tiles_x, tiles_per_img, S;
+    SeTail se;                // se.gate != NULL: block 0's squeeze-excite gate is finished inside the launch (se_tail.h)
 };
 
 __global__ __launch_bounds__(256, 2) void stem_dw_kernel(const SdArgs p) {
@@ -165,15 +167,25 @@ __global__ __launch_bounds__(256, 2) void stem_dw_kernel(const SdArgs p) {
     for (int off = 8; off < 64; off <<= 1)
 #pragma unroll
         for (int e = 0; e < 4; ++e) sum[e] += __shfl_xor(sum[e], off);
-    if (p.partial && lane < 8) red[wave * 8 + lane] = sum;
-    __syncthreads();
-    if (p.partial && tid < 8) {
+    const bool se_on = p.se.gate != nullptr;
+    if ((p.partial || se_on) && lane < 8) red[wave * 8 + lane] = sum;
+    __syncthreads();                                   // (every thread is done with the stem tile `se`: the tail reuses it)
+    float *selds = se, *tots = se + MYDET_SE_LDS_FLOATS;
+    if ((p.partial || se_on) && tid < 8) {
         f32x4 tot = red[tid];
 #pragma unroll
         for (int w = 1; w < 4; ++w)
 #pragma unroll
             for (int e = 0; e < 4; ++e) tot[e] += red[w * 8 + tid][e];
-        *reinterpret_cast<f32x4 *>(p.partial + ((int64_t)b * (p.S + 1) + r) * SD_C + tid * 4) = tot;
+        if (p.partial) *reinterpret_cast<f32x4 *>(p.partial + ((int64_t)b * (p.S + 1) + r) * SD_C + tid * 4) = tot;
+        if (se_on) *reinterpret_cast<f32x4 *>(&tots[tid * 4]) = tot;
+    }
+    if (se_on) {        // this tile's share of W1 . sums, then the per-image hand-over (se_tail.h)
+        if (tid >= 64 && tid < 64 + MYDET_SE_MAX_CSE) selds[tid - 64] = 0.f;
+        __syncthreads();
+        se_fc1_accumulate(p.se, SD_C, tots, 0, SD_C, selds);
+        __syncthreads();
+        se_tail_finish(p.se, selds, SD_C, p.Hs * p.Ws, b, r, p.tiles_per_img);
     }
 }
 
@@ -183,7 +195,8 @@ inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 extern "C" int mydet_stem_dw_f32(const float *x, int64_t sxb, int64_t sxc, int64_t sxh, int64_t sxw, const float *w_stem,
                                  const float *shift0, const float *w_dw, const float *shift1, float *y, int64_t ldy, int B, int H,
-                                 int W, int C, int pad_t, int pad_l, int Hs, int Ws, float *se_partial, int S, void *stream) {
+                                 int W, int C, int pad_t, int pad_l, int Hs, int Ws, float *se_partial, int S,
+                                 const mydet_se_tail *se, void *stream) {
     if (!x || !w_stem || !shift0 || !w_dw || !shift1 || !y || B <= 0 || H <= 0 || W <= 0 || Hs <= 0 || Ws <= 0)
         return MYDET_E_BADARG;
     if (C != SD_C) return MYDET_E_UNSUPP;
@@ -198,7 +211,10 @@ extern "C" int mydet_stem_dw_f32(const float *x, int64_t sxb, int64_t sxc, int64
     p.tiles_x = (Ws + SD_TW - 1) / SD_TW;
     p.tiles_per_img = p.tiles_x * ((Hs + SD_TH - 1) / SD_TH);
     p.S = S;
-    if (se_partial && S != p.tiles_per_img) return MYDET_E_BADARG;
+    const SeTail none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    p.se = se ? *se : none;
+    if (const int e = mydet_se_tail_check(p.se, C)) return e;
+    if ((se_partial || p.se.gate) && S != p.tiles_per_img) return MYDET_E_BADARG;
     const int64_t grid = (int64_t)B * p.tiles_per_img;
     if (grid > 0x7fffffff) return MYDET_E_UNSUPP;
     hipLaunchKernelGGL(stem_dw_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);

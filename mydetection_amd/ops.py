@@ -158,11 +158,51 @@ def wino4_workspace(device, nbytes):
     return ws
 
 
+_SE_SHARES = {}
+SE_MAX_CSE = 96
+# MYDET_SE_IN_DW=0: the squeeze-excite gate as a launch of its own (mydet_se_gate_f32) behind every depthwise launch (A/B)
+SE_IN_DW = os.environ.get('MYDET_SE_IN_DW', '1') != '0'
+# The in-launch tail is used from this many (expanded) channels up.  Measured per block on a lane of 8 images
+# (profiles/r05_se_in_dw.txt: depthwise + gate launch vs depthwise launch with the tail): 1152 channels 34.5 -> 25.3 us,
+# 1920 channels 48.0 -> 36.6 us -- the gate launch is a 13-32 us chain of dependent round trips on one CU per image there --,
+# but +-1 us at 16 .. 672 channels (the gate launch costs 7-10 us, the finishing workgroup about as much) and 3 us WORSE in
+# the fused expand + depthwise launches, so the narrow blocks keep the separate launch.  MYDET_SE_IN_DW_MIN_C overrides.
+SE_IN_DW_MIN_C = int(os.environ.get('MYDET_SE_IN_DW_MIN_C', '1000'))
+
+
+def se_shares(device, n_floats):
+    """Per-device, per-lane share buffer of the in-launch squeeze-excite tail (include/mydet.h: mydet_se_tail.hpart): every
+    word holds the "empty" mark between launches by the kernels' own protocol, so ONE buffer serves every layer of a lane's
+    stream.  Grows to the largest layer seen (filled with the mark when it is made; not during a stream capture)."""
+    key = (device.type, device.index, _LANE)
+    buf = _SE_SHARES.get(key)
+    if buf is None or buf.numel() < n_floats:
+        if device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('se_shares: the share buffer would grow during stream capture; run the model once eagerly first')
+        n = max(int(n_floats), 1 << 20)
+        buf = _SE_SHARES[key] = torch.full((n,), _lib.SE_EMPTY_WORD, dtype=torch.int32, device=device).view(torch.float32)
+    return buf
+
+
+def _se_tail(se, B, C, groups, device):
+    """(ctypes struct, gate tensor, tensors to keep alive) for `se` = (w1 [Cse,C], b1, w2t [Cse,C], b2) or (None, None, ())."""
+    if se is None:
+        return None, None, ()
+    w1, b1, w2t, b2 = se
+    Cse = w1.shape[0]
+    assert tuple(w1.shape) == (Cse, C) and tuple(w2t.shape) == (Cse, C) and w1.is_contiguous() and w2t.is_contiguous()
+    assert Cse <= SE_MAX_CSE and groups > 0
+    gate = torch.empty((B, C), dtype=torch.float32, device=device)
+    hpart = se_shares(device, B * groups * Cse)
+    t = _lib.SeTail(w1.data_ptr(), b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), gate.data_ptr(), hpart.data_ptr(), Cse)
+    return t, gate, (hpart, w1, b1, w2t, b2)
+
+
 def live_workspaces(device):
     """The scratch tensors launches on `device` are currently handed (split-K workspace, F(4x4) transform-domain
     input).  A captured launch sequence holds on to this list for as long as it can be replayed."""
     key = (device.type, device.index)
-    return [t for d in (_WORKSPACE, _WINO4_WS) for k, t in d.items() if k[:2] == key]
+    return [t for d in (_WORKSPACE, _WINO4_WS, _SE_SHARES) for k, t in d.items() if k[:2] == key]
 
 
 def conv_out_size(n, k, stride, pad_lo, pad_hi):
@@ -311,9 +351,11 @@ def se_slices(n_pixels):
     return max(1, min(128, n_pixels // 16))
 
 
-def dwconv(x, w_kkc, scale, shift, k, stride, pad, act, squeeze=False, interior=False):
+def dwconv(x, w_kkc, scale, shift, k, stride, pad, act, squeeze=False, interior=False, se=None):
     """Depthwise k x k conv, y = act(conv*scale + shift); w_kkc [k,k,C]; pad=(top,left,bottom,right).
-    squeeze=True also returns the per-slice channel sums [B,S,C] of y (input of `se_gate`)."""
+    squeeze=True also returns the per-slice channel sums [B,S,C] of y (input of `se_gate`).
+    se=(w1 [Cse,C], b1 [Cse], w2t [Cse,C], b2 [C]): the launch also finishes the squeeze-excite gate of y
+    (include/mydet.h: mydet_se_tail) and (y, gate [B,C]) is returned -- no squeeze sums, no gate launch."""
     require_gpu(x, 'dwconv')
     x, ldx = to_nhwc(x)
     B, C, H, W = x.shape
@@ -321,16 +363,21 @@ def dwconv(x, w_kkc, scale, shift, k, stride, pad, act, squeeze=False, interior=
     Wo = conv_out_size(W, k, stride, pad[1], pad[3])
     out, ldy = empty_nhwc(B, C, Ho, Wo, x.device)
     partial, S = None, 0
-    if squeeze:
+    if squeeze or se is not None:
         S = _lib.lib().mydet_dwconv_slices(Ho, Wo, C, k, stride)      # what the kernel chosen for this layer writes
+    if squeeze:
         partial = torch.empty((B, S + 1, C), dtype=torch.float32, device=x.device)    # slice S: scratch for the mean
+    tail, gate, keep = _se_tail(se, B, C, _lib.lib().mydet_dwconv_se_groups(Ho, Wo, C, k, stride) if se is not None else 0, x.device)
     t0 = TIMER.start() if TIMER else None
     code = _lib.lib().mydet_dwconv_f32(_ptr(x), ldx, _ptr(w_kkc), _ptr(scale), _ptr(shift), _ptr(out), ldy, B, H, W, C,
-                                       k, stride, pad[0], pad[1], Ho, Wo, act, _ptr(partial), S, _stream())
+                                       k, stride, pad[0], pad[1], Ho, Wo, act, _ptr(partial), S,
+                                       ctypes.byref(tail) if tail is not None else None, _stream())
     if t0:
         TIMER.stop(f'dwconv {C} k{k}s{stride} {H}x{W}' if TIMER_DETAIL else 'dwconv', t0, *[4.0 * B * C * (H * W + Ho * Wo)] * 2,
                    fused=0.0 if interior is True else (4.0 * B * C * H * W if interior == 'out' else None))
     _lib.check(code, 'mydet_dwconv_f32')
+    if se is not None:
+        return out, gate
     return (out, partial) if squeeze else out
 
 
@@ -348,11 +395,12 @@ def fold_scale(w, scale):
     return (w * scale.view(-1, *([1] * (w.dim() - 1)))).contiguous()
 
 
-def mbconv_expand_dw(x, w_expand, shift0, w_dw, shift1, k, stride, pad):
+def mbconv_expand_dw(x, w_expand, shift0, w_dw, shift1, k, stride, pad, se=None):
     """swish(BN1(depthwise_k(swish(BN0(expand1x1(x)))))) and the per-tile channel sums of the result (SE squeeze) in
     one launch; w_expand OHWI [Cexp,1,1,Cin] and w_dw [k,k,Cexp] carry the BatchNorm scales (`fold_scale`), shift0 /
     shift1 are the folded shifts; pad=(top,left,bottom,right) of the expanded map.
-    Returns (y [B,Cexp,Ho,Wo], partial [B,S+1,Cexp])."""
+    Returns (y [B,Cexp,Ho,Wo], partial [B,S+1,Cexp]) -- or, with se=(w1, b1, w2t, b2) as in `dwconv`, (y, gate [B,Cexp]):
+    the launch finishes the squeeze-excite gate itself."""
     require_gpu(x, 'mbconv_expand_dw')
     x, ldx = to_nhwc(x)
     B, Cin, H, W = x.shape
@@ -361,28 +409,30 @@ def mbconv_expand_dw(x, w_expand, shift0, w_dw, shift1, k, stride, pad):
     Wo = conv_out_size(W, k, stride, pad[1], pad[3])
     out, ldy = empty_nhwc(B, Cexp, Ho, Wo, x.device)
     S = _lib.lib().mydet_mbconv_tiles(Ho, Wo, stride)
-    partial = torch.empty((B, S + 1, Cexp), dtype=torch.float32, device=x.device)
+    partial = torch.empty((B, S + 1, Cexp), dtype=torch.float32, device=x.device) if se is None else None
+    tail, gate, keep = _se_tail(se, B, Cexp, S, x.device)
     t0 = TIMER.start() if TIMER else None
     code = _lib.lib().mydet_mbconv_expand_dw_f32(_ptr(x), ldx, _ptr(w_expand), _ptr(shift0), _ptr(w_dw),
                                                  _ptr(shift1), _ptr(out), ldy, B, H, W, Cin, Cexp, k, stride,
-                                                 pad[0], pad[1], Ho, Wo, _ptr(partial), S, _stream())
+                                                 pad[0], pad[1], Ho, Wo, _ptr(partial), S,
+                                                 ctypes.byref(tail) if tail is not None else None, _stream())
     if t0:      # algorithmic bytes of the two reference layers it replaces: expand (in + out) and depthwise (in + out)
         nb = 4.0 * B * (H * W * (Cin + Cexp) + Cexp * (H * W + Ho * Wo))
         TIMER.stop(f'mbconv_expand_dw {Cin}->{Cexp} k{k}s{stride} {H}x{W}' if TIMER_DETAIL else 'mbconv_expand_dw', t0,
                    2.0 * B * H * W * Cin * Cexp, nb, fused=4.0 * B * H * W * Cin)
     _lib.check(code, 'mydet_mbconv_expand_dw_f32')
-    return out, partial
+    return (out, gate) if se is not None else (out, partial)
 
 
 # MYDET_FUSED_STEM=0 keeps the EfficientNet stem and block 0's depthwise conv as two launches
 FUSED_STEM_DW = os.environ.get('MYDET_FUSED_STEM', '1') != '0'
 
 
-def stem_dw(x, w_stem, shift0, w_dw, shift1, pad):
+def stem_dw(x, w_stem, shift0, w_dw, shift1, pad, se=None):
     """swish(BN1(depthwise3x3(swish(BN0(conv3x3_s2(image)))))) and the per-tile channel sums of the result in one launch
     (EfficientNet stem + block 0's depthwise conv).  x [B,3,H,W] in any strides; w_stem OHWI [32,3,3,3] and w_dw
     [3,3,32] carry the BatchNorm scales (`fold_scale`); pad = the stem's (top, left, bottom, right).
-    Returns (y [B,32,Hs,Ws], partial [B,S+1,32])."""
+    Returns (y [B,32,Hs,Ws], partial [B,S+1,32]) -- or, with se=(w1, b1, w2t, b2) as in `dwconv`, (y, gate [B,32])."""
     require_gpu(x, 'stem_dw')
     assert x.dtype == torch.float32 and x.shape[1] == 3
     B, _, H, W = x.shape
@@ -391,15 +441,17 @@ def stem_dw(x, w_stem, shift0, w_dw, shift1, pad):
     Ws = conv_out_size(W, 3, 2, pad[1], pad[3])
     out, ldy = empty_nhwc(B, C, Hs, Ws, x.device)
     S = _lib.lib().mydet_mbconv_tiles(Hs, Ws, 1)
-    partial = torch.empty((B, S + 1, C), dtype=torch.float32, device=x.device)
+    partial = torch.empty((B, S + 1, C), dtype=torch.float32, device=x.device) if se is None else None
+    tail, gate, keep = _se_tail(se, B, C, S, x.device)
     sb, sc, sh, sw = x.stride()
     t0 = TIMER.start() if TIMER else None
     code = _lib.lib().mydet_stem_dw_f32(_ptr(x), sb, sc, sh, sw, _ptr(w_stem), _ptr(shift0), _ptr(w_dw), _ptr(shift1), _ptr(out),
-                                        ldy, B, H, W, C, pad[0], pad[1], Hs, Ws, _ptr(partial), S, _stream())
+                                        ldy, B, H, W, C, pad[0], pad[1], Hs, Ws, _ptr(partial), S,
+                                        ctypes.byref(tail) if tail is not None else None, _stream())
     if t0:      # reference-layer bytes: stem (image in, map out) + depthwise (map in, map out)
         TIMER.stop('stem_dw', t0, 0.0, 4.0 * B * (3 * H * W + 3 * C * Hs * Ws), fused=4.0 * B * (3 * H * W + C * Hs * Ws))
     _lib.check(code, 'mydet_stem_dw_f32')
-    return out, partial
+    return (out, gate) if se is not None else (out, partial)
 
 
 def channel_sums(x):

@@ -609,6 +609,79 @@ def test_se_tail_from_slice_sums(dev, C, Cse, S):
     assert torch.equal(ops.se_gate(partial.to(dev), *args), gate)
 
 
+@pytest.mark.parametrize('kind,C,Cse,k,s,H,W', [
+    ('dw', 1152, 48, 5, 1, 20, 20),        # LDS-tiled kernel, 36 channel chunks x 6 tiles per image (blocks 17-20)
+    ('dw', 1920, 80, 3, 1, 20, 20),        # the widest block: Cse > 64 (two passes of the share computation)
+    ('dw', 144, 6, 3, 1, 37, 41),          # ragged tiles, a last chunk of 16 channels
+    ('dw', 16, 4, 3, 1, 64, 96),           # the narrow (4-quad, 8 x 32) tile
+    ('dw', 672, 28, 5, 2, 40, 40),         # stride 2: the slice kernel (all channels in one workgroup per slice)
+    ('dw', 240, 10, 3, 2, 31, 33),         # stride 2, odd sizes
+    ('mbconv', 24, 6, 3, 1, 40, 48),       # fused expand + depthwise (Cexp 144: 5 chunks, the last of 16 channels)
+    ('mbconv', 16, 4, 3, 2, 64, 64),       # ... stride 2
+    ('stem', 32, 8, 3, 1, 96, 64),         # stem + block 0's depthwise conv
+])
+def test_se_gate_inside_depthwise_launch(dev, kind, C, Cse, k, s, H, W):
+    """The squeeze-excite gate finished INSIDE the launch that produces the depthwise output (csrc/se_tail.h; `se=` of
+    ops.dwconv / mbconv_expand_dw / stem_dw: every workgroup adds its share of W1 . sums, the last workgroup of an image
+    finishes) == the gate of the separate launch (squeeze sums + mydet_se_gate_f32) to float32 round-off and == float64 of
+    the launch's own output; the output map is bit-identical with and without the tail; three runs give the same bits (the
+    share buffer is back to its "empty" mark after every launch, the sums run in a fixed order); batch of 3."""
+    from mydetection_amd import ops
+    from mydetection_amd.external.efficientnet.model import static_same_pad
+    g = torch.Generator().manual_seed(C * 7 + H)
+    B = 3
+    pad = static_same_pad(k, s, 240)
+    if kind == 'dw':
+        x = torch.randn(B, C, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        wd = (torch.randn(k, k, C, generator=g) / k).to(dev)
+        sc, sh = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.3).to(dev)
+        Cg = C
+
+        def run(se=None):
+            if se is None:
+                return ops.dwconv(x, wd, sc, sh, k, s, pad, ops.ACT_SWISH, squeeze=True)
+            return ops.dwconv(x, wd, sc, sh, k, s, pad, ops.ACT_SWISH, se=se)
+    elif kind == 'mbconv':
+        cin, Cg = C, C * 6
+        x = torch.randn(B, cin, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        we = (torch.randn(Cg, 1, 1, cin, generator=g) / cin ** 0.5).to(dev)
+        wd = (torch.randn(k, k, Cg, generator=g) / k).to(dev)
+        sh0, sh1 = (torch.randn(Cg, generator=g) * 0.3).to(dev), (torch.randn(Cg, generator=g) * 0.3).to(dev)
+
+        def run(se=None):
+            return ops.mbconv_expand_dw(x, we, sh0, wd, sh1, k, s, pad, se=se)
+    else:
+        Cg = 32
+        x = (torch.rand(B, 3, H, W, generator=g) * 2 - 1).to(dev)
+        ws = (torch.randn(32, 3, 3, 3, generator=g) * 0.3).to(dev)
+        wd = (torch.randn(3, 3, 32, generator=g) * 0.3).to(dev)
+        sh0, sh1 = (torch.randn(32, generator=g) * 0.2).to(dev), (torch.randn(32, generator=g) * 0.2).to(dev)
+
+        def run(se=None):
+            return ops.stem_dw(x, ws, sh0, wd, sh1, (0, 0, 1, 1), se=se)
+    w1 = (torch.randn(Cse, Cg, generator=g) / Cg ** 0.5).to(dev)
+    b1 = (torch.randn(Cse, generator=g) * 0.1).to(dev)
+    w2t = (torch.randn(Cse, Cg, generator=g) * 0.3).to(dev)
+    b2 = (torch.randn(Cg, generator=g) * 0.1).to(dev)
+    y0, partial = run()
+    gate0 = ops.se_gate(partial, y0.shape[2] * y0.shape[3], w1, b1, w2t, b2)
+    y1, gate1 = run((w1, b1, w2t, b2))
+    assert torch.equal(y1.contiguous(), y0.contiguous())
+    assert tuple(gate1.shape) == (B, Cg)
+    m = y0.double().mean(dim=(2, 3)).cpu()
+    h = m @ w1.double().cpu().t() + b1.double().cpu()
+    h = h * torch.sigmoid(h)
+    ref = torch.sigmoid(h @ w2t.double().cpu() + b2.double().cpu())
+    assert (gate1.cpu().double() - ref).abs().max().item() < 3e-6
+    assert (gate1 - gate0).abs().max().item() < 3e-6
+    for _ in range(2):
+        y2, gate2 = run((w1, b1, w2t, b2))
+        assert torch.equal(gate2, gate1) and torch.equal(y2.contiguous(), y0.contiguous())
+    from mydetection_amd import _lib
+    shares = ops.se_shares(dev, 1).view(torch.int32)
+    assert bool((shares == _lib.SE_EMPTY_WORD).all())
+
+
 @pytest.mark.parametrize('Cin,Cout,H,W,gated,res,act', [
     (16, 16, 192, 192, True, True, 0), (32, 16, 181, 183, True, False, 0), (96, 24, 192, 176, True, False, 0),
     (144, 24, 181, 183, True, True, 0), (144, 40, 192, 176, True, False, 0), (240, 40, 181, 183, True, True, 0),

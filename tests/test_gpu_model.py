@@ -523,7 +523,7 @@ def test_effdet_full_size_properties_640(name, batch):
         bp, cp, sp = m.forward_candidates(x[perm].contiguous())
         assert torch.equal(b2, bb) and torch.equal(c2, ci) and torch.equal(s2, sc)
         # to 1e-5, not bit for bit: where a tile's K range is cut (split-K tail) depends on its position in the grid
-        np.testing.assert_allclose(sp.cpu().numpy(), sc[perm].cpu().numpy(), rtol=1e-4, atol=3e-5)      # (head gain: see synth._YOLO_TARGETS)
+        np.testing.assert_allclose(sp.cpu().numpy(), sc[perm].cpu().numpy(), rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(bp.cpu().numpy(), bb[perm].cpu().numpy(), rtol=1e-5, atol=1e-5)
         assert (cp != ci[perm]).float().mean().item() < 1e-4
         for i in (0, batch - 1):
@@ -732,7 +732,7 @@ def test_full_size_properties_batch32_640(model):
             ops.WINOGRAD = True
     assert bb.shape == (32, 25200, 4)
     assert torch.equal(b2, bb) and torch.equal(c2, ci) and torch.equal(s2, sc)
-    np.testing.assert_allclose(sp.cpu().numpy(), sc[perm].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(sp.cpu().numpy(), sc[perm].cpu().numpy(), rtol=1e-4, atol=3e-5)      # (head gain: see synth._YOLO_TARGETS)
     np.testing.assert_allclose(bp.cpu().numpy(), bb[perm].cpu().numpy(), rtol=1e-5, atol=1e-5)
     assert (cp != ci[perm]).float().mean().item() < 1e-4
     np.testing.assert_allclose(sc.cpu().numpy(), sd_.cpu().numpy(), rtol=RTOL, atol=ATOL)
