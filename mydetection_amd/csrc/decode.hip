@@ -143,25 +143,36 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs p) {
             const float *rowp = sm + px * p.row;
             const float *cl = rowp + a * p.cls_astride + p.cls_c0;
             // class max / first argmax (strict >: the first maximum wins, as torch.max)
-            float best = cl[k_lo];
+            // ... and the runner-up VALUE (`second`: the largest logit at another index, equal to `best` on an exact tie): it
+            // decides below whether the float32 logistic can merge the two
+            float best = cl[k_lo], second = -__builtin_inff();
             int bi = k_lo;
             for (int k0 = k_lo + 1; k0 < k_hi; k0 += 8) {      // 8 LDS reads in flight, then the ordered compare chain
                 float x[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = cl[k0 + j < k_hi ? k0 + j : k_hi - 1];   // clamped repeats never win
+                for (int j = 0; j < 8; ++j) x[j] = cl[k0 + j < k_hi ? k0 + j : k_hi - 1];   // clamped repeats never win ...
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (x[j] > best) { best = x[j]; bi = k0 + j; }
+                for (int j = 0; j < 8; ++j) {
+                    const bool real = k0 + j < k_hi;           // ... and must not pose as a runner-up either
+                    const bool gt = x[j] > best;
+                    second = gt ? best : ((real && x[j] > second) ? x[j] : second);
+                    bi = gt ? k0 + j : bi;
+                    best = gt ? x[j] : best;
+                }
             }
             for (int sft = 1; sft < p.tpc; sft <<= 1) {
-                const float ob = __shfl_xor(best, sft);
+                const float ob = __shfl_xor(best, sft), os = __shfl_xor(second, sft);
                 const int obi = __shfl_xor(bi, sft);
                 const bool take = (part & sft) ? !(best > ob) : (ob > best);     // the upper share wins only when strictly greater
+                second = fmaxf(fmaxf(second, os), take ? best : ob);             // the loser's best is a runner-up too
                 best = take ? ob : best;
                 bi = take ? obi : bi;
             }
             float cmax;
-            if (best < 5.0f && best > -80.0f) {
+            // Below 5 distinct logits have distinct float32 logistics.  From 5 up two logits can share one -- but only when the
+            // runner-up is within 2 of the best (or both are past 15: the logistic of 17 and more is exactly 1); otherwise the
+            // first maximum of the logits IS the first maximum of the logistics and the scan above has it.
+            if (best > -80.0f && (best < 5.0f || second < fminf(best - 2.0f, 15.0f))) {
                 cmax = mydet_sigmoid(best);
             } else {                                   // near saturation: compare the sigmoid values themselves
                 // ... of the classes that can tie with the best one.  The logistic is monotonic, and a logit two below the best
