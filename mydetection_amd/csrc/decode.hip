@@ -182,12 +182,16 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs p) {
                 const float lim = best > -80.0f ? fminf(best - 2.0f, 15.0f) : -__builtin_inff();
                 cmax = -1.0f;
                 bi = 0;
-                for (int k = 0; k < p.C; ++k) {
-                    const float xk = cl[k];
-                    if (xk >= lim) {
-                        const float sv = mydet_sigmoid(xk);
-                        if (sv > cmax) { cmax = sv; bi = k; }
-                    }
+                for (int k0 = 0; k0 < p.C; k0 += 8) {          // 8 LDS reads in flight, as in the scan above
+                    float x[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = k0 + j < p.C ? cl[k0 + j] : -__builtin_inff();
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (x[j] >= lim) {                     // rare: a logistic only for the few classes that can tie
+                            const float sv = mydet_sigmoid(x[j]);
+                            if (sv > cmax) { cmax = sv; bi = k0 + j; }
+                        }
                 }
             }
             if (part) continue;                        // lane 2c finishes the candidate

@@ -705,7 +705,7 @@ def test_full_size_properties_batch32_640(model):
     """BASELINE configs[1] size (batch 32, 640x640; the stream-K Winograd schedule and every conv tile shape of the
     benchmark are live here), through properties that need no CPU forward:
       * the same batch twice gives the same bits (the split-K / stream-K schedules sum in a fixed order, no atomics);
-      * permuting the images permutes the candidates (no cross-image coupling) -- scores to 3e-5 (boxes 1e-5), not bit for bit:
+      * permuting the images permutes the candidates (no cross-image coupling) -- scores to 3e-5, boxes to 5e-5, not bit for bit:
         where a tile's K range is cut depends on the tile's position in the schedule;
       * the Winograd layers agree with the same network on the direct implicit-GEMM kernel within the tolerance;
       * NMS output invariants per image: count <= 512, score >= conf, class ascending / score descending inside a
@@ -733,7 +733,7 @@ def test_full_size_properties_batch32_640(model):
     assert bb.shape == (32, 25200, 4)
     assert torch.equal(b2, bb) and torch.equal(c2, ci) and torch.equal(s2, sc)
     np.testing.assert_allclose(sp.cpu().numpy(), sc[perm].cpu().numpy(), rtol=1e-4, atol=3e-5)      # (head gain: see synth._YOLO_TARGETS)
-    np.testing.assert_allclose(bp.cpu().numpy(), bb[perm].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(bp.cpu().numpy(), bb[perm].cpu().numpy(), rtol=5e-5, atol=5e-5)
     assert (cp != ci[perm]).float().mean().item() < 1e-4
     np.testing.assert_allclose(sc.cpu().numpy(), sd_.cpu().numpy(), rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(bb.cpu().numpy(), bd.cpu().numpy(), rtol=RTOL, atol=ATOL)
