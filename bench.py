@@ -219,11 +219,18 @@ def parity_check(cand, rec, conf, nms, oracle_cand=None, images=2, extra_conf=()
         b_err = float((np.abs(bb - obb) / (1e-4 + 1e-4 * np.abs(obb))).max())
         safe = equal = 0
         kept = {f'conf_{conf}': [int(k) for k in count]}     # detections per image at every threshold: the sets are not empty
+        jac = []                                             # agreement of the kept candidate ids with the oracle's own detections,
+                                                             # every (image, threshold) pair, margin-safe or not (Jaccard index)
+
+        def jaccard(mine, ref):
+            u = len(np.union1d(mine, ref))
+            return 1.0 if u == 0 else len(np.intersect1d(mine, ref)) / u
         for b in range(n):
+            _, rc, _, ri = opp.post_process(obb[b], oci[b], osc[b], conf, nms)
+            k = int(count[b])
+            jac.append(jaccard(index[b, :k], ri))
             if opp.decision_margins(osc[b], oci[b], conf, eps=max(2.0 * s_err, 2e-6)) is None:
                 safe += 1
-                _, rc, _, ri = opp.post_process(obb[b], oci[b], osc[b], conf, nms)
-                k = int(count[b])
                 equal += int(k == len(ri) and np.array_equal(index[b, :k], ri) and np.array_equal(cls[b, :k], rc))
         extra = {f'conf_{conf}': f'{equal}/{safe}'}
         # the same comparison at the other two thresholds (fresh post-process launches on the step's candidates)
@@ -234,10 +241,11 @@ def parity_check(cand, rec, conf, nms, oracle_cand=None, images=2, extra_conf=()
             kept[f'conf_{t}'] = [int(k) for k in cnt_t]
             s_t = e_t = 0
             for b in range(n):
+                _, rc, _, ri = opp.post_process(obb[b], oci[b], osc[b], t, nms)
+                k = int(cnt_t[b])
+                jac.append(jaccard(idx_t[b, :k], ri))
                 if opp.decision_margins(osc[b], oci[b], t, eps=max(2.0 * s_err, 2e-6)) is None:
                     s_t += 1
-                    _, rc, _, ri = opp.post_process(obb[b], oci[b], osc[b], t, nms)
-                    k = int(cnt_t[b])
                     e_t += int(k == len(ri) and np.array_equal(idx_t[b, :k], ri) and np.array_equal(cls_t[b, :k], rc))
             extra[f'conf_{t}'] = f'{e_t}/{s_t}'
             safe, equal = safe + s_t, equal + e_t
@@ -246,8 +254,11 @@ def parity_check(cand, rec, conf, nms, oracle_cand=None, images=2, extra_conf=()
         out.update({'max_score_err': s_err, 'max_box_err_over_tol': round(b_err, 4),
                     'class_id_agreement': round(float((ci == oci).mean()), 6),
                     'sets_equal': f'{equal}/{safe} margin-safe (image, threshold) pairs equal the oracle\'s detections (count, candidate indices, classes, order)',
-                    'margin_safe_pairs': safe, 'tolerance': 'scores 1e-4 abs; boxes 1e-4 + 1e-4 |ref|'})
-        ok = ok and s_err <= 1e-4 and b_err <= 1.0 and equal == safe
+                    'margin_safe_pairs': safe, 'tolerance': 'scores 1e-4 abs; boxes 1e-4 + 1e-4 |ref|',
+                    'kept_ids_jaccard': {'pairs': len(jac), 'min': round(min(jac), 4), 'mean': round(sum(jac) / len(jac), 4),
+                                         'note': 'kept candidate ids vs the oracle\'s own detections over ALL (image, threshold) pairs; '
+                                                 'below 1 only through decisions inside the float32 round-off band'}})
+        ok = ok and s_err <= 1e-4 and b_err <= 1.0 and equal == safe and min(jac) >= 0.95
     out['ok'] = bool(ok)
     return out
 

@@ -763,36 +763,46 @@ def test_full_size_properties_batch32_640(model):
         k = int(cnt[i])
         assert k == len(src)
         np.testing.assert_array_equal(rec['index'][i, :k].cpu().numpy().astype(np.int64), src)
-    # images 0 and 31 of THIS production batch (F(4x4) on 31 layers, K-cut tails, the 128 x 128 tiles) against the CPU
-    # oracle forward: every candidate within north_star's 1e-4, class ids exact where the oracle's two best classes are
-    # further apart than round-off, and the detection sets equal wherever no decision sits inside the observed error
+    # six images of THIS production batch (F(4x4) on 31 layers, K-cut tails, the 128 x 128 tiles) against the CPU oracle
+    # forward: every candidate within north_star's 1e-4, class ids exact where the oracle's two best classes are further
+    # apart than round-off; at each of three thresholds the kept candidates agree with the oracle's own detections to
+    # >= 97 % (Jaccard index of the kept candidate ids: what differs are decisions inside the round-off band), and
+    # exactly -- count, ids, classes, order -- on every (image, threshold) pair whose decisions are all further than
+    # twice the observed score error from flipping (oracle.postprocess.decision_margins)
     from oracle import yolov3 as oy
     sd_cpu = {k: v.cpu() for k, v in m.state_dict().items()}
-    pick = [0, 31]
+    pick = [0, 5, 13, 20, 27, 31]
     with torch.no_grad():
         ob, oc, os_, raws = oy.forward(x[pick].cpu(), sd_cpu, return_raw=True)
     got_s, got_b, got_c = sc[pick].cpu().numpy(), bb[pick].cpu().numpy(), ci[pick].cpu().numpy()
     np.testing.assert_allclose(got_s, os_.numpy(), rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(got_b, ob.numpy(), rtol=RTOL, atol=ATOL)
+    n_p = len(pick)
     margin = []
     for r in raws:
-        t = torch.sigmoid(r.view(2, 3, 85, *r.shape[2:])[:, :, 5:].permute(0, 1, 3, 4, 2)).reshape(2, -1, 80).topk(2, dim=-1).values
+        t = torch.sigmoid(r.view(n_p, 3, 85, *r.shape[2:])[:, :, 5:].permute(0, 1, 3, 4, 2)).reshape(n_p, -1, 80).topk(2, dim=-1).values
         margin.append(t[..., 0] - t[..., 1])
     margin = torch.cat(margin, dim=1).numpy()
     err = float(np.abs(got_s - os_.numpy()).max())
-    n_safe = 0
+    n_safe, worst = 0, 1.0
     for j, i in enumerate(pick):
         _class_ids_exact_where_safe(got_c[j], oc[j].numpy(), margin[j], f'batch-32 image {i}')
         for t in (conf, 0.05, 0.5):
+            _, rc, _, ri = pp.post_process(ob[j].numpy(), oc[j].numpy(), os_[j].numpy(), t, thr)
+            r_t = batched_post_process(bb[i:i + 1], ci[i:i + 1], sc[i:i + 1], t, thr)
+            k = int(r_t['count'][0])
+            mine = r_t['index'][0, :k].cpu().numpy().astype(np.int64)
+            assert k >= 20 and len(ri) >= 20, f'image {i} conf {t}: vacuous ({k} / {len(ri)} detections)'
+            jac = len(np.intersect1d(mine, ri)) / len(np.union1d(mine, ri))
+            worst = min(worst, jac)
+            assert jac >= 0.97, f'image {i} conf {t}: kept candidates agree to {jac:.3f} only ({k} vs {len(ri)})'
             if pp.decision_margins(os_[j].numpy(), oc[j].numpy(), t, eps=max(2.0 * err, 2e-6)) is None:
                 n_safe += 1
-                _, rc, _, ri = pp.post_process(ob[j].numpy(), oc[j].numpy(), os_[j].numpy(), t, thr)
-                r_t = batched_post_process(bb[i:i + 1], ci[i:i + 1], sc[i:i + 1], t, thr)
-                k = int(r_t['count'][0])
-                assert k == len(ri) and k >= 20, f'image {i} conf {t}: {k} vs {len(ri)} detections'
-                np.testing.assert_array_equal(r_t['index'][0, :k].cpu().numpy().astype(np.int64), ri)
+                assert k == len(ri), f'image {i} conf {t}: {k} vs {len(ri)} detections'
+                np.testing.assert_array_equal(mine, ri)
                 np.testing.assert_array_equal(r_t['class_idx'][0, :k].cpu().numpy(), rc)
-    assert n_safe >= 3, f'only {n_safe} of 6 (image, threshold) pairs are margin-safe at score error {err:.1e}'
+    print(f'batch-32 vs oracle: score error {err:.1e}, {n_safe} of {3 * n_p} pairs margin-safe and exact, worst Jaccard {worst:.4f}')
+    assert n_safe >= 1, f'only {n_safe} of {3 * n_p} (image, threshold) pairs are margin-safe at score error {err:.1e}'
 
 
 def test_hipgraph_replay_equals_eager(model):
