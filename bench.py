@@ -43,6 +43,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_BF16_MFMA_TFLOPS = 2516.6      # dense: 256 CUs x 4 096 FLOP/clk (v_mfma_f32_32x32x16_bf16: 32 768 FLOP / 32 cycles / SIMD) x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
 DEFAULT_BATCH = {'yolov3_80': 32, 'efficientdet-d1': 16, 'd1_fcs2_atss': 32}
 WORKLOADS = {
@@ -571,25 +572,33 @@ def measure(args, ctx):
     if args.config == 'yolov3_80':
         # Dominant kernel = the conv family with the most time per step, priced with the ALGORITHMIC flops of its layers
         # (2*MACs of the direct form).  The Winograd kernels issue 2.25x (F(2x2)) / 4x (F(4x4)) fewer multiplies than that.
-        kernels = {'conv_igemm': ('conv_igemm_kernel (implicit GEMM, v_mfma_f32_32x32x2_f32)', 1.0),
-                   'conv_wino': ('conv_wino_kernel (fused Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32)', 2.25),
+        # family -> (kernel, multiplies issued on the matrix pipe per algorithmic multiply, dense peak of the instruction used)
+        kernels = {'conv_igemm': ('conv_igemm_kernel (implicit GEMM, v_mfma_f32_32x32x2_f32)', 1.0, PEAK_FP32_MFMA_TFLOPS),
+                   'conv_igemm_b3': ('conv_igemm_b3_kernel (the same implicit GEMM with float32-exact split operands: three bfloat16 '
+                                     'pieces per operand, six v_mfma_f32_32x32x16_bf16 piece products per k-step, float32 accumulation)',
+                                     6.0, PEAK_BF16_MFMA_TFLOPS),
+                   'conv_wino': ('conv_wino_kernel (fused Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32)', 1 / 2.25, PEAK_FP32_MFMA_TFLOPS),
                    'conv_wino4': ('wino4_input_kernel + conv_wino4_kernel (Winograd F(4x4,3x3): input-transform launch + DMA-fed '
                                   'v_mfma_f32_16x16x4_f32 GEMMs with fused output transform, + the K-cut tail\'s piece and fixup '
-                                  'launches where the item count leaves a remainder; one layer timed as one unit)', 4.0)}
+                                  'launches where the item count leaves a remainder; one layer timed as one unit)', 0.25, PEAK_FP32_MFMA_TFLOPS)}
         fams = {k: summ[k] for k in kernels if k in summ}
         dom = max(fams, key=lambda k: fams[k][1])
         n_k, ms_k, flops_k = fams[dom]
         alg = flops_k / (ms_k * 1e-3) / 1e12
         for k, (n_f, ms_f, fl_f) in fams.items():
             stages[k]['algorithmic_TFLOPs'] = round(fl_f / (ms_f * 1e-3) / 1e12, 2)
-            stages[k]['mfma_frac'] = round(fl_f / kernels[k][1] / (ms_f * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
+            stages[k]['mfma_frac'] = round(fl_f * kernels[k][1] / (ms_f * 1e-3) / 1e12 / kernels[k][2], 4)
+            if k == 'conv_igemm_b3':
+                stages[k]['mfma_frac_note'] = ('6 x the algorithmic FLOPs issued on the bfloat16 pipe / its 2 516.6 TFLOP/s dense peak; the '
+                                               'float32 matrix instruction would need algorithmic_TFLOPs / 157.3 = '
+                                               f'{fl_f / (ms_f * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS:.2f} of its peak for this time')
         roofline = {'bound': 'mfma', 'kernel': kernels[dom][0],
-                    'achieved': round(alg / kernels[dom][1], 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(alg / kernels[dom][1] / PEAK_FP32_MFMA_TFLOPS, 4),
+                    'achieved': round(alg * kernels[dom][1], 2), 'peak': kernels[dom][2], 'unit': 'TFLOP/s',
+                    'frac': round(alg * kernels[dom][1] / kernels[dom][2], 4),
                     'algorithmic_achieved': round(alg, 2),
                     'algorithmic_frac': round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
-                    'note': 'achieved/frac = multiplies issued on the matrix pipe (algorithmic direct-form FLOPs / '
-                            f'{kernels[dom][1]}) / HIP-event time vs the FP32-MFMA peak; algorithmic_* = direct-form FLOPs / time',
+                    'note': 'achieved/frac = multiplies issued on the matrix pipe (algorithmic direct-form FLOPs x '
+                            f'{kernels[dom][1]:.4g}) / HIP-event time vs the dense peak of the instruction used; algorithmic_* = direct-form FLOPs / time vs the FP32-MFMA peak',
                     'algorithmic_gflop_per_launch': round(flops_k / n_k / 1e9, 3)}
     else:
         fams = {k: summ[k] for k in summ if timer.bytes.get(k)}

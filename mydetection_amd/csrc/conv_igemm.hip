@@ -45,6 +45,8 @@ struct ConvArgs {
     const float *x1;
     int64_t ldx1;
     int C1;
+    // split-bf16 form (conv_igemm_b3_kernel): the weights as three bfloat16 planes [3][Cout][K] with w = p0 + p1 + p2
+    const unsigned short *wsplit;
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -331,6 +333,258 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
         epilogue<ACT, RES, false, TM, TN>(p, acc, m_base, n_base, fr, fh, pscl, psft);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The same implicit GEMM on the bfloat16 matrix instructions, float32-exact operands ("split-bf16").
+// Every float32 operand is cut into three bfloat16 pieces by round-to-nearest remainders,
+//     a = a0 + a1 + a2,   a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1)      (both remainders are exact in float32;
+//                                                                                       |a - a0 - a1 - a2| <= 2^-27 |a|)
+// and a product is formed from the six piece products whose weight is 2^-18 or more,
+//     a b ~= a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0)        (dropped: a1 b2, a2 b1 <= 2^-27 |a b| each, a2 b2 <= 2^-36)
+// -- each piece product is exact in float32 (8 x 8 significant bits) and v_mfma_f32_32x32x16_bf16 accumulates in float32, so
+// the result carries the multiplicands' full 24 bits: the error of a product (2^-26) is BELOW the rounding of a float32
+// multiply-add (2^-24), and the sums are float32 sums as in conv_igemm_kernel.  Six bf16 MFMAs of 16 k each take 192 cycles
+// against 512 for the sixteen v_mfma_f32_32x32x2_f32 they replace: 2.67 x the matrix rate of the float32 instruction.
+// (tests hold it to the same 2e-5 * max|y| against float64 as the float32 kernel; measured it is as close or closer.)
+//
+// Workgroup = 4 waves, tile BM x BN = 128 x (128 | 64), wave tile 64 x (64 | 32), K in slabs of 16 (one MFMA k-step).
+// Activations are split while they are staged (global float32 -> registers -> three bf16 planes in LDS: ~7 VALU per
+// element, once per element and tile), the weights arrive pre-split from `wsplit` (mydet_split_bf16_f32, once per layer).
+// LDS rows of a plane: 16 bf16 + 8 pad = 48 bytes (fragment ds_read_b128 conflict-free); two slab buffers = 72 KB at 128 x 128:
+// two workgroups per CU as for the float32 tiles.  Cin % 16 == 0 (a slab never straddles taps).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3(const f32x4 v, bf16x4 &p0, bf16x4 &p1, bf16x4 &p2) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 h0 = (__bf16)v[e];
+        const float r1 = v[e] - (float)h0;
+        const __bf16 h1 = (__bf16)r1;
+        const float r2 = r1 - (float)h1;
+        p0[e] = h0; p1[e] = h1; p2[e] = (__bf16)r2;
+    }
+}
+
+#ifndef B3_PF
+#define B3_PF 4
+#endif
+template <int BM, int BN, int ACT, bool RES, bool SPLIT = false, int PF = B3_PF, int DIAG = 0>
+__global__ __launch_bounds__(256, 2) void conv_igemm_b3_kernel(const ConvArgs p) {
+    constexpr int NT = 256, WM = 2, WN = 2, BK = 16;
+    constexpr int ROWB = 48;                         // bytes per LDS row of one plane
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int AI = BM * 4 / NT;                  // 16-byte float4 chunks of A per thread and slab (4 per row)
+    constexpr int BCH = BN * 2;                      // 16-byte bf16x8 chunks of one B plane per slab (2 per row)
+    constexpr int PLANE_A = BM * ROWB, PLANE_B = BN * ROWB, BUF = 3 * (PLANE_A + PLANE_B);
+    extern __shared__ __attribute__((aligned(16))) char smem_b3[];
+
+    const int tid = threadIdx.x;
+    const int lid = SPLIT ? p.tile0 + (int)blockIdx.x / p.splits : mydet_xcd_remap(blockIdx.x, p.nblk);
+    const int m0 = (lid / p.ntiles) * BM;
+    const int n0 = (lid % p.ntiles) * BN;
+    const int hwo = p.Ho * p.Wo;
+    const int b0 = m0 / hwo;
+    const int64_t img = (int64_t)p.H * p.W * p.ldx;
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x + b0 * img, (p.B - b0) * img * 4);
+    const int64_t plane_el = (int64_t)p.Cout * p.K;
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(reinterpret_cast<const float *>(p.wsplit), 3 * plane_el * 2);
+
+    // ---- staging roles.  A: chunk (4 floats) sc of rows sr + 64 i.  B: chunk (8 bf16) bh of row br, all three planes.
+    const int sc = tid & 3, sr = tid >> 2;
+    const int ntaps = p.KH * p.KW;
+    int aoff[AI];
+    unsigned amask[AI];
+    const bool flat = ntaps == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 && p.Ho == p.H && p.Wo == p.W;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int m = m0 + sr + 64 * i;
+        const int mm = m < p.M ? m : p.M - 1;
+        if (flat) {
+            aoff[i] = (int)(((int64_t)(mm - b0 * hwo) * p.ldx + sc * 4) * 4);
+            amask[i] = m < p.M ? 1u : 0u;
+            continue;
+        }
+        const int ow = mm % p.Wo, t = mm / p.Wo;
+        const int oh = t % p.Ho, b = t / p.Ho;
+        const int ih0 = oh * p.stride - p.pad_t, iw0 = ow * p.stride - p.pad_l;
+        aoff[i] = (int)((((int64_t)(b - b0) * p.H + ih0) * p.W + iw0) * p.ldx + sc * 4) * 4;
+        unsigned mask = 0;
+        for (int tp = 0; tp < ntaps; ++tp) {
+            const int kh = tp / p.KW, kw = tp - kh * p.KW;
+            if ((unsigned)(ih0 + kh) < (unsigned)p.H && (unsigned)(iw0 + kw) < (unsigned)p.W) mask |= 1u << tp;
+        }
+        amask[i] = m < p.M ? mask : 0u;
+    }
+    const int br = tid >> 1, bh = tid & 1;
+    const bool bact = tid < BCH;
+    unsigned boff;
+    {
+        int n = n0 + br;
+        n = n < p.Cout ? n : p.Cout - 1;             // rows past Cout compute garbage that is never stored
+        boff = bact ? (unsigned)(((int64_t)n * p.K + bh * 8) * 2) : OOB;
+    }
+    const unsigned plane_bytes = (unsigned)(plane_el * 2);
+
+    f32x4 areg[PF][AI];
+    u32x4 breg[PF][3];
+    const int nk_all = p.K / BK;
+    int kt0 = 0, nk = nk_all;
+    if (SPLIT) {
+        const int sp = (int)blockIdx.x % p.splits;
+        kt0 = (int)((unsigned)(nk_all * sp) / (unsigned)p.splits);
+        nk = (int)((unsigned)(nk_all * (sp + 1)) / (unsigned)p.splits);
+    }
+    int tap = 0, c0 = 0, tapoff = 0;                 // uniform tap / channel base / byte offset of the slab being requested
+    if (SPLIT) {
+        const int k0 = kt0 * BK;
+        tap = k0 / p.Cin;
+        c0 = k0 - tap * p.Cin;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        tapoff = (int)(((int64_t)kh * p.W + kw) * p.ldx) * 4;
+    }
+    auto load_slab = [&](int kt, f32x4 (&ar)[AI], u32x4 (&brg)[3]) {
+        if (DIAG == 2 && kt > kt0 + PF) return;
+        const unsigned uoff = (unsigned)(tapoff + c0 * 4);
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const bool ok = (amask[i] >> tap) & 1u;
+            if (!(DIAG == 5 && kt > kt0 + PF)) ar[i] = buf_load16(xr, ok ? (unsigned)aoff[i] + uoff : OOB);
+        }
+        c0 += BK;
+        if (c0 == p.Cin) {                            // uniform: next tap
+            c0 = 0;
+            ++tap;
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+            tapoff = (int)(((int64_t)kh * p.W + kw) * p.ldx) * 4;
+        }
+        const unsigned koff = (unsigned)kt * (BK * 2);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            if (!(DIAG == 6 && kt > kt0 + PF))
+            brg[pl] = __builtin_amdgcn_raw_buffer_load_b128(wr, bact ? boff + koff : OOB,
+                                                            __builtin_amdgcn_readfirstlane((unsigned)pl * plane_bytes), 0);
+    };
+    auto store_slab = [&](int buf, const f32x4 (&ar)[AI], const u32x4 (&brg)[3]) {
+        if (DIAG == 4 && buf == 1) return;
+        char *a = smem_b3 + buf * BUF, *b = a + 3 * PLANE_A;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            bf16x4 q0, q1, q2;
+            if (DIAG == 1) {
+                q0 = __builtin_bit_cast(bf16x4, f32x2{ar[i][0], ar[i][1]}); q1 = __builtin_bit_cast(bf16x4, f32x2{ar[i][2], ar[i][3]}); q2 = q0;
+            } else split3(ar[i], q0, q1, q2);
+            char *d = a + (sr + 64 * i) * ROWB + sc * 8;
+            *reinterpret_cast<bf16x4 *>(d) = q0;
+            *reinterpret_cast<bf16x4 *>(d + PLANE_A) = q1;
+            *reinterpret_cast<bf16x4 *>(d + 2 * PLANE_A) = q2;
+        }
+        if (bact) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4 *>(b + pl * PLANE_B + br * ROWB + bh * 16) = brg[pl];
+        }
+    };
+
+    // ---- compute role
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 31, fh = lane >> 5;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int a_off = (wm * TM * 32 + fr) * ROWB + fh * 16;
+    const int b_off = 3 * PLANE_A + (wn * TN * 32 + fr) * ROWB + fh * 16;
+    float pscl[TN], psft[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + fr;
+        const int nc = n < p.Cout ? n : 0;
+        pscl[j] = (!SPLIT && p.scale) ? p.scale[nc] : 1.0f;
+        psft[j] = (!SPLIT && p.shift) ? p.shift[nc] : 0.0f;
+    }
+    auto compute = [&](int buf) {
+        if (DIAG == 3) return;
+        const char *a = smem_b3 + buf * BUF + a_off;
+        const char *b = smem_b3 + buf * BUF + b_off;
+        bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) af[i][pl] = *reinterpret_cast<const bf16x8 *>(a + pl * PLANE_A + i * 32 * ROWB);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8 *>(b + pl * PLANE_B + j * 32 * ROWB);
+        // the small piece products first (the running sum absorbs them at its own rounding either way)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+            }
+    };
+
+    load_slab(kt0, areg[0], breg[0]);
+    store_slab(0, areg[0], breg[0]);
+#pragma unroll
+    for (int d = 0; d < PF; ++d) load_slab(kt0 + 1 + d, areg[d], breg[d]);
+    __syncthreads();
+    int buf = 0;
+    for (int kt = kt0; kt < nk; kt += PF) {
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {               // register set d holds slab kt + d + 1
+            if (kt + d >= nk) break;
+            compute(buf);
+            store_slab(buf ^ 1, areg[d], breg[d]);
+            load_slab(kt + d + 1 + PF, areg[d], breg[d]);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+
+    if (SPLIT) {     // raw partial tile in conv_fixup_kernel's layout
+        constexpr int NV4 = TM * TN * 4;
+        f32x4 *dst = reinterpret_cast<f32x4 *>(p.ws) + (int64_t)blockIdx.x * NV4 * NT + tid;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    dst[((i * TN + j) * 4 + v) * NT] =
+                        f32x4{acc[i][j][4 * v], acc[i][j][4 * v + 1], acc[i][j][4 * v + 2], acc[i][j][4 * v + 3]};
+        return;
+    }
+    const int m_base = m0 + wm * TM * 32, n_base = n0 + wn * TN * 32;
+    if ((m0 + BM <= p.M) && (n0 + BN <= p.Cout))
+        epilogue<ACT, RES, true, TM, TN>(p, acc, m_base, n_base, fr, fh, pscl, psft);
+    else
+        epilogue<ACT, RES, false, TM, TN>(p, acc, m_base, n_base, fr, fh, pscl, psft);
+}
+
+// float32 -> three bfloat16 planes (see conv_igemm_b3_kernel): out[pl * n + i], pl = 0, 1, 2
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float *w, int64_t n, unsigned short *out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = w[i];
+    const __bf16 h0 = (__bf16)v;
+    const float r1 = v - (float)h0;
+    const __bf16 h1 = (__bf16)r1;
+    const __bf16 h2 = (__bf16)(r1 - (float)h1);
+    out[i] = __builtin_bit_cast(unsigned short, h0);
+    out[n + i] = __builtin_bit_cast(unsigned short, h1);
+    out[2 * n + i] = __builtin_bit_cast(unsigned short, h2);
+}
+
 // Split-K tail: sums the K-slice partials of one tile in slice order and applies the fused epilogue.
 template <int BM, int BN, int WM, int WN, int ACT, bool RES>
 __global__ __launch_bounds__(WM * WN * 64) void conv_fixup_kernel(const ConvArgs p) {
@@ -486,6 +740,64 @@ int launch(const ConvArgs &a0, int slots, hipStream_t stream) {
     return launch_fixup_act<BM, BN, WM, WN>(a, rem, stream);
 }
 
+// ---- split-bf16 launches (conv_igemm_b3_kernel): the same round / split-K-tail rule as `launch`, two workgroups per CU
+template <int BM, int BN, int ACT, bool RES, bool SPLIT, int PF = B3_PF, int DIAG = 0>
+int launch_b3_inst(const ConvArgs &a, hipStream_t stream) {
+    auto kern = &conv_igemm_b3_kernel<BM, BN, ACT, RES, SPLIT, PF, DIAG>;
+    constexpr int lds = 2 * 3 * (BM + BN) * 48;
+    static unsigned long long attr_set = 0;
+    if (const int e = mydet_lds_opt_in(attr_set, kern, lds)) return e;
+    hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(256), lds, stream, a);
+    return mydet_launch_status();
+}
+
+template <int BM, int BN>
+int launch_b3(const ConvArgs &a0, hipStream_t stream) {
+    ConvArgs a = a0;
+    const int slots = 2 * mydet_cu_count();
+    const int mtiles = (a.M + BM - 1) / BM;
+    a.ntiles = (a.Cout + BN - 1) / BN;
+    const int total = mtiles * a.ntiles;
+    const int nk = a.K / 16;
+    const int rounds = total / slots;
+    const int rem = total % slots;
+    const bool small = rounds == 0 && total * 4 <= slots && nk >= 32;
+    int splits = rem > 0 ? slots / rem : 0;
+    if (splits > 16) splits = 16;
+    if (splits > nk / 8) splits = nk / 8;
+    const size_t need = (size_t)rem * (splits > 0 ? splits : 0) * BM * BN * sizeof(float);
+    const bool split = rem > 0 && splits >= 2 && a0.ws && need <= a0.ws_bytes &&
+                       (small || (nk >= 64 && rounds >= 2 && rounds <= 4 && rem * 2 <= slots));
+    a.tile0 = 0; a.splits = 1;
+    a.nblk = split ? total - rem : total;
+    const bool res = a.res != nullptr;
+    int rc = 0;
+    if (a.nblk > 0) {
+        switch (a.act) {
+            case MYDET_ACT_LEAKY: {
+                const char *pe = getenv("MYDET_B3_PF");          // experiment: register-prefetch depth of the plain LeakyReLU instance
+                const int pf = pe ? atoi(pe) : 0;
+                if (!res && pf == 2) rc = launch_b3_inst<BM, BN, MYDET_ACT_LEAKY, false, false, 2>(a, stream);
+                else if (!res && pf == 11) rc = launch_b3_inst<BM, BN, MYDET_ACT_LEAKY, false, false, 2, 1>(a, stream);
+                else if (!res && pf == 12) rc = launch_b3_inst<BM, BN, MYDET_ACT_LEAKY, false, false, 2, 2>(a, stream);
+                else if (!res && pf == 13) rc = launch_b3_inst<BM, BN, MYDET_ACT_LEAKY, false, false, 2, 3>(a, stream);
+                else if (!res && pf == 14) rc = launch_b3_inst<BM, BN, MYDET_ACT_LEAKY, false, false, 2, 4>(a, stream);
+                else if (!res && pf == 15) rc = launch_b3_inst<BM, BN, MYDET_ACT_LEAKY, false, false, 2, 5>(a, stream);
+                else if (!res && pf == 16) rc = launch_b3_inst<BM, BN, MYDET_ACT_LEAKY, false, false, 2, 6>(a, stream);
+                else rc = res ? launch_b3_inst<BM, BN, MYDET_ACT_LEAKY, true, false>(a, stream) : launch_b3_inst<BM, BN, MYDET_ACT_LEAKY, false, false>(a, stream);
+                break;
+            }
+            case MYDET_ACT_SWISH: rc = res ? launch_b3_inst<BM, BN, MYDET_ACT_SWISH, true, false>(a, stream) : launch_b3_inst<BM, BN, MYDET_ACT_SWISH, false, false>(a, stream); break;
+            default: rc = res ? launch_b3_inst<BM, BN, MYDET_ACT_NONE, true, false>(a, stream) : launch_b3_inst<BM, BN, MYDET_ACT_NONE, false, false>(a, stream); break;
+        }
+    }
+    if (rc || !split) return rc;
+    a.tile0 = total - rem; a.splits = splits; a.nblk = rem * splits;
+    rc = launch_b3_inst<BM, BN, MYDET_ACT_NONE, false, true>(a, stream);
+    if (rc) return rc;
+    return launch_fixup_act<BM, BN, 2, 2>(a, rem, stream);
+}
+
 // Workgroups per CU assumed for tile configuration 6: the runtime reports 4 (mydet_conv_igemm_occupancy; the two-slab
 // register prefetch of round 4 took the fifth); MYDET_CFG6_PER_CU overrides (A/B), read once.
 int cfg6_per_cu() {
@@ -587,7 +899,7 @@ extern "C" int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *
     a.pad_t = pad_t; a.pad_l = pad_l; a.Ho = Ho; a.Wo = Wo; a.act = act;
     a.M = (int)M64; a.K = KH * KW * Cin; a.ntiles = 0; a.nblk = 0;
     a.tile0 = 0; a.splits = 1;
-    a.x1 = nullptr; a.ldx1 = 0; a.C1 = 0;
+    a.x1 = nullptr; a.ldx1 = 0; a.C1 = 0; a.wsplit = nullptr;
     a.ws = ((uintptr_t)workspace & 15) ? nullptr : (float *)workspace;
     a.ws_bytes = workspace_bytes > 0 ? (size_t)workspace_bytes : 0;
     hipStream_t s = (hipStream_t)stream;
@@ -600,6 +912,45 @@ extern "C" int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *
         if (rc != MYDET_E_UNSUPP) return rc;
     }
     return launch_cfg(choose_cfg(M64, Cin, Cout, KH * KW), a, s);
+}
+
+extern "C" int mydet_split_bf16_f32(const float *w, int64_t n, uint16_t *planes, void *stream) {
+    if (!w || !planes || n <= 0) return MYDET_E_BADARG;
+    if ((n + 255) / 256 > 0x7fffffff) return MYDET_E_UNSUPP;
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, n, planes);
+    return mydet_launch_status();
+}
+
+extern "C" int mydet_conv2d_igemm_b3_f32(const float *x, int64_t ldx, const uint16_t *w_planes, const float *scale,
+                                         const float *shift, const float *residual, int64_t ldr, void *workspace,
+                                         int64_t workspace_bytes, float *y, int64_t ldy, int B, int H, int W, int Cin, int Cout,
+                                         int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, void *stream) {
+    if (!x || !w_planes || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 ||
+        Ho <= 0 || Wo <= 0)
+        return MYDET_E_BADARG;
+    if ((ldx & 3) || ldx < Cin || ldy < Cout || (residual && ldr < Cout)) return MYDET_E_BADARG;
+    if (((uintptr_t)x & 15) || ((uintptr_t)w_planes & 15) || ((uintptr_t)y & 15) || (residual && ((uintptr_t)residual & 15)) ||
+        (scale && ((uintptr_t)scale & 15)) || (shift && ((uintptr_t)shift & 15)))
+        return MYDET_E_BADARG;
+    if (act < 0 || act > 2) return MYDET_E_BADARG;
+    if ((Cin & 15) || (ldy & 3) || (residual && (ldr & 3))) return MYDET_E_UNSUPP;   // a 16-channel slab never straddles taps
+    const int64_t M64 = (int64_t)B * Ho * Wo, K64 = (int64_t)KH * KW * Cin;
+    if (M64 > (int64_t)1 << 30 || K64 > (int64_t)1 << 30) return MYDET_E_BADARG;
+    const int64_t img_bytes = (int64_t)H * W * ldx * 4;
+    const int64_t span_imgs = 256 / ((int64_t)Ho * Wo) + 2;
+    if (M64 * ldy * 4 >= 0x7FFFFFF0ll || (residual && M64 * ldr * 4 >= 0x7FFFFFF0ll)) return MYDET_E_UNSUPP;
+    if (KH * KW > 31 || img_bytes * span_imgs >= 0x7FFFFFF0ll || 3 * (int64_t)Cout * K64 * 2 >= 0x7FFFFFF0ll) return MYDET_E_UNSUPP;
+    ConvArgs a;
+    a.x = x; a.w = nullptr; a.scale = scale; a.shift = shift; a.res = residual; a.gate = nullptr; a.y = y;
+    a.ldx = ldx; a.ldr = ldr; a.ldy = ldy;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride;
+    a.pad_t = pad_t; a.pad_l = pad_l; a.Ho = Ho; a.Wo = Wo; a.act = act;
+    a.M = (int)M64; a.K = (int)K64; a.ntiles = 0; a.nblk = 0; a.tile0 = 0; a.splits = 1;
+    a.x1 = nullptr; a.ldx1 = 0; a.C1 = 0; a.wsplit = w_planes;
+    a.ws = ((uintptr_t)workspace & 15) ? nullptr : (float *)workspace;
+    a.ws_bytes = workspace_bytes > 0 ? (size_t)workspace_bytes : 0;
+    if (Cout <= 64) return launch_b3<128, 64>(a, (hipStream_t)stream);
+    return launch_b3<128, 128>(a, (hipStream_t)stream);
 }
 
 /* Test / tuning hook: workgroups per CU the runtime reports for the base instance of tile configuration `cfg`
@@ -659,7 +1010,7 @@ extern "C" int mydet_conv1x1_upcat_f32(const float *x_lo, int64_t ld_lo, int C_l
     a.pad_t = 0; a.pad_l = 0; a.Ho = H; a.Wo = W; a.act = act;
     a.M = (int)M64; a.K = Cin; a.ntiles = 0; a.nblk = 0;
     a.tile0 = 0; a.splits = 1;
-    a.x1 = x_lo; a.ldx1 = ld_lo; a.C1 = C_lo;
+    a.x1 = x_lo; a.ldx1 = ld_lo; a.C1 = C_lo; a.wsplit = nullptr;
     a.ws = ((uintptr_t)workspace & 15) ? nullptr : (float *)workspace;
     a.ws_bytes = workspace_bytes > 0 ? (size_t)workspace_bytes : 0;
     return launch_cfg(3, a, (hipStream_t)stream);          // the tile the 1x1 layers of this shape take anyway (same k order)

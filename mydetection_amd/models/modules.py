@@ -63,6 +63,19 @@ def prepare_wino(owner, slot, w_ohwi):
     return hit[1]
 
 
+def prepare_b3(owner, slot, w_ohwi):
+    """Three-plane bfloat16 copy of a prepared OHWI weight for the split-bf16 implicit GEMM (ops.split_bf16; cached on `owner`
+    next to the weight it was made from), or None when no shape of the layer can take that kernel (Cin % 16)."""
+    if not ops.SPLIT_BF16 or w_ohwi.shape[3] % 16:
+        return None
+    cache = owner.__dict__.setdefault('_prep_cache', {})
+    hit = cache.get(slot)
+    if hit is None or hit[0] is not w_ohwi:
+        hit = (w_ohwi, ops.split_bf16(w_ohwi))
+        cache[slot] = hit
+    return hit[1]
+
+
 class FusedConvMixin:
     """Caches kernel-ready parameters (OHWI weights, per-channel scale/shift)."""
 
@@ -102,7 +115,9 @@ class ConvBnLeaky(nn.Module, FusedConvMixin):
         if w.shape[3] == 3 and self.k == 3 and w.shape[0] == 32 and residual is None:
             return ops.conv2d_stem(x, w, scale, shift, self.s, (p, p, p, p), ops.ACT_LEAKY)
         u, u4 = prepare_wino(self, 'wino', w) if self.k == 3 and self.s == 1 else (None, None)
-        return ops.conv2d(x, w, scale, shift, self.k, self.s, (p, p, p, p), ops.ACT_LEAKY, residual=residual, wino=u, wino4=u4)
+        # the layers that stay on the direct implicit GEMM (1x1, stride-2 3x3) take its split-bf16 form where ops.b3_takes says so
+        b3 = prepare_b3(self, 'b3', w) if u is None and u4 is None else None
+        return ops.conv2d(x, w, scale, shift, self.k, self.s, (p, p, p, p), ops.ACT_LEAKY, residual=residual, wino=u, wino4=u4, b3=b3)
 
 
 class DarkBlock(nn.Module):

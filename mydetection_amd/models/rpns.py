@@ -5,7 +5,7 @@ from .. import ops
 import numpy as np
 import torch
 
-from .modules import prepare_wino, FusedConvMixin, SeparableConv2d, SpconvBn, prepare_conv
+from .modules import prepare_wino, prepare_b3, FusedConvMixin, SeparableConv2d, SpconvBn, prepare_conv
 
 
 class RawPreds(dict):
@@ -42,7 +42,7 @@ class YOLOHead(nn.Module):
         all_level_preds = []
         for module, P in zip(self.heads, features):
             w, scale, shift = module._prepared(module, None)
-            preds = ops.conv2d(P, w, scale, shift, 1, 1, (0, 0, 0, 0), ops.ACT_NONE)
+            preds = ops.conv2d(P, w, scale, shift, 1, 1, (0, 0, 0, 0), ops.ACT_NONE, b3=prepare_b3(module, 'b3', w))
             nB, _, nH, nW = preds.shape
             per = nBp + 1 + self.n_cls
             raw = RawPreds()

@@ -259,14 +259,41 @@ def wino4_weights(w_ohwi):
     return u
 
 
+# MYDET_CONV_SPLIT_BF16=0 keeps every direct conv on the float32 matrix instruction (A/B measurements)
+SPLIT_BF16 = os.environ.get('MYDET_CONV_SPLIT_BF16', '1') != '0'
+
+
+# The split-bf16 form takes a direct-conv layer from this many output pixels (B * Ho * Wo) up -- below, the float32 kernel's
+# small-grid K cut is the tuned path (batch-1 layers) -- and, for 1x1 layers, from 128 output channels (tools/r05_b3.py:
+# 128->64 @160^2 0.197 vs 0.187 ms for the float32 kernel; every wider shape of the headline 1.25-1.35 x faster)
+B3_MIN_ROWS = int(os.environ.get('MYDET_B3_MIN_ROWS', '8192'))
+
+
+def b3_takes(M, Cin, Cout, k):
+    """True when `conv2d(..., b3=)` runs the split-bf16 kernel for a layer of this shape."""
+    return SPLIT_BF16 and Cin % 16 == 0 and M >= B3_MIN_ROWS and (k > 1 or Cout >= 128)
+
+
+def split_bf16(w):
+    """Three bfloat16 planes [3, n] (int16 storage) of a float32 tensor, w = p0 + p1 + p2 to 2^-27 |w| (include/mydet.h:
+    mydet_split_bf16_f32): the weight operand of `conv2d(..., b3=)`."""
+    require_gpu(w, 'split_bf16')
+    w = w.contiguous().float()
+    out = torch.empty((3, w.numel()), dtype=torch.int16, device=w.device)
+    _lib.check(_lib.lib().mydet_split_bf16_f32(_ptr(w), w.numel(), _ptr(out), _stream()), 'mydet_split_bf16_f32')
+    return out
+
+
 def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None, out_ld=None, gate=None, wino=None,
-           wino4=None, interior=None):
+           wino4=None, interior=None, b3=None):
     """y = act(conv(x * gate)*scale + shift) + residual.  x logical [B,Cin,H,W]; pad=(top,left,bottom,right);
     gate: optional [B,Cin] per-image channel multipliers (squeeze-excite), 1x1 convs only;
     wino / wino4: optional `wino_weights(w_ohwi)` / `wino4_weights(w_ohwi)`: 3x3 stride-1 pad-1 layers then run a fused
     Winograd kernel -- F(4x4,3x3) when given and the grid fills the chip (or no F(2x2,3x3) weights are given).
     interior: 'in' / 'out' marks the input / output as a tensor that lives only inside a block (bookkeeping of the
-    fused-minimum byte count of KernelTimer; no effect on the launch)."""
+    fused-minimum byte count of KernelTimer; no effect on the launch).
+    b3: optional `split_bf16(w_ohwi)`: a layer that stays on the direct implicit GEMM then runs it on the bfloat16 matrix
+    instructions with float32-exact split operands (include/mydet.h: mydet_conv2d_igemm_b3_f32; Cin % 16 == 0, no gate)."""
     require_gpu(x, 'conv2d')
     if x.shape[1] % 4:
         raise ValueError(f'conv2d: Cin = {x.shape[1]} is not a multiple of 4 (the implicit-GEMM kernel reads channels in '
@@ -311,6 +338,19 @@ def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None
         _lib.check(code, 'mydet_conv2d_wino_f32')
         return out
     ws = conv_workspace(x.device)
+    if b3 is not None and gate is None and b3_takes(B * Ho * Wo, Cin, Cout, k):
+        t0 = TIMER.start() if TIMER else None
+        code = _lib.lib().mydet_conv2d_igemm_b3_f32(
+            _ptr(x), ldx, _ptr(b3), _ptr(scale), _ptr(shift), _ptr(residual), ldr, _ptr(ws), ws.numel() * 4, _ptr(out), ldy,
+            B, H, W, Cin, Cout, k, k, stride, pad[0], pad[1], Ho, Wo, act, _stream())
+        if code != -2:                              # MYDET_E_UNSUPP: the float32 kernel below
+            if t0:
+                name = f'conv_igemm_b3 {Cin}->{Cout} k{k}s{stride} {H}x{W}' if TIMER_DETAIL else 'conv_igemm_b3'
+                b_in, b_out = 4.0 * B * H * W * Cin, 4.0 * B * Ho * Wo * Cout
+                b_rest = 4.0 * (k * k * Cin * Cout) + (b_out if residual is not None else 0.0)
+                TIMER.stop(name, t0, 2.0 * B * Ho * Wo * Cout * k * k * Cin, b_in + b_out + b_rest)
+            _lib.check(code, 'mydet_conv2d_igemm_b3_f32')
+            return out
     t0 = TIMER.start() if TIMER else None
     code = _lib.lib().mydet_conv2d_igemm_f32(
         _ptr(x), ldx, _ptr(w_ohwi), _ptr(scale), _ptr(shift), _ptr(residual), ldr, _ptr(gate),

@@ -72,6 +72,61 @@ def test_conv_igemm_vs_fp64(dev, case):
     _conv_case(dev, **case)
 
 
+@pytest.mark.parametrize('case', [
+    dict(B=32, Cin=32, Cout=64, k=3, s=2, H=64, W=64, act=1),                    # 128 x 64 tile (Cout <= 64), the first stride-2 layer's shape
+    dict(B=32, Cin=128, Cout=256, k=3, s=2, H=40, W=40, act=1),                  # 128 x 128 tiles, 72 slabs
+    dict(B=16, Cin=256, Cout=128, k=1, s=1, H=40, W=40, act=1, residual=True),   # 1x1 flat path + residual, 200 tiles
+    dict(B=9, Cin=512, Cout=255, k=1, s=1, H=31, W=33, act=0, bias_only=True),   # head conv: ragged rows and channels (255), bias only
+    dict(B=9, Cin=64, Cout=192, k=3, s=2, H=77, W=53, act=2),                    # odd sizes, swish, a half-empty second channel tile
+    dict(B=40, Cin=1024, Cout=512, k=1, s=1, H=20, W=20, act=1),                 # 125 x 4 = 500 tiles: one round of 512
+    dict(B=33, Cin=512, Cout=1024, k=3, s=2, H=40, W=40, act=1),                 # 104 x 8 = 832 tiles, 288 slabs: whole round + split-K tail
+])
+def test_conv_split_bf16_vs_fp64(dev, case, monkeypatch):
+    """The implicit GEMM on the bfloat16 matrix instructions with float32-exact split operands (conv_igemm_b3_kernel;
+    ops.conv2d(..., b3=)): held to the SAME 2e-5 * max|y| against float64 as the float32-instruction kernel, agrees with that
+    kernel to float32 round-off, is bit-repeatable, and really ran (ops.b3_takes for the shape)."""
+    from mydetection_amd import ops
+    B, Cin, Cout, k, s, H, W = (case[n] for n in ('B', 'Cin', 'Cout', 'k', 's', 'H', 'W'))
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    scale = None if case.get('bias_only') else torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g) * 0.1
+    p = (k - 1) // 2
+    ref = F.conv2d(F.pad(x, (p, p, p, p)).double(), w.double(), None, s)
+    ref = ref * (scale.double().view(1, -1, 1, 1) if scale is not None else 1.0) + shift.double().view(1, -1, 1, 1)
+    if case['act'] == 1:
+        ref = F.leaky_relu(ref, 0.1)
+    elif case['act'] == 2:
+        ref = ref * torch.sigmoid(ref)
+    res = None
+    if case.get('residual'):
+        res = torch.randn(ref.shape, generator=g)
+        ref = ref + res.double()
+    Ho, Wo = ref.shape[2:]
+    assert ops.b3_takes(B * Ho * Wo, Cin, Cout, k)
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    w3 = ops.split_bf16(wd)
+    planes = w3.view(torch.bfloat16).float().sum(0).view_as(wd)               # p0 + p1 + p2 == w to 2^-27
+    assert (planes - wd).abs().max().item() <= 2.0 ** -24 * wd.abs().max().item()
+    kw = dict(residual=res.to(dev).contiguous(memory_format=torch.channels_last) if res is not None else None)
+    args = (xd, wd, scale.to(dev) if scale is not None else None, shift.to(dev), k, s, (p, p, p, p), case['act'])
+    ops.TIMER = ops.KernelTimer()
+    try:
+        y3 = ops.conv2d(*args, b3=w3, **kw).clone()
+    finally:
+        timer, ops.TIMER = ops.TIMER, None
+    assert 'conv_igemm_b3' in timer.spans and 'conv_igemm' not in timer.spans
+    y32 = ops.conv2d(*args, **kw)
+    tol = 2e-5 * ref.abs().max().item()
+    e3, e32 = (y3.cpu().double() - ref).abs().max().item(), (y32.cpu().double() - ref).abs().max().item()
+    assert e3 <= tol, (e3, e32, tol)
+    assert e3 <= 4.0 * e32 + 1e-6, f'split-bf16 error {e3:.2e} vs float32-instruction error {e32:.2e}'
+    for _ in range(2):
+        assert torch.equal(ops.conv2d(*args, b3=w3, **kw), y3)
+
+
 @pytest.mark.parametrize('shape', [(2, 256, 512, 256, 20, 20),      # 28 x 4 tiles, K = 24 slabs: the small-grid K cut + CAT
                                    (1, 256, 512, 256, 10, 10),      # the same layer at batch 1 (7 x 4 tiles cut along K)
                                    (1, 128, 256, 128, 32, 32),      # batch 1, 12 slabs: uncut
