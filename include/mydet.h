@@ -192,14 +192,19 @@ int mydet_conv1x1_upcat_f32(const float *x_lo, int64_t ld_lo, int C_lo, const fl
  * product is the sum of the six piece products of weight >= 2^-18 (each exact in float32), accumulated in float32 by
  * v_mfma_f32_32x32x16_bf16: per product an error of 2^-26 |a b|, below the rounding of a float32 multiply-add -- the same
  * results as the float32 kernel to float32 round-off (tests hold both to 2e-5 * max|y| against float64) at 2.67 x its matrix
- * rate.  Same arguments as mydet_conv2d_igemm_f32 except: w_planes = the OHWI weight as three bfloat16 planes [3][Cout][KH*KW*Cin]
- * made ONCE per layer by mydet_split_bf16_f32 (n = Cout*KH*KW*Cin floats -> 3 n uint16); no SE gate.  Cin % 16 == 0;
+ * rate.  Same arguments as mydet_conv2d_igemm_f32 except: w_planes = the OHWI weight [Cout][K = KH*KW*Cin] as three bfloat16
+ * planes in the kernels' slab-major, DMA-swizzled order (csrc/conv_igemm.hip: split_bf16_kernel; Cout padded to 256 rows),
+ * made ONCE per layer by mydet_split_bf16_f32 into mydet_split_bf16_elems(Cout, K) uint16; no SE gate.  Cin % 16 == 0;
  * MYDET_E_UNSUPP otherwise (the caller then uses mydet_conv2d_igemm_f32).  Replaces the same reference lines. */
-int mydet_split_bf16_f32(const float *w, int64_t n, uint16_t *planes, void *stream);
+int64_t mydet_split_bf16_elems(int Cout, int K);      /* uint16 elements of the operand below (0: K % 16 != 0) */
+int mydet_split_bf16_f32(const float *w, int Cout, int K, uint16_t *planes, void *stream);
 int mydet_conv2d_igemm_b3_f32(const float *x, int64_t ldx, const uint16_t *w_planes, const float *scale, const float *shift,
                               const float *residual, int64_t ldr, void *workspace, int64_t workspace_bytes, float *y,
                               int64_t ldy, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_t,
                               int pad_l, int Ho, int Wo, int act, void *stream);
+/* Test hook: the split-bf16 launcher reads MYDET_B3_WIDE / MYDET_B3_WAVES once per process; this reads them again.
+ * Returns the form bits (1 = wide 128 x 256 tiles from 192 output channels, 2 = 8-wave workgroups). */
+int mydet_conv_b3_reload_tuning(void);
 
 /* Test / tuning hook: workgroups per CU the runtime reports (hipOccupancyMaxActiveBlocksPerMultiprocessor) for the
  * base instance of conv_igemm tile configuration `cfg` (0, 1, 2, 3, 6, 8, 9); *assumed = the count the launch rule

@@ -25,8 +25,10 @@ SIGNATURES = {
     'mydet_wino4_weights_f32': [c_ptr, c_int, c_int, c_ptr, c_ptr],
     'mydet_wino4_workspace_bytes': [c_int, c_int, c_int, c_int, c_int],
     'mydet_wino4_reload_tuning': [],
+    'mydet_conv_b3_reload_tuning': [],
     'mydet_conv_igemm_occupancy': [c_int, c_ptr],
-    'mydet_split_bf16_f32': [c_ptr, c_i64, c_ptr, c_ptr],
+    'mydet_split_bf16_elems': [c_int, c_int],
+    'mydet_split_bf16_f32': [c_ptr, c_int, c_int, c_ptr, c_ptr],
     'mydet_conv2d_igemm_b3_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64] + [c_int] * 13 + [c_ptr],
     'mydet_wino4_tail_plan': [c_int, c_int, c_int, c_int, c_int, c_int, c_ptr],
     'mydet_conv2d_wino4_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64] + [c_int] * 6 + [c_ptr],
@@ -69,7 +71,7 @@ SIGNATURES = {
 
 
 
-RETURNS_I64 = {'mydet_wino_weights_floats', 'mydet_wino4_weights_floats', 'mydet_wino4_workspace_bytes'}
+RETURNS_I64 = {'mydet_wino_weights_floats', 'mydet_wino4_weights_floats', 'mydet_wino4_workspace_bytes', 'mydet_split_bf16_elems'}
 
 # detection record layout (MYDET_REC_* of include/mydet.h), in int32 words
 REC_TOPK = 512

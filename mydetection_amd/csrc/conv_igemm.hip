@@ -351,7 +351,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
 // element, once per element and tile), the weights arrive pre-split from `wsplit` (mydet_split_bf16_f32, once per layer).
 // LDS rows of a plane: 16 bf16 + 8 pad = 48 bytes (fragment ds_read_b128 conflict-free); two slab buffers = 72 KB at 128 x 128:
 // two workgroups per CU as for the float32 tiles.  Cin % 16 == 0 (a slab never straddles taps).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int B3_COUT_PAD = 256;            // rows of the weight operand are padded to this (split_bf16_kernel)
+__device__ __host__ __forceinline__ int b3_unit(int rr, int h) { return 2 * rr + (h ^ ((rr >> 2) & 1)); }
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -367,11 +368,11 @@ __device__ __forceinline__ void split3(const f32x4 v, bf16x4 &p0, bf16x4 &p1, bf
 }
 
 #ifndef B3_PF
-#define B3_PF 4
+#define B3_PF 2          // slabs prefetched into registers beyond the one staged (2, 3, 4, 6 measured equal: profiles/HISTORY.md)
 #endif
-template <int BM, int BN, int ACT, bool RES, bool SPLIT = false, int PF = B3_PF, int DIAG = 0>
-__global__ __launch_bounds__(256, 2) void conv_igemm_b3_kernel(const ConvArgs p) {
-    constexpr int NT = 256, WM = 2, WN = 2, BK = 16;
+template <int BM, int BN, int ACT, bool RES, bool SPLIT = false, int PF = B3_PF, int WN = 2>
+__global__ __launch_bounds__(128 * WN, 2) void conv_igemm_b3_kernel(const ConvArgs p) {
+    constexpr int NT = 128 * WN, WM = 2, BK = 16;
     constexpr int ROWB = 48;                         // bytes per LDS row of one plane
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int AI = BM * 4 / NT;                  // 16-byte float4 chunks of A per thread and slab (4 per row)
@@ -387,10 +388,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_b3_kernel(const ConvArgs p)
     const int b0 = m0 / hwo;
     const int64_t img = (int64_t)p.H * p.W * p.ldx;
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x + b0 * img, (p.B - b0) * img * 4);
-    const int64_t plane_el = (int64_t)p.Cout * p.K;
-    const __amdgpu_buffer_rsrc_t wr = make_rsrc(reinterpret_cast<const float *>(p.wsplit), 3 * plane_el * 2);
+    const int CoutP = (p.Cout + B3_COUT_PAD - 1) / B3_COUT_PAD * B3_COUT_PAD;
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(reinterpret_cast<const float *>(p.wsplit), (int64_t)(p.K >> 4) * 3 * CoutP * 32);
 
-    // ---- staging roles.  A: chunk (4 floats) sc of rows sr + 64 i.  B: chunk (8 bf16) bh of row br, all three planes.
+    // ---- staging roles.  A: chunk (4 floats) sc of rows sr + RP i.  B: chunk (8 bf16) bh of row br, all three planes.
+    constexpr int RP = NT / 4;
     const int sc = tid & 3, sr = tid >> 2;
     const int ntaps = p.KH * p.KW;
     int aoff[AI];
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_b3_kernel(const ConvArgs p)
     const bool flat = ntaps == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 && p.Ho == p.H && p.Wo == p.W;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-        const int m = m0 + sr + 64 * i;
+        const int m = m0 + sr + RP * i;
         const int mm = m < p.M ? m : p.M - 1;
         if (flat) {
             aoff[i] = (int)(((int64_t)(mm - b0 * hwo) * p.ldx + sc * 4) * 4);
@@ -416,15 +418,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_b3_kernel(const ConvArgs p)
         }
         amask[i] = m < p.M ? mask : 0u;
     }
-    const int br = tid >> 1, bh = tid & 1;
+    // B: 16-byte unit `tid` of the tile's plane-slab (BN rows x 32 bytes, contiguous in the slab-major layout); the unit's
+    // (row, k-half) follow from the layout's swizzle (split_bf16_kernel); rows past Cout are zeros there
     const bool bact = tid < BCH;
-    unsigned boff;
-    {
-        int n = n0 + br;
-        n = n < p.Cout ? n : p.Cout - 1;             // rows past Cout compute garbage that is never stored
-        boff = bact ? (unsigned)(((int64_t)n * p.K + bh * 8) * 2) : OOB;
-    }
-    const unsigned plane_bytes = (unsigned)(plane_el * 2);
+    const int bu = tid & 63, brr = bu >> 1;
+    const int br = (tid >> 6) * 32 + brr, bh = (bu & 1) ^ ((brr >> 2) & 1);
+    const unsigned boff = bact ? (unsigned)(n0 * 32 + tid * 16) : OOB;
+    const unsigned plane_bytes = (unsigned)CoutP * 32u, slab_bytes = 3u * plane_bytes;
 
     f32x4 areg[PF][AI];
     u32x4 breg[PF][3];
@@ -444,12 +444,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_b3_kernel(const ConvArgs p)
         tapoff = (int)(((int64_t)kh * p.W + kw) * p.ldx) * 4;
     }
     auto load_slab = [&](int kt, f32x4 (&ar)[AI], u32x4 (&brg)[3]) {
-        if (DIAG == 2 && kt > kt0 + PF) return;
         const unsigned uoff = (unsigned)(tapoff + c0 * 4);
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             const bool ok = (amask[i] >> tap) & 1u;
-            if (!(DIAG == 5 && kt > kt0 + PF)) ar[i] = buf_load16(xr, ok ? (unsigned)aoff[i] + uoff : OOB);
+            ar[i] = buf_load16(xr, ok ? (unsigned)aoff[i] + uoff : OOB);
         }
         c0 += BK;
         if (c0 == p.Cin) {                            // uniform: next tap
@@ -458,23 +457,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_b3_kernel(const ConvArgs p)
             const int kh = tap / p.KW, kw = tap - kh * p.KW;
             tapoff = (int)(((int64_t)kh * p.W + kw) * p.ldx) * 4;
         }
-        const unsigned koff = (unsigned)kt * (BK * 2);
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
-            if (!(DIAG == 6 && kt > kt0 + PF))
-            brg[pl] = __builtin_amdgcn_raw_buffer_load_b128(wr, bact ? boff + koff : OOB,
-                                                            __builtin_amdgcn_readfirstlane((unsigned)pl * plane_bytes), 0);
+            brg[pl] = __builtin_amdgcn_raw_buffer_load_b128(wr, boff,
+                                                            __builtin_amdgcn_readfirstlane((unsigned)kt * slab_bytes + (unsigned)pl * plane_bytes), 0);
     };
     auto store_slab = [&](int buf, const f32x4 (&ar)[AI], const u32x4 (&brg)[3]) {
-        if (DIAG == 4 && buf == 1) return;
         char *a = smem_b3 + buf * BUF, *b = a + 3 * PLANE_A;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             bf16x4 q0, q1, q2;
-            if (DIAG == 1) {
-                q0 = __builtin_bit_cast(bf16x4, f32x2{ar[i][0], ar[i][1]}); q1 = __builtin_bit_cast(bf16x4, f32x2{ar[i][2], ar[i][3]}); q2 = q0;
-            } else split3(ar[i], q0, q1, q2);
-            char *d = a + (sr + 64 * i) * ROWB + sc * 8;
+            split3(ar[i], q0, q1, q2);
+            char *d = a + (sr + RP * i) * ROWB + sc * 8;
             *reinterpret_cast<bf16x4 *>(d) = q0;
             *reinterpret_cast<bf16x4 *>(d + PLANE_A) = q1;
             *reinterpret_cast<bf16x4 *>(d + 2 * PLANE_A) = q2;
@@ -507,7 +501,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_b3_kernel(const ConvArgs p)
         psft[j] = (!SPLIT && p.shift) ? p.shift[nc] : 0.0f;
     }
     auto compute = [&](int buf) {
-        if (DIAG == 3) return;
         const char *a = smem_b3 + buf * BUF + a_off;
         const char *b = smem_b3 + buf * BUF + b_off;
         bf16x8 af[TM][3], bf[TN][3];
@@ -519,18 +512,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_b3_kernel(const ConvArgs p)
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8 *>(b + pl * PLANE_B + j * 32 * ROWB);
-        // the small piece products first (the running sum absorbs them at its own rounding either way)
+        // the six piece products, small ones first (the running sum absorbs them at its own rounding either way); a piece pair
+        // sweeps all blocks of the wave tile before the next pair, so MFMAs on one accumulator are TM * TN instructions apart
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int t = 0; t < 6; ++t)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
-            }
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
     };
 
     load_slab(kt0, areg[0], breg[0]);
@@ -571,18 +562,227 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_b3_kernel(const ConvArgs p)
         epilogue<ACT, RES, false, TM, TN>(p, acc, m_base, n_base, fr, fh, pscl, psft);
 }
 
-// float32 -> three bfloat16 planes (see conv_igemm_b3_kernel): out[pl * n + i], pl = 0, 1, 2
-__global__ __launch_bounds__(256) void split_bf16_kernel(const float *w, int64_t n, unsigned short *out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float v = w[i];
+// ---- wide form: tile 128 x 256 on 8 waves (wave tile 64 x 64), ONE workgroup per CU.
+// conv_igemm_b3_kernel above moves 20 KB per 128 x 128 x 16 multiplies: at the bf16 matrix rate that is the 27 B/cycle/CU an
+// L2-resident stream sustains at best, and splitting 128 x 16 activations for 128 output channels keeps the vector ALU as busy
+// as the matrix pipe (measured: 0.32 of the bf16 peak, 0.53 ms of a 0.73 ms launch is staging alone).  Twice the output channels per
+// tile halve the activation bytes AND the split arithmetic per multiply; the weights -- already split, slab-major and swizzled
+// -- come by LDS-DMA (raw_ptr_buffer_load_lds: no registers, no VALU, 1 KB contiguous per wave instruction) into a ring of three
+// slab slots, two slabs ahead, so their landing is never waited for; activations are staged as above (one 16-byte chunk per
+// thread and slab).  LDS: 2 x 18 KB of activation planes + 3 x 24 KB of weight slabs = 108 KB.
+template <int ACT, bool RES, bool SPLIT = false>
+__global__ __launch_bounds__(512, 1) void conv_igemm_b3w_kernel(const ConvArgs p) {
+    constexpr int BM = 128, BN = 256, NT = 512, WN = 4, BK = 16, PF = 2, RING = 3;
+    constexpr int ROWB = 48;                         // bytes per LDS row of one activation plane
+    constexpr int TM = 2, TN = 2;
+    constexpr int PLANE_A = BM * ROWB, ABUF = 3 * PLANE_A;
+    constexpr int PLANE_B = BN * 32, BSLOT = 3 * PLANE_B;      // weight planes are packed 32-byte rows in DMA (swizzled) order
+    extern __shared__ __attribute__((aligned(16))) char smem_b3[];
+    char *As = smem_b3, *Bs = smem_b3 + 2 * ABUF;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int lid = SPLIT ? p.tile0 + (int)blockIdx.x / p.splits : mydet_xcd_remap(blockIdx.x, p.nblk);
+    const int m0 = (lid / p.ntiles) * BM;
+    const int n0 = (lid % p.ntiles) * BN;
+    const int hwo = p.Ho * p.Wo;
+    const int b0 = m0 / hwo;
+    const int64_t img = (int64_t)p.H * p.W * p.ldx;
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x + b0 * img, (p.B - b0) * img * 4);
+    const int CoutP = (p.Cout + B3_COUT_PAD - 1) / B3_COUT_PAD * B3_COUT_PAD;
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(reinterpret_cast<const float *>(p.wsplit), (int64_t)(p.K >> 4) * 3 * CoutP * 32);
+    const unsigned plane_bytes = (unsigned)CoutP * 32u, slab_bytes = 3u * plane_bytes;
+
+    // ---- activation staging role: chunk (4 floats) sc of row sr
+    const int sc = tid & 3, sr = tid >> 2;
+    const int ntaps = p.KH * p.KW;
+    int aoff;
+    unsigned amask;
+    {
+        const bool flat = ntaps == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 && p.Ho == p.H && p.Wo == p.W;
+        const int m = m0 + sr;
+        const int mm = m < p.M ? m : p.M - 1;
+        if (flat) {
+            aoff = (int)(((int64_t)(mm - b0 * hwo) * p.ldx + sc * 4) * 4);
+            amask = m < p.M ? 1u : 0u;
+        } else {
+            const int ow = mm % p.Wo, t = mm / p.Wo;
+            const int oh = t % p.Ho, b = t / p.Ho;
+            const int ih0 = oh * p.stride - p.pad_t, iw0 = ow * p.stride - p.pad_l;
+            aoff = (int)((((int64_t)(b - b0) * p.H + ih0) * p.W + iw0) * p.ldx + sc * 4) * 4;
+            unsigned mask = 0;
+            for (int tp = 0; tp < ntaps; ++tp) {
+                const int kh = tp / p.KW, kw = tp - kh * p.KW;
+                if ((unsigned)(ih0 + kh) < (unsigned)p.H && (unsigned)(iw0 + kw) < (unsigned)p.W) mask |= 1u << tp;
+            }
+            amask = m < p.M ? mask : 0u;
+        }
+    }
+    const int nk_all = p.K / BK;
+    int kt0 = 0, nk = nk_all;
+    if (SPLIT) {
+        const int sp = (int)blockIdx.x % p.splits;
+        kt0 = (int)((unsigned)(nk_all * sp) / (unsigned)p.splits);
+        nk = (int)((unsigned)(nk_all * (sp + 1)) / (unsigned)p.splits);
+    }
+    int tap = 0, c0 = 0, tapoff = 0;                 // uniform tap / channel base / byte offset of the activation slab being requested
+    if (SPLIT) {
+        const int k0 = kt0 * BK;
+        tap = k0 / p.Cin;
+        c0 = k0 - tap * p.Cin;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        tapoff = (int)(((int64_t)kh * p.W + kw) * p.ldx) * 4;
+    }
+    auto load_a = [&](f32x4 &ar) {                   // requests past the last slab run into masked taps: harmless, never consumed
+        const bool ok = (amask >> tap) & 1u;
+        ar = buf_load16(xr, ok ? (unsigned)aoff + (unsigned)(tapoff + c0 * 4) : OOB);
+        c0 += BK;
+        if (c0 == p.Cin) {                            // uniform: next tap
+            c0 = 0;
+            ++tap;
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+            tapoff = (int)(((int64_t)kh * p.W + kw) * p.ldx) * 4;
+        }
+    };
+    auto store_a = [&](int buf, const f32x4 &ar) {
+        bf16x4 q0, q1, q2;
+        split3(ar, q0, q1, q2);
+        char *d = As + buf * ABUF + sr * ROWB + sc * 8;
+        *reinterpret_cast<bf16x4 *>(d) = q0;
+        *reinterpret_cast<bf16x4 *>(d + PLANE_A) = q1;
+        *reinterpret_cast<bf16x4 *>(d + 2 * PLANE_A) = q2;
+    };
+    // weight slab kt -> ring slot: 24 pieces of 1 KB (3 planes x 8 row blocks of 32), three per wave; always three requests per
+    // wave and call (a slab past the end reads out of range: zeros), so the counted waits below hold in every iteration
+    const unsigned dma_lane = (unsigned)(n0 * 32 + lane * 16);
+    auto dma_b = [&](int kt, int slot) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int idx = wave * 3 + j, pl = idx >> 3, pc = idx & 7;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                wr, (__attribute__((address_space(3))) void *)(Bs + slot * BSLOT + pl * PLANE_B + pc * 1024), 16,
+                kt < nk_all ? dma_lane : OOB,
+                __builtin_amdgcn_readfirstlane((unsigned)kt * slab_bytes + (unsigned)pl * plane_bytes + (unsigned)pc * 1024u), 0, 0);
+        }
+    };
+
+    // ---- compute role
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 31, fh = lane >> 5;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int a_off = (wm * 64 + fr) * ROWB + fh * 16;
+    const int b_off = (wn * 2) * 1024 + b3_unit(fr, fh) * 16;            // + j * 1024 + plane * PLANE_B
+    float pscl[TN], psft[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + fr;
+        const int nc = n < p.Cout ? n : 0;
+        pscl[j] = (!SPLIT && p.scale) ? p.scale[nc] : 1.0f;
+        psft[j] = (!SPLIT && p.shift) ? p.shift[nc] : 0.0f;
+    }
+    auto compute = [&](int buf, int slot) {
+        const char *a = As + buf * ABUF + a_off;
+        const char *b = Bs + slot * BSLOT + b_off;
+        bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) af[i][pl] = *reinterpret_cast<const bf16x8 *>(a + pl * PLANE_A + i * 32 * ROWB);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8 *>(b + pl * PLANE_B + j * 1024);
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
+    };
+
+    // prologue.  Requests, oldest first: B(kt0), B(kt0+1), A(kt0), A(kt0+1), A(kt0+2)
+    f32x4 areg[PF];
+    dma_b(kt0, 0);
+    dma_b(kt0 + 1, 1);
+    {
+        f32x4 first;
+        load_a(first);
+        store_a(0, first);                            // (the wait for `first` also covers the two weight slabs requested before it)
+    }
+    load_a(areg[0]);
+    load_a(areg[1]);
+    __syncthreads();
+    int buf = 0, slot = 0;
+    for (int kt = kt0; kt < nk; kt += PF) {
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {               // register set d holds activation slab kt + d + 1
+            if (kt + d >= nk) break;
+            const int s2 = slot >= 1 ? slot - 1 : RING - 1;             // (slot + 2) % 3: the slot read in the previous iteration
+            dma_b(kt + d + 2, s2);
+            compute(buf, slot);
+            store_a(buf ^ 1, areg[d]);
+            load_a(areg[d]);
+            // in flight, oldest first: B(kt+d+1) | A(kt+d+2) | B(kt+d+2) x3 | A(kt+d+3).  Slab kt+d+1 of the weights is read
+            // after the barrier: all but the five youngest requests must have landed
+            __builtin_amdgcn_s_waitcnt(0x0F70 | 5);
+            __syncthreads();
+            buf ^= 1;
+            slot = slot == RING - 1 ? 0 : slot + 1;
+        }
+    }
+
+    if (SPLIT) {     // raw partial tile in conv_fixup_kernel's layout
+        constexpr int NV4 = TM * TN * 4;
+        f32x4 *dst = reinterpret_cast<f32x4 *>(p.ws) + (int64_t)blockIdx.x * NV4 * NT + tid;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    dst[((i * TN + j) * 4 + v) * NT] =
+                        f32x4{acc[i][j][4 * v], acc[i][j][4 * v + 1], acc[i][j][4 * v + 2], acc[i][j][4 * v + 3]};
+        return;
+    }
+    const int m_base = m0 + wm * 64, n_base = n0 + wn * 64;
+    if ((m0 + BM <= p.M) && (n0 + BN <= p.Cout))
+        epilogue<ACT, RES, true, TM, TN>(p, acc, m_base, n_base, fr, fh, pscl, psft);
+    else
+        epilogue<ACT, RES, false, TM, TN>(p, acc, m_base, n_base, fr, fh, pscl, psft);
+}
+
+// float32 OHWI weight [Cout][K] -> the split-bf16 kernels' operand: three bfloat16 planes (w = p0 + p1 + p2), SLAB-MAJOR so that
+// the rows a workgroup needs for one 16-k slab are one contiguous run, and swizzled for the LDS-DMA path:
+//     out[((kt * 3 + pl) * CoutP + 32 * blk) * 16 + 8 * u + e],   kt = k / 16, CoutP = Cout rounded up to 256 (zero rows),
+//     blk = n / 32, the 1 KB piece of rows 32 blk .. 32 blk + 31 holds 16-byte unit u = 2 (n % 32) + (h ^ ((n % 32 >> 2) & 1)) for
+//     row n, k-half h (k % 16 = 8 h + e): copied to LDS as it lies (raw_ptr_buffer_load_lds writes a wave's 64 units in
+//     order), a fragment read of eight consecutive rows then touches eight different 16-byte bank groups.
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float *w, int Cout, int K, int CoutP, unsigned short *out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (kt, n, k % 16) over the padded rows
+    const int64_t total = (int64_t)(K >> 4) * CoutP * 16;
+    if (i >= total) return;
+    const int kk = (int)(i & 15);
+    const int64_t t = i >> 4;
+    const int n = (int)(t % CoutP), kt = (int)(t / CoutP);
+    const float v = n < Cout ? w[(int64_t)n * K + kt * 16 + kk] : 0.f;
     const __bf16 h0 = (__bf16)v;
     const float r1 = v - (float)h0;
     const __bf16 h1 = (__bf16)r1;
     const __bf16 h2 = (__bf16)(r1 - (float)h1);
-    out[i] = __builtin_bit_cast(unsigned short, h0);
-    out[n + i] = __builtin_bit_cast(unsigned short, h1);
-    out[2 * n + i] = __builtin_bit_cast(unsigned short, h2);
+    const int64_t pos = ((int64_t)(n >> 5) * 64 + b3_unit(n & 31, kk >> 3)) * 8 + (kk & 7);      // inside one plane-slab
+    const int64_t plane = (int64_t)CoutP * 16;
+    unsigned short *o = out + (int64_t)kt * 3 * plane + pos;
+    o[0] = __builtin_bit_cast(unsigned short, h0);
+    o[plane] = __builtin_bit_cast(unsigned short, h1);
+    o[2 * plane] = __builtin_bit_cast(unsigned short, h2);
 }
 
 // Split-K tail: sums the K-slice partials of one tile in slice order and applies the fused epilogue.
@@ -741,17 +941,17 @@ int launch(const ConvArgs &a0, int slots, hipStream_t stream) {
 }
 
 // ---- split-bf16 launches (conv_igemm_b3_kernel): the same round / split-K-tail rule as `launch`, two workgroups per CU
-template <int BM, int BN, int ACT, bool RES, bool SPLIT, int PF = B3_PF, int DIAG = 0>
+template <int BM, int BN, int ACT, bool RES, bool SPLIT, int PF = B3_PF, int WN = 2>
 int launch_b3_inst(const ConvArgs &a, hipStream_t stream) {
-    auto kern = &conv_igemm_b3_kernel<BM, BN, ACT, RES, SPLIT, PF, DIAG>;
+    auto kern = &conv_igemm_b3_kernel<BM, BN, ACT, RES, SPLIT, PF, WN>;
     constexpr int lds = 2 * 3 * (BM + BN) * 48;
     static unsigned long long attr_set = 0;
     if (const int e = mydet_lds_opt_in(attr_set, kern, lds)) return e;
-    hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(128 * WN), lds, stream, a);
     return mydet_launch_status();
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int WN = 2>
 int launch_b3(const ConvArgs &a0, hipStream_t stream) {
     ConvArgs a = a0;
     const int slots = 2 * mydet_cu_count();
@@ -774,28 +974,62 @@ int launch_b3(const ConvArgs &a0, hipStream_t stream) {
     int rc = 0;
     if (a.nblk > 0) {
         switch (a.act) {
-            case MYDET_ACT_LEAKY: {
-                const char *pe = getenv("MYDET_B3_PF");          // experiment: register-prefetch depth of the plain LeakyReLU instance
-                const int pf = pe ? atoi(pe) : 0;
-                if (!res && pf == 2) rc = launch_b3_inst<BM, BN, MYDET_ACT_LEAKY, false, false, 2>(a, stream);
-                else if (!res && pf == 11) rc = launch_b3_inst<BM, BN, MYDET_ACT_LEAKY, false, false, 2, 1>(a, stream);
-                else if (!res && pf == 12) rc = launch_b3_inst<BM, BN, MYDET_ACT_LEAKY, false, false, 2, 2>(a, stream);
-                else if (!res && pf == 13) rc = launch_b3_inst<BM, BN, MYDET_ACT_LEAKY, false, false, 2, 3>(a, stream);
-                else if (!res && pf == 14) rc = launch_b3_inst<BM, BN, MYDET_ACT_LEAKY, false, false, 2, 4>(a, stream);
-                else if (!res && pf == 15) rc = launch_b3_inst<BM, BN, MYDET_ACT_LEAKY, false, false, 2, 5>(a, stream);
-                else if (!res && pf == 16) rc = launch_b3_inst<BM, BN, MYDET_ACT_LEAKY, false, false, 2, 6>(a, stream);
-                else rc = res ? launch_b3_inst<BM, BN, MYDET_ACT_LEAKY, true, false>(a, stream) : launch_b3_inst<BM, BN, MYDET_ACT_LEAKY, false, false>(a, stream);
-                break;
-            }
-            case MYDET_ACT_SWISH: rc = res ? launch_b3_inst<BM, BN, MYDET_ACT_SWISH, true, false>(a, stream) : launch_b3_inst<BM, BN, MYDET_ACT_SWISH, false, false>(a, stream); break;
-            default: rc = res ? launch_b3_inst<BM, BN, MYDET_ACT_NONE, true, false>(a, stream) : launch_b3_inst<BM, BN, MYDET_ACT_NONE, false, false>(a, stream); break;
+            case MYDET_ACT_LEAKY: rc = res ? launch_b3_inst<BM, BN, MYDET_ACT_LEAKY, true, false, (WN == 4 ? 2 : B3_PF), WN>(a, stream) : launch_b3_inst<BM, BN, MYDET_ACT_LEAKY, false, false, (WN == 4 ? 2 : B3_PF), WN>(a, stream); break;
+            case MYDET_ACT_SWISH: rc = res ? launch_b3_inst<BM, BN, MYDET_ACT_SWISH, true, false, (WN == 4 ? 2 : B3_PF), WN>(a, stream) : launch_b3_inst<BM, BN, MYDET_ACT_SWISH, false, false, (WN == 4 ? 2 : B3_PF), WN>(a, stream); break;
+            default: rc = res ? launch_b3_inst<BM, BN, MYDET_ACT_NONE, true, false, (WN == 4 ? 2 : B3_PF), WN>(a, stream) : launch_b3_inst<BM, BN, MYDET_ACT_NONE, false, false, (WN == 4 ? 2 : B3_PF), WN>(a, stream); break;
         }
     }
     if (rc || !split) return rc;
     a.tile0 = total - rem; a.splits = splits; a.nblk = rem * splits;
-    rc = launch_b3_inst<BM, BN, MYDET_ACT_NONE, false, true>(a, stream);
+    rc = launch_b3_inst<BM, BN, MYDET_ACT_NONE, false, true, (WN == 4 ? 2 : B3_PF), WN>(a, stream);
     if (rc) return rc;
-    return launch_fixup_act<BM, BN, 2, 2>(a, rem, stream);
+    return launch_fixup_act<BM, BN, 2, WN>(a, rem, stream);
+}
+
+template <int ACT, bool RES, bool SPLIT>
+int launch_b3w_inst(const ConvArgs &a, hipStream_t stream) {
+    auto kern = &conv_igemm_b3w_kernel<ACT, RES, SPLIT>;
+    constexpr int lds = 2 * 3 * 128 * 48 + 3 * 3 * 256 * 32;
+    static unsigned long long attr_set = 0;
+    if (const int e = mydet_lds_opt_in(attr_set, kern, lds)) return e;
+    hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(512), lds, stream, a);
+    return mydet_launch_status();
+}
+
+// the wide form: one workgroup per CU, so a round is `cus` tiles; same split-K-tail rule otherwise
+int launch_b3w(const ConvArgs &a0, hipStream_t stream) {
+    constexpr int BM = 128, BN = 256;
+    ConvArgs a = a0;
+    const int slots = mydet_cu_count();
+    const int mtiles = (a.M + BM - 1) / BM;
+    a.ntiles = (a.Cout + BN - 1) / BN;
+    const int total = mtiles * a.ntiles;
+    const int nk = a.K / 16;
+    const int rounds = total / slots;
+    const int rem = total % slots;
+    const bool small = rounds == 0 && total * 4 <= slots && nk >= 32;
+    int splits = rem > 0 ? slots / rem : 0;
+    if (splits > 16) splits = 16;
+    if (splits > nk / 8) splits = nk / 8;
+    const size_t need = (size_t)rem * (splits > 0 ? splits : 0) * BM * BN * sizeof(float);
+    const bool split = rem > 0 && splits >= 2 && a0.ws && need <= a0.ws_bytes &&
+                       (small || (nk >= 64 && rounds >= 2 && rounds <= 4 && rem * 2 <= slots));
+    a.tile0 = 0; a.splits = 1;
+    a.nblk = split ? total - rem : total;
+    const bool res = a.res != nullptr;
+    int rc = 0;
+    if (a.nblk > 0) {
+        switch (a.act) {
+            case MYDET_ACT_LEAKY: rc = res ? launch_b3w_inst<MYDET_ACT_LEAKY, true, false>(a, stream) : launch_b3w_inst<MYDET_ACT_LEAKY, false, false>(a, stream); break;
+            case MYDET_ACT_SWISH: rc = res ? launch_b3w_inst<MYDET_ACT_SWISH, true, false>(a, stream) : launch_b3w_inst<MYDET_ACT_SWISH, false, false>(a, stream); break;
+            default: rc = res ? launch_b3w_inst<MYDET_ACT_NONE, true, false>(a, stream) : launch_b3w_inst<MYDET_ACT_NONE, false, false>(a, stream); break;
+        }
+    }
+    if (rc || !split) return rc;
+    a.tile0 = total - rem; a.splits = splits; a.nblk = rem * splits;
+    rc = launch_b3w_inst<MYDET_ACT_NONE, false, true>(a, stream);
+    if (rc) return rc;
+    return launch_fixup_act<BM, BN, 2, 4>(a, rem, stream);
 }
 
 // Workgroups per CU assumed for tile configuration 6: the runtime reports 4 (mydet_conv_igemm_occupancy; the two-slab
@@ -914,11 +1148,34 @@ extern "C" int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *
     return launch_cfg(choose_cfg(M64, Cin, Cout, KH * KW), a, s);
 }
 
-extern "C" int mydet_split_bf16_f32(const float *w, int64_t n, uint16_t *planes, void *stream) {
-    if (!w || !planes || n <= 0) return MYDET_E_BADARG;
-    if ((n + 255) / 256 > 0x7fffffff) return MYDET_E_UNSUPP;
-    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, n, planes);
+extern "C" int64_t mydet_split_bf16_elems(int Cout, int K) {
+    if (Cout <= 0 || K <= 0 || (K & 15)) return 0;
+    return (int64_t)(K >> 4) * 3 * ((Cout + B3_COUT_PAD - 1) / B3_COUT_PAD * B3_COUT_PAD) * 16;
+}
+
+extern "C" int mydet_split_bf16_f32(const float *w, int Cout, int K, uint16_t *planes, void *stream) {
+    if (!w || !planes || Cout <= 0 || K <= 0) return MYDET_E_BADARG;
+    if (K & 15) return MYDET_E_UNSUPP;
+    const int CoutP = (Cout + B3_COUT_PAD - 1) / B3_COUT_PAD * B3_COUT_PAD;
+    const int64_t total = (int64_t)(K >> 4) * CoutP * 16;
+    if ((total + 255) / 256 > 0x7fffffff) return MYDET_E_UNSUPP;
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, K,
+                       CoutP, planes);
     return mydet_launch_status();
+}
+
+static int g_b3_form = -1;
+static int b3_form() {
+    if (g_b3_form < 0) {
+        const char *w = getenv("MYDET_B3_WIDE"), *v = getenv("MYDET_B3_WAVES");
+        g_b3_form = ((w && *w == '1') ? 1 : 0) | ((v && atoi(v) == 8) ? 2 : 0);
+    }
+    return g_b3_form;
+}
+/* Test hook: read MYDET_B3_WIDE / MYDET_B3_WAVES again (they are read once per process otherwise). */
+extern "C" int mydet_conv_b3_reload_tuning(void) {
+    g_b3_form = -1;
+    return b3_form();
 }
 
 extern "C" int mydet_conv2d_igemm_b3_f32(const float *x, int64_t ldx, const uint16_t *w_planes, const float *scale,
@@ -939,7 +1196,7 @@ extern "C" int mydet_conv2d_igemm_b3_f32(const float *x, int64_t ldx, const uint
     const int64_t img_bytes = (int64_t)H * W * ldx * 4;
     const int64_t span_imgs = 256 / ((int64_t)Ho * Wo) + 2;
     if (M64 * ldy * 4 >= 0x7FFFFFF0ll || (residual && M64 * ldr * 4 >= 0x7FFFFFF0ll)) return MYDET_E_UNSUPP;
-    if (KH * KW > 31 || img_bytes * span_imgs >= 0x7FFFFFF0ll || 3 * (int64_t)Cout * K64 * 2 >= 0x7FFFFFF0ll) return MYDET_E_UNSUPP;
+    if (KH * KW > 31 || img_bytes * span_imgs >= 0x7FFFFFF0ll || mydet_split_bf16_elems(Cout, (int)K64) * 2 >= 0x7FFFFFF0ll) return MYDET_E_UNSUPP;
     ConvArgs a;
     a.x = x; a.w = nullptr; a.scale = scale; a.shift = shift; a.res = residual; a.gate = nullptr; a.y = y;
     a.ldx = ldx; a.ldr = ldr; a.ldy = ldy;
@@ -950,6 +1207,14 @@ extern "C" int mydet_conv2d_igemm_b3_f32(const float *x, int64_t ldx, const uint
     a.ws = ((uintptr_t)workspace & 15) ? nullptr : (float *)workspace;
     a.ws_bytes = workspace_bytes > 0 ? (size_t)workspace_bytes : 0;
     if (Cout <= 64) return launch_b3<128, 64>(a, (hipStream_t)stream);
+    // two other forms stay selectable (read once; mydet_conv_b3_reload_tuning re-reads), both correct and tested, neither faster:
+    //   MYDET_B3_WIDE=1  from 192 output channels a 128 x 256 tile, one 8-wave workgroup per CU, weights by LDS-DMA -- 0.66 / 0.75
+    //                    / 0.66 ms vs 0.65 / 0.69 / 0.69 on the three deep stride-2 layers, 1 538 vs 1 545 images/s in the model;
+    //   MYDET_B3_WAVES=8 8-wave workgroups (wave tile 64 x 32, four waves per SIMD) -- 5-10 % faster back to back, 0.7 % slower
+    //                    in the model (1 510 vs 1 520 images/s, twice each in one call)
+    const int form = b3_form();
+    if ((form & 1) && Cout > 192) return launch_b3w(a, (hipStream_t)stream);
+    if (form & 2) return launch_b3<128, 128, 4>(a, (hipStream_t)stream);
     return launch_b3<128, 128>(a, (hipStream_t)stream);
 }
 

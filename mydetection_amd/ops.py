@@ -274,13 +274,19 @@ def b3_takes(M, Cin, Cout, k):
     return SPLIT_BF16 and Cin % 16 == 0 and M >= B3_MIN_ROWS and (k > 1 or Cout >= 128)
 
 
-def split_bf16(w):
-    """Three bfloat16 planes [3, n] (int16 storage) of a float32 tensor, w = p0 + p1 + p2 to 2^-27 |w| (include/mydet.h:
-    mydet_split_bf16_f32): the weight operand of `conv2d(..., b3=)`."""
-    require_gpu(w, 'split_bf16')
-    w = w.contiguous().float()
-    out = torch.empty((3, w.numel()), dtype=torch.int16, device=w.device)
-    _lib.check(_lib.lib().mydet_split_bf16_f32(_ptr(w), w.numel(), _ptr(out), _stream()), 'mydet_split_bf16_f32')
+def split_bf16(w_ohwi):
+    """The weight operand of `conv2d(..., b3=)`: the OHWI weight [Cout, kh, kw, Cin] as three bfloat16 planes, w = p0 + p1 + p2 to
+    2^-27 |w|, in the split-bf16 kernels' slab-major order (include/mydet.h: mydet_split_bf16_f32); int16 storage.
+    None when Cin % 16."""
+    require_gpu(w_ohwi, 'split_bf16')
+    Cout = w_ohwi.shape[0]
+    K = w_ohwi.numel() // Cout
+    n = _lib.lib().mydet_split_bf16_elems(Cout, K)
+    if n <= 0 or w_ohwi.shape[-1] % 16:
+        return None
+    w = w_ohwi.contiguous().float()
+    out = torch.empty(n, dtype=torch.int16, device=w.device)
+    _lib.check(_lib.lib().mydet_split_bf16_f32(_ptr(w), Cout, K, _ptr(out), _stream()), 'mydet_split_bf16_f32')
     return out
 
 

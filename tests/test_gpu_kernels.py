@@ -79,12 +79,30 @@ def test_conv_igemm_vs_fp64(dev, case):
     dict(B=9, Cin=512, Cout=255, k=1, s=1, H=31, W=33, act=0, bias_only=True),   # head conv: ragged rows and channels (255), bias only
     dict(B=9, Cin=64, Cout=192, k=3, s=2, H=77, W=53, act=2),                    # odd sizes, swish, a half-empty second channel tile
     dict(B=40, Cin=1024, Cout=512, k=1, s=1, H=20, W=20, act=1),                 # 125 x 4 = 500 tiles: one round of 512
-    dict(B=33, Cin=512, Cout=1024, k=3, s=2, H=40, W=40, act=1),                 # 104 x 8 = 832 tiles, 288 slabs: whole round + split-K tail
+    dict(B=33, Cin=512, Cout=1024, k=3, s=2, H=40, W=40, act=1),                 # 288 slabs
+    dict(B=33, Cin=512, Cout=1024, k=3, s=2, H=40, W=40, act=1, form='wide'),    # wide form (128 x 256 tiles, DMA-fed weights): 104 x 4 tiles, 288 slabs
+    dict(B=69, Cin=128, Cout=256, k=3, s=2, H=64, W=64, act=1, residual=True, form='wide'),   # 552 tiles = two rounds of 256 + 40 cut along K (fixup launch)
+    dict(B=12, Cin=256, Cout=320, k=1, s=1, H=27, W=29, act=2, form='wide'),     # ragged rows, a quarter-full second channel tile (320)
+    dict(B=32, Cin=128, Cout=256, k=3, s=2, H=40, W=40, act=1, form='waves8'),   # 8-wave workgroups (wave tile 64 x 32)
+    dict(B=9, Cin=512, Cout=255, k=1, s=1, H=31, W=33, act=0, bias_only=True, form='waves8'),
 ])
 def test_conv_split_bf16_vs_fp64(dev, case, monkeypatch):
     """The implicit GEMM on the bfloat16 matrix instructions with float32-exact split operands (conv_igemm_b3_kernel;
     ops.conv2d(..., b3=)): held to the SAME 2e-5 * max|y| against float64 as the float32-instruction kernel, agrees with that
     kernel to float32 round-off, is bit-repeatable, and really ran (ops.b3_takes for the shape)."""
+    from mydetection_amd import ops, _lib
+    form = case.get('form')
+    if form:                                               # the two opt-in forms of the launcher (read once per process otherwise)
+        monkeypatch.setenv('MYDET_B3_WIDE' if form == 'wide' else 'MYDET_B3_WAVES', '1' if form == 'wide' else '8')
+    assert _lib.lib().mydet_conv_b3_reload_tuning() == {None: 0, 'wide': 1, 'waves8': 2}[form]
+    try:
+        _split_bf16_case(dev, case)
+    finally:
+        monkeypatch.undo()
+        assert _lib.lib().mydet_conv_b3_reload_tuning() == 0
+
+
+def _split_bf16_case(dev, case):
     from mydetection_amd import ops
     B, Cin, Cout, k, s, H, W = (case[n] for n in ('B', 'Cin', 'Cout', 'k', 's', 'H', 'W'))
     g = torch.Generator().manual_seed(Cin + Cout)
@@ -108,8 +126,15 @@ def test_conv_split_bf16_vs_fp64(dev, case, monkeypatch):
     xd = x.to(dev).contiguous(memory_format=torch.channels_last)
     wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
     w3 = ops.split_bf16(wd)
-    planes = w3.view(torch.bfloat16).float().sum(0).view_as(wd)               # p0 + p1 + p2 == w to 2^-27
-    assert (planes - wd).abs().max().item() <= 2.0 ** -24 * wd.abs().max().item()
+    # the operand's layout (slab-major, 256-row padding, DMA swizzle): undone here, p0 + p1 + p2 == w to 2^-27
+    K, CoutP = wd.numel() // Cout, (Cout + 255) // 256 * 256
+    pl = w3.view(torch.bfloat16).float().view(K // 16, 3, CoutP // 32, 64, 8).sum(1)          # [kt][blk][unit][8]
+    rr = torch.arange(32, device=dev)
+    unit = torch.stack([2 * rr + (h ^ ((rr >> 2) & 1)) for h in (0, 1)], 1)                    # [row in block][k-half]
+    rows = pl[:, :, unit]                                                                     # [kt][blk][32][2][8]
+    back = rows.permute(1, 2, 0, 3, 4).reshape(CoutP, K)[:Cout].view_as(wd)
+    assert (back - wd).abs().max().item() <= 2.0 ** -24 * wd.abs().max().item()
+    assert not bool(rows.permute(1, 2, 0, 3, 4).reshape(CoutP, K)[Cout:].any())
     kw = dict(residual=res.to(dev).contiguous(memory_format=torch.channels_last) if res is not None else None)
     args = (xd, wd, scale.to(dev) if scale is not None else None, shift.to(dev), k, s, (p, p, p, p), case['act'])
     ops.TIMER = ops.KernelTimer()
