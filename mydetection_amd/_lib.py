@@ -93,7 +93,7 @@ class SeTail(ctypes.Structure):
     _fields_ = [('w1', c_ptr), ('b1', c_ptr), ('w2t', c_ptr), ('b2', c_ptr), ('gate', c_ptr), ('hpart', c_ptr), ('Cse', c_int)]
 
 
-SE_EMPTY_WORD = 0x7FC5E5E5          # MYDET_SE_EMPTY_WORD of include/mydet.h
+SE_EPOCH_WORDS = 1024               # MYDET_SE_EPOCH_WORDS of include/mydet.h
 
 
 class SepconvNode(ctypes.Structure):

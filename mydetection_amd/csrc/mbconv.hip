@@ -162,6 +162,7 @@ __global__ __launch_bounds__(256) void dwconv_sum_kernel(const DwArgs p) {
     if (se_on && threadIdx.x < MYDET_SE_MAX_CSE) selds[threadIdx.x] = 0.f;      // (the first barrier below orders it)
     const int Q = p.C >> 2, WG = p.Wo / TW;
     const int b = blockIdx.y, s = blockIdx.x;
+    const unsigned se_ep = se_on ? se_epoch(p.se, b) : 0u;
     const int NG = (p.Ho / TH) * WG;                   // TH = 2: a work item is a TW x 2 block (stride 1, Ho even)
     const int per = (NG + p.S - 1) / p.S;
     const int g0 = s * per, g1 = min(NG, g0 + per);
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256) void dwconv_sum_kernel(const DwArgs p) {
             __syncthreads();
         }
     }
-    if (se_on) se_tail_finish(p.se, selds, p.C, p.Ho * p.Wo, b, s, p.S);
+    if (se_on) se_tail_finish(p.se, selds, p.C, p.Ho * p.Wo, b, s, p.S, se_ep);
 }
 
 
@@ -259,6 +260,8 @@ __global__ __launch_bounds__(256, 4) void dwconv_tile_kernel(const DwTArgs p) {
     const int ih0 = oh0 - p.pad_t, iw0 = ow0 - p.pad_l;
     const int Q = p.C >> 2, q0 = chunk * CQ;
     const float *xb = p.x + (int64_t)b * p.H * p.W * p.ldx;
+    unsigned se_ep = 0u;
+    if (SUM && p.se.gate != nullptr) se_ep = se_epoch(p.se, b);
     // taps of this chunk -> LDS (a quad past the end reads the last quad; its outputs are never stored)
     if (tid < K * K * CQ) {
         const int tap = tid / CQ, q = min(q0 + tid % CQ, Q - 1);
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(256, 4) void dwconv_tile_kernel(const DwTArgs p) {
             __syncthreads();
             se_fc1_accumulate(p.se, p.C, tots, q0 * 4, min(CQ * 4, p.C - q0 * 4), selds);
             __syncthreads();
-            se_tail_finish(p.se, selds, p.C, p.Ho * p.Wo, b, r * p.nchunks + chunk, p.S * p.nchunks);
+            se_tail_finish(p.se, selds, p.C, p.Ho * p.Wo, b, r * p.nchunks + chunk, p.S * p.nchunks, se_ep);
         }
     }
 }
@@ -839,7 +842,7 @@ extern "C" int mydet_dwconv_f32(const float *x, int64_t ldx, const float *w, con
     p.x = x; p.w = w; p.scale = scale; p.shift = shift; p.y = y; p.partial = se_partial; p.ldx = ldx; p.ldy = ldy;
     p.C = C; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.pad_t = pad_t; p.pad_l = pad_l; p.act = act; p.S = S; p.total = 0;
     p.se = se ? *se : NO_SE_TAIL;
-    if (const int e = mydet_se_tail_check(p.se, C)) return e;
+    if (const int e = mydet_se_tail_check(p.se, C, B)) return e;
     if (p.se.gate && (S <= 0 || S > 4096 || B > 65535)) return MYDET_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     if ((se_partial || p.se.gate) && S != mydet_dwconv_slices(Ho, Wo, C, K, stride)) return MYDET_E_BADARG;

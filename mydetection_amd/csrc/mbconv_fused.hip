@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256, 2) void mbconv_expand_dw_kernel(const MbArgs p
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = blockIdx.x;
     const int b = t / p.tiles_per_img, r = t - b * p.tiles_per_img;
+    const unsigned se_ep = se_on ? se_epoch(p.se, b) : 0u;
     const int ty = r / p.tiles_x, tx = r - ty * p.tiles_x;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = oy0 * ST - p.pad_t, ix0 = ox0 * ST - p.pad_l;
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void mbconv_expand_dw_kernel(const MbArgs p
         __syncthreads();
         se_fc1_accumulate(p.se, p.Cexp, tots, 0, p.Cexp, selds);
         __syncthreads();
-        se_tail_finish(p.se, selds, p.Cexp, p.Ho * p.Wo, b, r, p.tiles_per_img);
+        se_tail_finish(p.se, selds, p.Cexp, p.Ho * p.Wo, b, r, p.tiles_per_img, se_ep);
     }
 }
 
@@ -284,7 +285,7 @@ extern "C" int mydet_mbconv_expand_dw_f32(const float *x, int64_t ldx, const flo
     p.Cexp = Cexp; p.pad_t = pad_t; p.pad_l = pad_l; p.S = S;
     const SeTail none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     p.se = se ? *se : none;
-    if (const int e = mydet_se_tail_check(p.se, Cexp)) return e;
+    if (const int e = mydet_se_tail_check(p.se, Cexp, B)) return e;
     hipStream_t st = (hipStream_t)stream;
     // the (kernel, stride, Cin) combinations of EfficientNet-B0..B2 stages 2-4 (external/efficientnet/utils.py:258-263)
     if (K == 3 && stride == 2 && Cin == 16) return launch<3, 2, 16>(p, B, st);

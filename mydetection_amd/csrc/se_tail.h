@@ -11,10 +11,18 @@
 //     order (fixed order: deterministic), applies 1 / HW, bias and swish, and runs the expand conv + sigmoid for the image's C
 //     channels.  Nobody else waits for anything: a share is Cse fire-and-forget stores.
 // Stores / loads that cross workgroups carry the sc1 (device) scope, so no L2 write-back or invalidate is needed -- the idiom
-// the split-K experiment of round 4 proved bit-exact (profiles/r04_tried/igemm_inkernel_split_sum.diff.txt).  The share
-// buffer holds an "empty" mark in every float between launches; the finishing workgroup puts it back.
-// (A first form with an arrival counter -- every workgroup waits for its stores, then for its atomic -- doubled the depthwise
-// kernels' time: two dependent device-scope round trips at the end of thousands of 8 us workgroups.)
+// the split-K experiment of round 4 proved bit-exact (profiles/r04_tried/igemm_inkernel_split_sum.diff.txt).
+// How the finishing workgroup knows a share is THIS launch's: every image slot of the buffer has a launch counter (its
+// "epoch"); a workgroup reads its image's counter when it starts and publishes every share value as an 8-byte (value, epoch)
+// pair in ONE store; the finishing workgroup accepts pairs of its epoch only and, when it is done, advances the counter.
+// Every word of the buffer has exactly ONE writer per launch (the pair: its workgroup; the counter: the image's finishing
+// workgroup), so nothing depends on the order in which two stores of one launch reach memory.
+// (Two earlier forms.  An arrival counter -- every workgroup waits for its stores, then for its atomic -- doubled the
+// depthwise kernels' time: two dependent device-scope round trips at the end of thousands of 8 us workgroups.  An "empty" mark
+// that the finishing workgroup put back into every share word after reading it: correct in every single-stream run, and WRONG
+// under two batch lanes -- the finishing workgroup's reset and the owner's earlier store of the same launch are two writers
+// of one word from different XCDs, the owner's value could land last, and the next layer's finishing workgroup, started
+// early because the other lane held the CUs, summed the PREVIOUS layer's share: profiles/HISTORY.md, round 5.)
 #pragma once
 #include "common.h"
 
@@ -22,13 +30,6 @@ typedef mydet_se_tail SeTail;      // include/mydet.h; .gate == nullptr: no in-l
 
 constexpr int MYDET_SE_MAX_CSE = 96;
 constexpr int MYDET_SE_LDS_FLOATS = MYDET_SE_MAX_CSE + 256 + MYDET_SE_MAX_CSE;     // h_acc | phase sums | hidden layer
-
-__device__ __forceinline__ void mydet_store_dev(float *p, float v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float mydet_load_dev(const float *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // h_acc[o] += sum_{j < nc} W1[o][c0 + j] * tot[j] for every o < Cse; tot: LDS, channel sums of channels c0 .. c0 + nc - 1
 // (c0 % 4 == 0).  256 threads: thread (o = tid / 4, part = tid % 4) takes 8 of every 32 channels, the four parts are added in
@@ -58,36 +59,36 @@ __device__ __forceinline__ void se_fc1_accumulate(const SeTail &t, int C, const 
     }
 }
 
-// Called by ALL 256 threads of every workgroup of image b once its h_acc is complete (and a barrier has made it visible).
-// wg = this workgroup's index among the nwg workgroups of its image (in dispatch order: the kernels number their blocks image
-// by image), hpart = the image-major share buffer [B][nwg][Cse] whose every float holds MYDET_SE_EMPTY between launches.
-//   * every workgroup but the last of its image: Cse device-scope stores, fire and forget -- no wait, no atomic, no fence;
-//   * the last workgroup (wg == nwg - 1; block ids are dispatched in order, so every other workgroup of the image is running
-//     or done when it starts): reads all shares at device scope until none is empty (a bounded poll: workgroups that are
-//     still finishing), puts the empty mark back for the next launch, and finishes the gate.  Sums in workgroup order:
-//     deterministic.  If the poll gives up (it never should) the gate is NaN, so the failure cannot pass for a result.
-constexpr unsigned MYDET_SE_EMPTY = 0x7FC5E5E5u;      // a quiet NaN with a payload no arithmetic produces
+// The share buffer (include/mydet.h: mydet_se_tail.hpart), 8-byte aligned, 32-bit words:
+//     [0, MYDET_SE_EPOCH_WORDS)   launch counter of image slot b (never 0; 1 when the buffer is made)
+//     then [B][nwg][Cse] pairs    (value, epoch) of workgroup wg's share of hidden unit o; all zero when the buffer is made
+constexpr int MYDET_SE_EPOCHS = MYDET_SE_EPOCH_WORDS;
 
-__device__ __forceinline__ void se_tail_finish(const SeTail &t, float *lds, int C, int HW, int b, int wg, int nwg) {
+// the epoch of image b's slot, requested when the workgroup starts (the value is needed only when its share leaves)
+__device__ __forceinline__ unsigned se_epoch(const SeTail &t, int b) {
+    return __hip_atomic_load(reinterpret_cast<const unsigned *>(t.hpart) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Called by ALL 256 threads of every workgroup of image b once its h_acc is complete (and a barrier has made it visible).
+// wg = this workgroup's index among the nwg workgroups of its image, epoch = se_epoch(t, b) read by this workgroup.
+//   * every workgroup but the last of its image: Cse device-scope 8-byte stores, fire and forget -- no wait, no atomic, no fence;
+//   * the last workgroup (wg == nwg - 1; within an XCD block ids are dispatched in order, so most of the image's other
+//     workgroups are running or done when it starts -- a matter of waiting time only): reads all pairs at device scope until
+//     every one carries its epoch (a bounded poll), sums the values in workgroup order (deterministic), finishes the gate and
+//     advances the image's counter.  If the poll gives up (it never should) the gate is NaN, so the failure cannot pass for
+//     a result.
+__device__ __forceinline__ void se_tail_finish(const SeTail &t, float *lds, int C, int HW, int b, int wg, int nwg, unsigned epoch) {
     const int tid = threadIdx.x, Cse = t.Cse;
-    float *hp = t.hpart + (int64_t)b * nwg * Cse;
-    if (tid < Cse) mydet_store_dev(hp + (int64_t)wg * Cse + tid, lds[tid]);
+    unsigned long long *hp = reinterpret_cast<unsigned long long *>(t.hpart + MYDET_SE_EPOCHS) + (int64_t)b * nwg * Cse;
+    if (tid < Cse)
+        __hip_atomic_store(hp + (int64_t)wg * Cse + tid, ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, lds[tid]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (wg != nwg - 1) return;
     float *phase = lds + MYDET_SE_MAX_CSE, *hid = phase + 256;
     // hidden layer: the shares of all workgroups in workgroup order (P interleaved chains, combined in chain order)
     const int P = 256 / Cse;                                   // >= 2 (Cse <= 96)
     const int o = tid % Cse, ph = tid / Cse;
-    const float empty = __builtin_bit_cast(float, MYDET_SE_EMPTY);
-    // the expand conv's operands do not depend on the data: bias and the first eight rows of this thread's first channel quad
-    // are requested before the wait for the shares (consumed in place of the same loads below)
     const int Q = C >> 2;
-    f32x4 pw[8], pb2 = {0.f, 0.f, 0.f, 0.f};
-    {
-        const int q = tid < Q ? tid : 0;
-        pb2 = *reinterpret_cast<const f32x4 *>(t.b2 + q * 4);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pw[j] = *reinterpret_cast<const f32x4 *>(t.w2t + (int64_t)(j < Cse ? j : 0) * C + q * 4);
-    }
     float sum = 0.f;
     int spins = 0;
     bool ok = true;
@@ -95,17 +96,18 @@ __device__ __forceinline__ void se_tail_finish(const SeTail &t, float *lds, int 
         int missing = 0;
         sum = 0.f;
         if (ph < P) {
-            for (int w0 = ph; w0 < nwg; w0 += 16 * P) {        // 16 independent device-scope loads in flight
-                float v[16];
+            for (int w0 = ph; w0 < nwg; w0 += 8 * P) {         // 8 independent 8-byte device-scope loads in flight
+                unsigned long long v[8];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
+                for (int u = 0; u < 8; ++u) {
                     const int w = w0 + u * P;
-                    v[u] = w < nwg ? mydet_load_dev(hp + (int64_t)w * Cse + o) : 0.f;
+                    v[u] = __hip_atomic_load(hp + (int64_t)(w < nwg ? w : wg) * Cse + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    missing |= __builtin_bit_cast(unsigned, v[u]) == MYDET_SE_EMPTY;
-                    sum += v[u];
+                for (int u = 0; u < 8; ++u) {
+                    const bool in = w0 + u * P < nwg;
+                    missing |= in && (unsigned)(v[u] >> 32) != epoch;
+                    sum += in ? __builtin_bit_cast(float, (unsigned)v[u]) : 0.f;
                 }
             }
         }
@@ -113,10 +115,11 @@ __device__ __forceinline__ void se_tail_finish(const SeTail &t, float *lds, int 
         if (++spins >= (1 << 14)) { ok = false; break; }        // (uniform: every thread sees the same vote and count)
         __builtin_amdgcn_s_sleep(2);
     }
-    if (ph < P) {
-        for (int w = ph; w < nwg; w += P) mydet_store_dev(hp + (int64_t)w * Cse + o, empty);      // ready for the next launch
-        phase[ph * Cse + o] = sum;
+    if (tid == 0) {                                            // the next launch on this image slot gets a new epoch (never 0)
+        const unsigned next = epoch + 1u ? epoch + 1u : 1u;
+        __hip_atomic_store(reinterpret_cast<unsigned *>(t.hpart) + b, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (ph < P) phase[ph * Cse + o] = sum;
     __syncthreads();
     if (tid < Cse) {
         float s = phase[tid];
@@ -125,17 +128,16 @@ __device__ __forceinline__ void se_tail_finish(const SeTail &t, float *lds, int 
         hid[tid] = ok ? v * mydet_sigmoid(v) : __builtin_nanf("");
     }
     __syncthreads();
-    // expand conv + sigmoid: a thread per channel QUAD (16-byte rows of the transposed weight), k in order, eight rows in flight
+    // expand conv + sigmoid: a thread per channel QUAD (16-byte rows of the transposed weight), k in order, eight rows in flight.
+    // The multiply-adds are written as v_fma_f32, one per channel: left to the compiler this loop became v_pk_fma_f32 pairs, and
+    // that build -- and only that one -- returned wrong LOW halves in lanes 48-63 of the finishing workgroup whenever the other
+    // batch lane's split-bf16 convs ran on the same CUs (found with two lanes + split-bf16 expand convs: a third of the gates off
+    // by 1e-2..2e-1 in every replay; sums of the shares and the hidden layer were right every time; with this form 0 of 2 x 400
+    // replays differ and every gate equals the one recomputed on the host: profiles/HISTORY.md, round 5).  Not understood beyond
+    // that; a stand-alone probe of v_pk_fma_f32 beside MFMA kernels (tools/hw_pk_fma_vs_mfma.hip) did not reproduce it.
     for (int q = tid; q < Q; q += 256) {
-        f32x4 e = q == tid ? pb2 : *reinterpret_cast<const f32x4 *>(t.b2 + q * 4);
+        f32x4 e = *reinterpret_cast<const f32x4 *>(t.b2 + q * 4);
         int k = 0;
-        if (q == tid && Cse >= 8) {                    // the prefetched first eight rows
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) e[c] = fmaf(pw[j][c], hid[j], e[c]);
-            k = 8;
-        }
         for (; k + 7 < Cse; k += 8) {
             f32x4 w[8];
 #pragma unroll
@@ -143,12 +145,12 @@ __device__ __forceinline__ void se_tail_finish(const SeTail &t, float *lds, int 
 #pragma unroll
             for (int j = 0; j < 8; ++j)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) e[c] = fmaf(w[j][c], hid[k + j], e[c]);
+                for (int c = 0; c < 4; ++c) asm("v_fma_f32 %0, %1, %2, %0" : "+v"(e[c]) : "v"(w[j][c]), "v"(hid[k + j]));
         }
         for (; k < Cse; ++k) {
             const f32x4 w = *reinterpret_cast<const f32x4 *>(t.w2t + (int64_t)k * C + q * 4);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) e[c] = fmaf(w[c], hid[k], e[c]);
+            for (int c = 0; c < 4; ++c) asm("v_fma_f32 %0, %1, %2, %0" : "+v"(e[c]) : "v"(w[c]), "v"(hid[k]));
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) e[c] = mydet_sigmoid(e[c]);
@@ -157,10 +159,12 @@ __device__ __forceinline__ void se_tail_finish(const SeTail &t, float *lds, int 
 }
 
 // host side: arguments of an in-launch tail are complete and inside the kernels' limits
-static inline int mydet_se_tail_check(const SeTail &t, int C) {
+static inline int mydet_se_tail_check(const SeTail &t, int C, int B) {
     if (!t.gate) return 0;
+    if (B > MYDET_SE_EPOCH_WORDS) return MYDET_E_UNSUPP;
     if (!t.w1 || !t.b1 || !t.w2t || !t.b2 || !t.hpart) return MYDET_E_BADARG;
     if (((uintptr_t)t.w1 & 15) || ((uintptr_t)t.w2t & 15) || ((uintptr_t)t.b2 & 15) || ((uintptr_t)t.gate & 15) || (C & 3)) return MYDET_E_BADARG;
+    if ((uintptr_t)t.hpart & 7) return MYDET_E_BADARG;
     if (t.Cse < 1 || t.Cse > MYDET_SE_MAX_CSE) return MYDET_E_UNSUPP;
     return 0;
 }

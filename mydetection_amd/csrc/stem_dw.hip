@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256, 2) void stem_dw_kernel(const SdArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = blockIdx.x;
     const int b = t / p.tiles_per_img, r = t - b * p.tiles_per_img;
+    const unsigned se_ep = p.se.gate != nullptr ? se_epoch(p.se, b) : 0u;
     const int ty = r / p.tiles_x, tx = r - ty * p.tiles_x;
     const int oy0 = ty * SD_TH, ox0 = tx * SD_TW;
     const int sy0 = oy0 - 1, sx0 = ox0 - 1;                                   // first stem pixel of the tile (may be -1)
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void stem_dw_kernel(const SdArgs p) {
         __syncthreads();
         se_fc1_accumulate(p.se, SD_C, tots, 0, SD_C, selds);
         __syncthreads();
-        se_tail_finish(p.se, selds, SD_C, p.Hs * p.Ws, b, r, p.tiles_per_img);
+        se_tail_finish(p.se, selds, SD_C, p.Hs * p.Ws, b, r, p.tiles_per_img, se_ep);
     }
 }
 
@@ -213,7 +214,7 @@ extern "C" int mydet_stem_dw_f32(const float *x, int64_t sxb, int64_t sxc, int64
     p.S = S;
     const SeTail none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     p.se = se ? *se : none;
-    if (const int e = mydet_se_tail_check(p.se, C)) return e;
+    if (const int e = mydet_se_tail_check(p.se, C, B)) return e;
     if ((se_partial || p.se.gate) && S != p.tiles_per_img) return MYDET_E_BADARG;
     const int64_t grid = (int64_t)B * p.tiles_per_img;
     if (grid > 0x7fffffff) return MYDET_E_UNSUPP;

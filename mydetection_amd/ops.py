@@ -170,17 +170,19 @@ SE_IN_DW = os.environ.get('MYDET_SE_IN_DW', '1') != '0'
 SE_IN_DW_MIN_C = int(os.environ.get('MYDET_SE_IN_DW_MIN_C', '1000'))
 
 
-def se_shares(device, n_floats):
-    """Per-device, per-lane share buffer of the in-launch squeeze-excite tail (include/mydet.h: mydet_se_tail.hpart): every
-    word holds the "empty" mark between launches by the kernels' own protocol, so ONE buffer serves every layer of a lane's
-    stream.  Grows to the largest layer seen (filled with the mark when it is made; not during a stream capture)."""
+def se_shares(device, n_pairs):
+    """Per-device, per-lane share buffer of the in-launch squeeze-excite tail (include/mydet.h: mydet_se_tail.hpart): launch
+    counters (1) followed by room for `n_pairs` (value, epoch) pairs (0).  The kernels' own protocol keeps it consistent, so
+    ONE buffer serves every layer of a lane's stream.  Grows to the largest layer seen (not during a stream capture)."""
     key = (device.type, device.index, _LANE)
     buf = _SE_SHARES.get(key)
-    if buf is None or buf.numel() < n_floats:
+    need = _lib.SE_EPOCH_WORDS + 2 * int(n_pairs)
+    if buf is None or buf.numel() < need:
         if device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
             raise RuntimeError('se_shares: the share buffer would grow during stream capture; run the model once eagerly first')
-        n = max(int(n_floats), 1 << 20)
-        buf = _SE_SHARES[key] = torch.full((n,), _lib.SE_EMPTY_WORD, dtype=torch.int32, device=device).view(torch.float32)
+        buf = torch.zeros(max(need, 1 << 21), dtype=torch.int32, device=device)
+        buf[:_lib.SE_EPOCH_WORDS] = 1
+        _SE_SHARES[key] = buf = buf.view(torch.float32)
     return buf
 
 
@@ -191,7 +193,7 @@ def _se_tail(se, B, C, groups, device):
     w1, b1, w2t, b2 = se
     Cse = w1.shape[0]
     assert tuple(w1.shape) == (Cse, C) and tuple(w2t.shape) == (Cse, C) and w1.is_contiguous() and w2t.is_contiguous()
-    assert Cse <= SE_MAX_CSE and groups > 0
+    assert Cse <= SE_MAX_CSE and groups > 0 and B <= _lib.SE_EPOCH_WORDS
     gate = torch.empty((B, C), dtype=torch.float32, device=device)
     hpart = se_shares(device, B * groups * Cse)
     t = _lib.SeTail(w1.data_ptr(), b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), gate.data_ptr(), hpart.data_ptr(), Cse)
@@ -267,11 +269,16 @@ SPLIT_BF16 = os.environ.get('MYDET_CONV_SPLIT_BF16', '1') != '0'
 # small-grid K cut is the tuned path (batch-1 layers) -- and, for 1x1 layers, from 128 output channels (tools/r05_b3.py:
 # 128->64 @160^2 0.197 vs 0.187 ms for the float32 kernel; every wider shape of the headline 1.25-1.35 x faster)
 B3_MIN_ROWS = int(os.environ.get('MYDET_B3_MIN_ROWS', '8192'))
+# The EfficientNet expand convs (1x1, 6 x Cin output channels, swish) take it from fewer rows: on a batch lane of 8 / 16 images
+# the 20^2 layers have 3 200 / 6 400 rows and still fill the chip (225-750 tiles of 128 x 128).  Measured in the model, two
+# lanes (tools/r05_b3_effnet.sh, two runs each): expand convs on the float32 instruction 3 721 / 4 211 images/s (D1 batch 16 /
+# D1-FCOS batch 32), split-bf16 from 8 192 rows 3 761 / 4 268, from 3 000 rows 3 859 / 4 350.  MYDET_B3_EXPAND_MIN_ROWS=0 = off.
+B3_EXPAND_MIN_ROWS = int(os.environ.get('MYDET_B3_EXPAND_MIN_ROWS', '3000'))
 
 
-def b3_takes(M, Cin, Cout, k):
+def b3_takes(M, Cin, Cout, k, min_rows=None):
     """True when `conv2d(..., b3=)` runs the split-bf16 kernel for a layer of this shape."""
-    return SPLIT_BF16 and Cin % 16 == 0 and M >= B3_MIN_ROWS and (k > 1 or Cout >= 128)
+    return SPLIT_BF16 and Cin % 16 == 0 and M >= (B3_MIN_ROWS if min_rows is None else min_rows) and (k > 1 or Cout >= 128)
 
 
 def split_bf16(w_ohwi):
@@ -291,7 +298,7 @@ def split_bf16(w_ohwi):
 
 
 def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None, out_ld=None, gate=None, wino=None,
-           wino4=None, interior=None, b3=None):
+           wino4=None, interior=None, b3=None, b3_min_rows=None):
     """y = act(conv(x * gate)*scale + shift) + residual.  x logical [B,Cin,H,W]; pad=(top,left,bottom,right);
     gate: optional [B,Cin] per-image channel multipliers (squeeze-excite), 1x1 convs only;
     wino / wino4: optional `wino_weights(w_ohwi)` / `wino4_weights(w_ohwi)`: 3x3 stride-1 pad-1 layers then run a fused
@@ -299,7 +306,8 @@ def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None
     interior: 'in' / 'out' marks the input / output as a tensor that lives only inside a block (bookkeeping of the
     fused-minimum byte count of KernelTimer; no effect on the launch).
     b3: optional `split_bf16(w_ohwi)`: a layer that stays on the direct implicit GEMM then runs it on the bfloat16 matrix
-    instructions with float32-exact split operands (include/mydet.h: mydet_conv2d_igemm_b3_f32; Cin % 16 == 0, no gate)."""
+    instructions with float32-exact split operands (include/mydet.h: mydet_conv2d_igemm_b3_f32; Cin % 16 == 0, no gate), from
+    B3_MIN_ROWS output pixels up (`b3_min_rows` overrides)."""
     require_gpu(x, 'conv2d')
     if x.shape[1] % 4:
         raise ValueError(f'conv2d: Cin = {x.shape[1]} is not a multiple of 4 (the implicit-GEMM kernel reads channels in '
@@ -344,7 +352,7 @@ def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None
         _lib.check(code, 'mydet_conv2d_wino_f32')
         return out
     ws = conv_workspace(x.device)
-    if b3 is not None and gate is None and b3_takes(B * Ho * Wo, Cin, Cout, k):
+    if b3 is not None and gate is None and b3_takes(B * Ho * Wo, Cin, Cout, k, b3_min_rows):
         t0 = TIMER.start() if TIMER else None
         code = _lib.lib().mydet_conv2d_igemm_b3_f32(
             _ptr(x), ldx, _ptr(b3), _ptr(scale), _ptr(shift), _ptr(residual), ldr, _ptr(ws), ws.numel() * 4, _ptr(out), ldy,

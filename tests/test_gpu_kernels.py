@@ -759,7 +759,8 @@ def test_se_gate_inside_depthwise_launch(dev, kind, C, Cse, k, s, H, W):
         assert torch.equal(gate2, gate1) and torch.equal(y2.contiguous(), y0.contiguous())
     from mydetection_amd import _lib
     shares = ops.se_shares(dev, 1).view(torch.int32)
-    assert bool((shares == _lib.SE_EMPTY_WORD).all())
+    epochs = shares[:_lib.SE_EPOCH_WORDS]
+    assert bool((epochs[:B] == epochs[0]).all()) and int(epochs[0]) > 1 and bool((epochs[B:] == 1).all())     # one step per launch and image
 
 
 @pytest.mark.parametrize('Cin,Cout,H,W,gated,res,act', [
