@@ -278,7 +278,11 @@ B3_EXPAND_MIN_ROWS = int(os.environ.get('MYDET_B3_EXPAND_MIN_ROWS', '3000'))
 
 def b3_takes(M, Cin, Cout, k, min_rows=None):
     """True when `conv2d(..., b3=)` runs the split-bf16 kernel for a layer of this shape."""
-    return SPLIT_BF16 and Cin % 16 == 0 and M >= (B3_MIN_ROWS if min_rows is None else min_rows) and (k > 1 or Cout >= 128)
+    if not SPLIT_BF16 or Cin % 16 or not (k > 1 or Cout >= 128):
+        return False
+    if min_rows is None:        # layers of up to 64 output channels run 128 x 64 tiles: one per CU at least (batch 1 at 512^2: the
+        min_rows = max(B3_MIN_ROWS, 32768) if Cout <= 64 else B3_MIN_ROWS      # 128-tile 32->64 stride-2 layer 0.15 vs 0.08 ms)
+    return M >= min_rows
 
 
 def split_bf16(w_ohwi):
