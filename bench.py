@@ -346,6 +346,23 @@ def main():
             code = code or c
             others[key] = brief_line(o, time.perf_counter() - t0)
         out['other_configs'] = others
+        # the headline once more with every direct conv on the float32 matrix instruction (MYDET_CONV_SPLIT_BF16=0's path): what
+        # the split-bf16 kernels contribute, on this box, in this call
+        from mydetection_amd import ops
+        if ops.SPLIT_BF16:
+            a = argparse.Namespace(**vars(args))
+            a.steps, a.warmup, a.no_cpu_baseline, a.parity_images = min(args.steps, 10), min(args.warmup, 3), True, 2
+            t0 = time.perf_counter()
+            ops.SPLIT_BF16 = False
+            try:
+                o, c = measure(a, ctx)
+            finally:
+                ops.SPLIT_BF16 = True
+            code = code or c
+            out['float32_mfma_only'] = {'value': o['value'], 'unit': o['unit'], 'ms_per_step': o['ms_per_step'], 'steps': o['steps'],
+                                        'max_score_err': o['parity_check'].get('max_score_err'), 'parity_ok': o['parity_check'].get('ok'),
+                                        'note': 'the same step with every direct conv on v_mfma_f32_32x32x2_f32 (no split-bf16 kernels)',
+                                        'wall_s': round(time.perf_counter() - t0, 1)}
     if out is not None:
         print(json.dumps(out))
     if dist_on:
@@ -670,6 +687,11 @@ def measure(args, ctx):
         'scaling': 'weak',
         'vs_baseline': None,
         'dtype': 'f32',
+        'arithmetic': ('float32 values and float32 accumulation throughout; ' +
+                       ('direct convs with Cin % 16 == 0 form their float32 products from exact three-piece bfloat16 splits of both '
+                        'operands (six v_mfma_f32_32x32x16_bf16 piece products per k-step; results equal the float32-instruction '
+                        "kernel's to float32 round-off; MYDET_CONV_SPLIT_BF16=0 turns it off)" if ops.SPLIT_BF16 else
+                        'every matrix product on v_mfma_f32_* (MYDET_CONV_SPLIT_BF16=0)')),
         'data': 'synthetic',
         'config': {'workload': f'{WORKLOADS.get(args.config, args.config)}, batch {batch}/GPU, {args.size}x{args.size}, '
                                'random-init calibrated weights' + (f', hipGraph replay ({graphed.lanes} batch lane{"s" if graphed.lanes > 1 else ""} per GPU)' if args.graph else ', eager launches'),

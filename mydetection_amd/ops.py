@@ -269,6 +269,7 @@ SPLIT_BF16 = os.environ.get('MYDET_CONV_SPLIT_BF16', '1') != '0'
 # small-grid K cut is the tuned path (batch-1 layers) -- and, for 1x1 layers, from 128 output channels (tools/r05_b3.py:
 # 128->64 @160^2 0.197 vs 0.187 ms for the float32 kernel; every wider shape of the headline 1.25-1.35 x faster)
 B3_MIN_ROWS = int(os.environ.get('MYDET_B3_MIN_ROWS', '8192'))
+B3_MIN_FLOP = float(os.environ.get('MYDET_B3_MIN_FLOP', '3e9'))
 # The EfficientNet expand convs (1x1, 6 x Cin output channels, swish) take it from fewer rows: on a batch lane of 8 / 16 images
 # the 20^2 layers have 3 200 / 6 400 rows and still fill the chip (225-750 tiles of 128 x 128).  Measured in the model, two
 # lanes (tools/r05_b3_effnet.sh, two runs each): expand convs on the float32 instruction 3 721 / 4 211 images/s (D1 batch 16 /
@@ -280,9 +281,12 @@ def b3_takes(M, Cin, Cout, k, min_rows=None):
     """True when `conv2d(..., b3=)` runs the split-bf16 kernel for a layer of this shape."""
     if not SPLIT_BF16 or Cin % 16 or not (k > 1 or Cout >= 128):
         return False
-    if min_rows is None:        # layers of up to 64 output channels run 128 x 64 tiles: one per CU at least (batch 1 at 512^2: the
-        min_rows = max(B3_MIN_ROWS, 32768) if Cout <= 64 else B3_MIN_ROWS      # 128-tile 32->64 stride-2 layer 0.15 vs 0.08 ms)
-    return M >= min_rows
+    if min_rows is not None:
+        return M >= min_rows
+    # ... and from 3 GFLOP per launch: below, the float32 kernel's small tiles and K cut are the tuned path.  Batch 1 at 512^2 has two
+    # layers past the row limit (32->64 and 64->128 stride 2: 2.4 GFLOP each on 512 / 128 tiles): 1.560 ms per image with them on
+    # this kernel, 1.427 without (two runs each in one call); the smallest layers that gain at batch 32 have 3.4 GFLOP.
+    return M >= B3_MIN_ROWS and 2.0 * M * k * k * Cin * Cout >= B3_MIN_FLOP
 
 
 def split_bf16(w_ohwi):

@@ -122,7 +122,7 @@ def _split_bf16_case(dev, case):
         res = torch.randn(ref.shape, generator=g)
         ref = ref + res.double()
     Ho, Wo = ref.shape[2:]
-    assert ops.b3_takes(B * Ho * Wo, Cin, Cout, k)
+    assert ops.b3_takes(B * Ho * Wo, Cin, Cout, k, min_rows=1)        # (the kernel, not the dispatch rule, is under test)
     xd = x.to(dev).contiguous(memory_format=torch.channels_last)
     wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
     w3 = ops.split_bf16(wd)
@@ -139,7 +139,7 @@ def _split_bf16_case(dev, case):
     args = (xd, wd, scale.to(dev) if scale is not None else None, shift.to(dev), k, s, (p, p, p, p), case['act'])
     ops.TIMER = ops.KernelTimer()
     try:
-        y3 = ops.conv2d(*args, b3=w3, **kw).clone()
+        y3 = ops.conv2d(*args, b3=w3, b3_min_rows=1, **kw).clone()
     finally:
         timer, ops.TIMER = ops.TIMER, None
     assert 'conv_igemm_b3' in timer.spans and 'conv_igemm' not in timer.spans
@@ -149,7 +149,7 @@ def _split_bf16_case(dev, case):
     assert e3 <= tol, (e3, e32, tol)
     assert e3 <= 4.0 * e32 + 1e-6, f'split-bf16 error {e3:.2e} vs float32-instruction error {e32:.2e}'
     for _ in range(2):
-        assert torch.equal(ops.conv2d(*args, b3=w3, **kw), y3)
+        assert torch.equal(ops.conv2d(*args, b3=w3, b3_min_rows=1, **kw), y3)
 
 
 @pytest.mark.parametrize('shape', [(2, 256, 512, 256, 20, 20),      # 28 x 4 tiles, K = 24 slabs: the small-grid K cut + CAT

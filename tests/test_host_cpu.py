@@ -570,3 +570,21 @@ def test_wino4_tail_plan_covers_every_item_once():
     assert lib.mydet_wino4_tail_plan(32, 40, 40, 256, 512, 512, out) == 1 and list(out[2:6]) == [1536, 2, 32, 8]
     assert lib.mydet_wino4_tail_plan(32, 20, 20, 512, 1024, 512, out) == 2 and list(out[2:6]) == [512, 4, 64, 2] and list(out[7:11]) == [768, 4, 8, 8]
     assert lib.mydet_wino4_tail_plan(32, 80, 80, 128, 256, 512, out) == 0          # six whole rounds: no tail
+
+
+def test_split_bf16_dispatch_rule():
+    """ops.b3_takes: which direct-conv layers run on the split-bf16 kernel (mydetection_amd/ops.py: measured thresholds)."""
+    from mydetection_amd import ops
+    if not ops.SPLIT_BF16:
+        return
+    px = lambda b, s: b * s * s                                                       # noqa: E731
+    # the headline (batch 32, 640^2): stride-2 3x3 layers, the DarkBlock / pyramid 1x1 layers from 128 outputs, the heads
+    for M, cin, cout, k in ((px(32, 320), 32, 64, 3), (px(32, 20), 512, 1024, 3), (px(32, 80), 256, 128, 1), (px(32, 20), 1024, 512, 1),
+                            (px(32, 20), 512, 256, 1), (px(32, 20), 1024, 255, 1), (px(32, 16), 512, 1024, 3)):
+        assert ops.b3_takes(M, cin, cout, k), (M, cin, cout, k)
+    # not: 1x1 layers below 128 outputs, channel counts that are no multiple of 16, and every layer of batch 1 at 512^2
+    for M, cin, cout, k in ((px(32, 160), 128, 64, 1), (px(32, 320), 64, 32, 1), (px(32, 40), 40, 240, 1), (px(1, 256), 32, 64, 3),
+                            (px(1, 128), 64, 128, 3), (px(1, 64), 128, 256, 3), (px(1, 64), 256, 128, 1)):
+        assert not ops.b3_takes(M, cin, cout, k), (M, cin, cout, k)
+    # the EfficientNet expand convs carry their own row limit: a lane of 8 images at 20^2 is in, a 10^2 map is not
+    assert ops.b3_takes(px(8, 20), 192, 1152, 1, ops.B3_EXPAND_MIN_ROWS) and not ops.b3_takes(px(8, 10), 192, 1152, 1, ops.B3_EXPAND_MIN_ROWS)
