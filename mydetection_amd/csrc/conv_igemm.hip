@@ -799,24 +799,41 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fixup_kernel(const ConvArgs
     const int fr = lane & 31, fh = lane >> 5;
     f32x16 acc[TM][TN];
     const f32x4 *src = reinterpret_cast<const f32x4 *>(p.ws) + (int64_t)blockIdx.x * p.splits * NV4 * NT + tid;
+    // slice by slice, in slice order, the next slice's NV4 16-byte loads in flight under the current slice's adds: a slice is
+    // NV4 * 4 registers whatever the tile, and every element is summed o[0] + o[1] + ... as before.  (All slices of a fragment
+    // requested at once -- 16 x 4 registers per fragment, unrolled over the fragments -- spilled: 1-3 KB of scratch per lane,
+    // and the 64-tile x 8-slice fixup of the 256->512 stride-2 layer took 89 us for 32 MB.)
+    f32x4 cur[NV4], nxt[NV4];
+#pragma unroll
+    for (int q = 0; q < NV4; ++q) cur[q] = src[(int64_t)q * NT];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                // all slices requested before the first add (splits <= 16: one round trip instead of one per slice),
-                // summed in slice order
-                f32x4 o[16];
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int sp = 0; sp < p.splits; ++sp) {
+        const bool more = sp + 1 < p.splits;          // uniform
+        if (more) {
 #pragma unroll
-                for (int sp = 0; sp < 16; ++sp)
-                    if (sp < p.splits) o[sp] = src[((int64_t)sp * NV4 + (i * TN + j) * 4 + v) * NT];
-                f32x4 t = o[0];
+            for (int q = 0; q < NV4; ++q) nxt[q] = src[((int64_t)(sp + 1) * NV4 + q) * NT];
+        }
 #pragma unroll
-                for (int sp = 1; sp < 16; ++sp)
-                    if (sp < p.splits) { t[0] += o[sp][0]; t[1] += o[sp][1]; t[2] += o[sp][2]; t[3] += o[sp][3]; }
-                acc[i][j][4 * v] = t[0]; acc[i][j][4 * v + 1] = t[1]; acc[i][j][4 * v + 2] = t[2]; acc[i][j][4 * v + 3] = t[3];
-            }
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float o = cur[(i * TN + j) * 4 + v][e];
+                        acc[i][j][4 * v + e] = sp == 0 ? o : acc[i][j][4 * v + e] + o;
+                    }
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < NV4; ++q) cur[q] = nxt[q];
+        }
+    }
     const int m_base = m0 + wm * TM * 32, n_base = n0 + wn * TN * 32;
     float pscl[TN], psft[TN];
 #pragma unroll

@@ -319,6 +319,26 @@ def test_no_store_data_hazard_in_the_shipped_library():
     assert hazards == 0
 
 
+def test_no_kernel_spills_beyond_a_few_registers():
+    """Scratch (private segment) use of every kernel in the shipped library, read from the code objects' metadata
+    (tools/check_store_hazard.py: scratch_users).  A spilled register set runs through memory on every use: round 5 found the
+    split-K fixup kernels at 1-3 KB per lane (an array the unroller kept whole), one of them taking 89 us for a 32 MB sum.
+    Allowed: the three 16-byte spills in the EPILOGUE of the F(4x4) GEMM kernel's residual variant (after the K loop; at the
+    256-register limit since round 2) and in the opt-in wide split-bf16 form's fixups -- nothing else, and nothing above 64 B."""
+    import importlib.util
+    import re
+    from mydetection_amd import _lib
+    if not os.path.exists('/opt/rocm/lib/llvm/bin/llvm-readelf'):
+        pytest.skip('no llvm-readelf on this machine')
+    spec = importlib.util.spec_from_file_location('check_store_hazard', os.path.join(ROOT, 'tools', 'check_store_hazard.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    users = mod.scratch_users(_lib.LIB_PATH)
+    allowed = re.compile(r'conv_wino4_kernelILi\dELb1ELb0E|conv_fixup_kernelILi128ELi256E')
+    for name, nbytes in users.items():
+        assert nbytes <= 64 and allowed.search(name), (name, nbytes)
+
+
 def test_pyramid_node_address_audit():
     """Host-side enumeration of every global address the fused pyramid-node kernel forms (csrc/sepconv.hip:
     sp_stage_halo / sp_read_m and the epilogue store) over the whole node table of EfficientDet-D1 and D1-FCOS2-ATSS at

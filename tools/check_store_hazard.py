@@ -21,7 +21,7 @@ STORE = re.compile(r'\bbuffer_store_dwordx[34]\s+v\[(\d+):(\d+)\],\s*(\S+),\s*s\
 VDST = re.compile(r'^\s*(v_\w+)\s+(v\[(\d+):(\d+)\]|v(\d+))')
 
 
-def code_objects(lib):
+def code_objects(lib, notes=False):
     """Disassembly text of every gfx950 code object bundled in `lib` (one bundle per translation unit)."""
     with tempfile.TemporaryDirectory() as tmp:
         fat = os.path.join(tmp, 'fat.bin')
@@ -36,7 +36,27 @@ def code_objects(lib):
                                 '--targets=hipv4-amdgcn-amd-amdhsa--gfx950', f'--output={co}'], capture_output=True)
             if r.returncode or not os.path.exists(co) or os.path.getsize(co) == 0:
                 continue
-            yield i, subprocess.run([f'{LLVM}/llvm-objdump', '-d', co], capture_output=True, text=True, check=True).stdout
+            if notes:
+                yield i, subprocess.run([f'{LLVM}/llvm-readelf', '--notes', co], capture_output=True, text=True, check=True).stdout
+            else:
+                yield i, subprocess.run([f'{LLVM}/llvm-objdump', '-d', co], capture_output=True, text=True, check=True).stdout
+
+
+def scratch_users(lib):
+    """{kernel name: bytes of scratch per lane} for every kernel of `lib` whose code object metadata asks for a private
+    segment (register spills or a dynamically indexed local array): such a kernel runs its spills through memory, and round 5
+    found a fixup kernel at 3 KB per lane (89 us for a 32 MB sum)."""
+    out = {}
+    for _, text in code_objects(lib, notes=True):
+        name = None
+        for line in text.splitlines():
+            m = re.match(r'\s*\.name:\s+(\S+)', line)
+            if m:
+                name = m.group(1)
+            m = re.match(r'\s*\.private_segment_fixed_size:\s+(\d+)', line)
+            if m and name and int(m.group(1)) > 0:
+                out[name] = int(m.group(1))
+    return out
 
 
 def instructions(text):
