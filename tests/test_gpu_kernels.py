@@ -705,7 +705,7 @@ def test_se_gate_inside_depthwise_launch(dev, kind, C, Cse, k, s, H, W):
     ops.dwconv / mbconv_expand_dw / stem_dw: every workgroup adds its share of W1 . sums, the last workgroup of an image
     finishes) == the gate of the separate launch (squeeze sums + mydet_se_gate_f32) to float32 round-off and == float64 of
     the launch's own output; the output map is bit-identical with and without the tail; three runs give the same bits (the
-    share buffer is back to its "empty" mark after every launch, the sums run in a fixed order); batch of 3."""
+    share hand-over leaves every image's launch counter one step further, the sums run in a fixed order); batch of 3."""
     from mydetection_amd import ops
     from mydetection_amd.external.efficientnet.model import static_same_pad
     g = torch.Generator().manual_seed(C * 7 + H)
