@@ -44,6 +44,8 @@ __global__ __launch_bounds__(256) void probe_compiled_kernel(const float *w, con
 
 template <int KIND>      // 0: v_mfma_f32_32x32x16_bf16, 1: v_mfma_f32_32x32x2_f32, 2: plain VALU fma
 __global__ __launch_bounds__(256) void busy_kernel(float *sink, int iters, float seed) {
+    extern __shared__ char busy_lds[];              // 72 KB requested at launch: two workgroups per CU, as the split-bf16 conv
+    if (iters < 0) busy_lds[threadIdx.x] = 1;
     f32x16 acc0, acc1;
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
     bf16x8 a, b;
@@ -70,7 +72,9 @@ __global__ __launch_bounds__(256) void busy_kernel(float *sink, int iters, float
 }
 
 int main() {
-    const int WGS = 512, K = 96, rounds = 200;
+    // ONE probe workgroup per CU (one probe wave per SIMD, as the finishing workgroup of the squeeze-excite tail), the busy kernel's
+    // workgroups (two per CU by their LDS request) beside it
+    const int WGS = 256, K = 96, rounds = 2000;
     const size_t nw = (size_t)K * WGS * 256 * 4;
     std::vector<float> hw(nw), hh(1024);
     srand(1);
@@ -80,6 +84,9 @@ int main() {
     CHECK(hipMalloc(&w, nw * 4)); CHECK(hipMalloc(&h, 1024 * 4)); CHECK(hipMalloc(&sink, 64));
     CHECK(hipMalloc(&out, (size_t)WGS * 256 * 16)); CHECK(hipMalloc(&out_ref, (size_t)WGS * 256 * 16));
     CHECK(hipMemcpy(w, hw.data(), nw * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(h, hh.data(), 1024 * 4, hipMemcpyHostToDevice));
+    CHECK(hipFuncSetAttribute((const void *)busy_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+    CHECK(hipFuncSetAttribute((const void *)busy_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+    CHECK(hipFuncSetAttribute((const void *)busy_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
     hipStream_t s1, s2;
     CHECK(hipStreamCreate(&s1)); CHECK(hipStreamCreate(&s2));
     // reference of the compiled form: alone on the chip
@@ -92,9 +99,9 @@ int main() {
         unsigned cmp_bad = 0;
         int cmp_lane[64] = {0};
         for (int rep = 0; rep < 20; ++rep) {
-            if (co == 1) hipLaunchKernelGGL(busy_kernel<0>, dim3(1024), dim3(256), 0, s2, sink, 60000, 0.3f);
-            if (co == 2) hipLaunchKernelGGL(busy_kernel<1>, dim3(1024), dim3(256), 0, s2, sink, 15000, 0.3f);
-            if (co == 3) hipLaunchKernelGGL(busy_kernel<2>, dim3(1024), dim3(256), 0, s2, sink, 200000, 0.3f);
+            if (co == 1) hipLaunchKernelGGL(busy_kernel<0>, dim3(1024), dim3(256), 72 * 1024, s2, sink, 60000, 0.3f);
+            if (co == 2) hipLaunchKernelGGL(busy_kernel<1>, dim3(1024), dim3(256), 72 * 1024, s2, sink, 15000, 0.3f);
+            if (co == 3) hipLaunchKernelGGL(busy_kernel<2>, dim3(1024), dim3(256), 72 * 1024, s2, sink, 200000, 0.3f);
             for (int i = 0; i < 4; ++i) hipLaunchKernelGGL(probe_compiled_kernel, dim3(WGS), dim3(256), 0, s1, w, h, rounds / 20, K, out);
             CHECK(hipDeviceSynchronize());
             CHECK(hipMemcpy(got.data(), out, got.size() * 4, hipMemcpyDeviceToHost));
