@@ -25,7 +25,7 @@ def case(B, Cin, Cout, k, s, H, check64=True, reps=0):
     w3 = ops.split_bf16(wd)
     args = (xd, wd, scale.to(dev), shift.to(dev), k, s, (p, p, p, p), ops.ACT_LEAKY)
     y32 = ops.conv2d(*args)
-    y3 = ops.conv2d(*args, b3=w3)
+    y3 = ops.conv2d(*args, b3=w3, b3_min_rows=1)
     torch.cuda.synchronize()
     d = (y3 - y32).abs().max().item()
     line = f'{B}x{Cin}->{Cout} k{k}s{s} {H}^2: |b3 - f32| {d:.2e} (max|y| {y32.abs().max().item():.2f})'
@@ -37,7 +37,7 @@ def case(B, Cin, Cout, k, s, H, check64=True, reps=0):
         line += f' | vs float64 / max|y|: b3 {e3:.2e}  f32 {e32:.2e}'
         assert e3 < 2e-5, line
     if reps:
-        for fn, tag in ((lambda: ops.conv2d(*args), 'f32'), (lambda: ops.conv2d(*args, b3=w3), 'b3')):
+        for fn, tag in ((lambda: ops.conv2d(*args), 'f32'), (lambda: ops.conv2d(*args, b3=w3, b3_min_rows=1), 'b3')):
             for _ in range(3):
                 fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
