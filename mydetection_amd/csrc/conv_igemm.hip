@@ -373,7 +373,12 @@ __device__ __forceinline__ void split3(const f32x4 v, bf16x4 &p0, bf16x4 &p1, bf
 template <int BM, int BN, int ACT, bool RES, bool SPLIT = false, int PF = B3_PF, int WN = 2>
 __global__ __launch_bounds__(128 * WN, 2) void conv_igemm_b3_kernel(const ConvArgs p) {
     constexpr int NT = 128 * WN, WM = 2, BK = 16;
-    constexpr int ROWB = 48;                         // bytes per LDS row of one plane
+    // LDS rows of one plane are the 32 bytes of a row's 16 k-values, unpadded; the two 16-byte halves of row r are swapped when
+    // bit 3 of r is set.  Fragment reads (lane = row, 16 bytes): 16 consecutive lanes cover all sixteen 16-byte slots of the 256-byte
+    // bank space; staging writes (four 8-byte or two 16-byte lanes per row): 8 consecutive rows are 256 contiguous bytes.
+    // (48-byte padded rows made the reads conflict-free and left the WRITES colliding: SQ_LDS_BANK_CONFLICT was a third of
+    // SQ_LDS_IDX_ACTIVE -- profiles/r05_pmc_sq_b3.txt; 24.6 instead of 36.9 KB per buffer also lets a third workgroup onto the CU.)
+    constexpr int ROWB = 32;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int AI = BM * 4 / NT;                  // 16-byte float4 chunks of A per thread and slab (4 per row)
     constexpr int BCH = BN * 2;                      // 16-byte bf16x8 chunks of one B plane per slab (2 per row)
@@ -468,14 +473,14 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm_b3_kernel(const ConvAr
         for (int i = 0; i < AI; ++i) {
             bf16x4 q0, q1, q2;
             split3(ar[i], q0, q1, q2);
-            char *d = a + (sr + RP * i) * ROWB + sc * 8;
+            char *d = a + (sr + RP * i) * ROWB + (((sc >> 1) ^ ((sr >> 3) & 1)) * 16) + (sc & 1) * 8;      // (RP % 16 == 0)
             *reinterpret_cast<bf16x4 *>(d) = q0;
             *reinterpret_cast<bf16x4 *>(d + PLANE_A) = q1;
             *reinterpret_cast<bf16x4 *>(d + 2 * PLANE_A) = q2;
         }
         if (bact) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4 *>(b + pl * PLANE_B + br * ROWB + bh * 16) = brg[pl];
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4 *>(b + pl * PLANE_B + br * ROWB + ((bh ^ ((br >> 3) & 1)) * 16)) = brg[pl];
         }
     };
 
@@ -490,8 +495,9 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm_b3_kernel(const ConvAr
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int a_off = (wm * TM * 32 + fr) * ROWB + fh * 16;
-    const int b_off = 3 * PLANE_A + (wn * TN * 32 + fr) * ROWB + fh * 16;
+    const int fsw = (fh ^ ((fr >> 3) & 1)) * 16;           // (block rows start at multiples of 32: bit 3 of the row is bit 3 of fr)
+    const int a_off = (wm * TM * 32 + fr) * ROWB + fsw;
+    const int b_off = 3 * PLANE_A + (wn * TN * 32 + fr) * ROWB + fsw;
     float pscl[TN], psft[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -961,7 +967,7 @@ int launch(const ConvArgs &a0, int slots, hipStream_t stream) {
 template <int BM, int BN, int ACT, bool RES, bool SPLIT, int PF = B3_PF, int WN = 2>
 int launch_b3_inst(const ConvArgs &a, hipStream_t stream) {
     auto kern = &conv_igemm_b3_kernel<BM, BN, ACT, RES, SPLIT, PF, WN>;
-    constexpr int lds = 2 * 3 * (BM + BN) * 48;
+    constexpr int lds = 2 * 3 * (BM + BN) * 32;
     static unsigned long long attr_set = 0;
     if (const int e = mydet_lds_opt_in(attr_set, kern, lds)) return e;
     hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(128 * WN), lds, stream, a);
