@@ -761,6 +761,13 @@ def test_se_gate_inside_depthwise_launch(dev, kind, C, Cse, k, s, H, W):
     shares = ops.se_shares(dev, 1).view(torch.int32)
     epochs = shares[:_lib.SE_EPOCH_WORDS]
     assert bool((epochs[:B] == epochs[0]).all()) and int(epochs[0]) > 1 and bool((epochs[B:] == 1).all())     # one step per launch and image
+    # the launch counters wrap past 2^32 - 1 to 1 (0 is the tag of a fresh buffer): same gate before, across and after the wrap
+    before = int(epochs[0])
+    epochs[:B] = -2                                          # 0xFFFFFFFE
+    for want in (-1, 1, 2):
+        _, gate3 = run((w1, b1, w2t, b2))
+        assert torch.equal(gate3, gate1) and bool((epochs[:B] == want).all()), want
+    epochs[:B] = before + 3
 
 
 @pytest.mark.parametrize('Cin,Cout,H,W,gated,res,act', [
