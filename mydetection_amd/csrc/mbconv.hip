@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void dwconv_sum_kernel(const DwArgs p) {
             __syncthreads();
         }
     }
-    if (se_on) se_tail_finish(p.se, selds, p.C, p.Ho * p.Wo, b, s, p.S, se_ep);
+    if (se_on) se_tail_finish(p.se, selds, p.C, p.Ho * p.Wo, b, s, p.S, (int)gridDim.y, se_ep);
 }
 
 
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256, 4) void dwconv_tile_kernel(const DwTArgs p) {
             __syncthreads();
             se_fc1_accumulate(p.se, p.C, tots, q0 * 4, min(CQ * 4, p.C - q0 * 4), selds);
             __syncthreads();
-            se_tail_finish(p.se, selds, p.C, p.Ho * p.Wo, b, r * p.nchunks + chunk, p.S * p.nchunks, se_ep);
+            se_tail_finish(p.se, selds, p.C, p.Ho * p.Wo, b, r * p.nchunks + chunk, p.S * p.nchunks, (int)gridDim.x / (p.S * p.nchunks), se_ep);
         }
     }
 }

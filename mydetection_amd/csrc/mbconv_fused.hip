@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void mbconv_expand_dw_kernel(const MbArgs p
         __syncthreads();
         se_fc1_accumulate(p.se, p.Cexp, tots, 0, p.Cexp, selds);
         __syncthreads();
-        se_tail_finish(p.se, selds, p.Cexp, p.Ho * p.Wo, b, r, p.tiles_per_img, se_ep);
+        se_tail_finish(p.se, selds, p.Cexp, p.Ho * p.Wo, b, r, p.tiles_per_img, (int)gridDim.x / p.tiles_per_img, se_ep);
     }
 }
 

@@ -12,11 +12,13 @@
 //     channels.  Nobody else waits for anything: a share is Cse fire-and-forget stores.
 // Stores / loads that cross workgroups carry the sc1 (device) scope, so no L2 write-back or invalidate is needed -- the idiom
 // the split-K experiment of round 4 proved bit-exact (profiles/r04_tried/igemm_inkernel_split_sum.diff.txt).
-// How the finishing workgroup knows a share is THIS launch's: every image slot of the buffer has a launch counter (its
-// "epoch"); a workgroup reads its image's counter when it starts and publishes every share value as an 8-byte (value, epoch)
-// pair in ONE store; the finishing workgroup accepts pairs of its epoch only and, when it is done, advances the counter.
-// Every word of the buffer has exactly ONE writer per launch (the pair: its workgroup; the counter: the image's finishing
-// workgroup), so nothing depends on the order in which two stores of one launch reach memory.
+// How the finishing workgroup knows a share is THIS launch's: the buffer has ONE launch counter (its "epoch"); a workgroup reads it
+// when it starts and publishes every share value as an 8-byte (value, epoch) pair in ONE store; the finishing workgroup of an image
+// accepts pairs of its epoch only; the LAST finishing workgroup of the launch (an atomic count of the finished images) advances the
+// counter -- after every share of the launch has been published, i.e. after every workgroup of the launch has read it.  Share words
+// have exactly one writer per launch, and a stale pair anywhere in the buffer, whatever layer, batch size or image wrote it, carries
+// an older epoch.  (A counter per image slot was the first form: slots that different batch sizes had advanced differently let a
+// stale pair of another slot carry the current epoch of this one -- a one-in-hundreds flake of the full test suite.)
 // (Two earlier forms.  An arrival counter -- every workgroup waits for its stores, then for its atomic -- doubled the
 // depthwise kernels' time: two dependent device-scope round trips at the end of thousands of 8 us workgroups.  An "empty" mark
 // that the finishing workgroup put back into every share word after reading it: correct in every single-stream run, and WRONG
@@ -60,24 +62,28 @@ __device__ __forceinline__ void se_fc1_accumulate(const SeTail &t, int C, const 
 }
 
 // The share buffer (include/mydet.h: mydet_se_tail.hpart), 8-byte aligned, 32-bit words:
-//     [0, MYDET_SE_EPOCH_WORDS)   launch counter of image slot b (never 0; 1 when the buffer is made)
+//     [0]                         the launch counter (never 0; 1 when the buffer is made)
+//     [1]                         images finished in the running launch (0 between launches)
+//     [2, MYDET_SE_EPOCH_WORDS)   unused
 //     then [B][nwg][Cse] pairs    (value, epoch) of workgroup wg's share of hidden unit o; all zero when the buffer is made
 constexpr int MYDET_SE_EPOCHS = MYDET_SE_EPOCH_WORDS;
 
-// the epoch of image b's slot, requested when the workgroup starts (the value is needed only when its share leaves)
+// the launch's epoch, requested when the workgroup starts (the value is needed only when its share leaves)
 __device__ __forceinline__ unsigned se_epoch(const SeTail &t, int b) {
-    return __hip_atomic_load(reinterpret_cast<const unsigned *>(t.hpart) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    (void)b;
+    return __hip_atomic_load(reinterpret_cast<const unsigned *>(t.hpart), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Called by ALL 256 threads of every workgroup of image b once its h_acc is complete (and a barrier has made it visible).
-// wg = this workgroup's index among the nwg workgroups of its image, epoch = se_epoch(t, b) read by this workgroup.
+// wg = this workgroup's index among the nwg workgroups of its image, nimg = images of the launch, epoch = se_epoch(t, b) read by
+// this workgroup.
 //   * every workgroup but the last of its image: Cse device-scope 8-byte stores, fire and forget -- no wait, no atomic, no fence;
 //   * the last workgroup (wg == nwg - 1; within an XCD block ids are dispatched in order, so most of the image's other
 //     workgroups are running or done when it starts -- a matter of waiting time only): reads all pairs at device scope until
 //     every one carries its epoch (a bounded poll), sums the values in workgroup order (deterministic), finishes the gate and
-//     advances the image's counter.  If the poll gives up (it never should) the gate is NaN, so the failure cannot pass for
+//     counts its image as finished; the last image of the launch advances the counter.  If the poll gives up (it never should) the gate is NaN, so the failure cannot pass for
 //     a result.
-__device__ __forceinline__ void se_tail_finish(const SeTail &t, float *lds, int C, int HW, int b, int wg, int nwg, unsigned epoch) {
+__device__ __forceinline__ void se_tail_finish(const SeTail &t, float *lds, int C, int HW, int b, int wg, int nwg, int nimg, unsigned epoch) {
     const int tid = threadIdx.x, Cse = t.Cse;
     unsigned long long *hp = reinterpret_cast<unsigned long long *>(t.hpart + MYDET_SE_EPOCHS) + (int64_t)b * nwg * Cse;
     if (tid < Cse)
@@ -115,9 +121,12 @@ __device__ __forceinline__ void se_tail_finish(const SeTail &t, float *lds, int 
         if (++spins >= (1 << 14)) { ok = false; break; }        // (uniform: every thread sees the same vote and count)
         __builtin_amdgcn_s_sleep(2);
     }
-    if (tid == 0) {                                            // the next launch on this image slot gets a new epoch (never 0)
-        const unsigned next = epoch + 1u ? epoch + 1u : 1u;
-        __hip_atomic_store(reinterpret_cast<unsigned *>(t.hpart) + b, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {      // this image is finished; the last one of the launch hands the next launch a new epoch (never 0)
+        unsigned *hdr = reinterpret_cast<unsigned *>(t.hpart);
+        if (__hip_atomic_fetch_add(hdr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nimg - 1u) {
+            __hip_atomic_store(hdr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(hdr, epoch + 1u ? epoch + 1u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     if (ph < P) phase[ph * Cse + o] = sum;
     __syncthreads();
@@ -161,7 +170,7 @@ __device__ __forceinline__ void se_tail_finish(const SeTail &t, float *lds, int 
 // host side: arguments of an in-launch tail are complete and inside the kernels' limits
 static inline int mydet_se_tail_check(const SeTail &t, int C, int B) {
     if (!t.gate) return 0;
-    if (B > MYDET_SE_EPOCH_WORDS) return MYDET_E_UNSUPP;
+    (void)B;
     if (!t.w1 || !t.b1 || !t.w2t || !t.b2 || !t.hpart) return MYDET_E_BADARG;
     if (((uintptr_t)t.w1 & 15) || ((uintptr_t)t.w2t & 15) || ((uintptr_t)t.b2 & 15) || ((uintptr_t)t.gate & 15) || (C & 3)) return MYDET_E_BADARG;
     if ((uintptr_t)t.hpart & 7) return MYDET_E_BADARG;

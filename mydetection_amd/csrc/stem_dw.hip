@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void stem_dw_kernel(const SdArgs p) {
         __syncthreads();
         se_fc1_accumulate(p.se, SD_C, tots, 0, SD_C, selds);
         __syncthreads();
-        se_tail_finish(p.se, selds, SD_C, p.Hs * p.Ws, b, r, p.tiles_per_img, se_ep);
+        se_tail_finish(p.se, selds, SD_C, p.Hs * p.Ws, b, r, p.tiles_per_img, (int)gridDim.x / p.tiles_per_img, se_ep);
     }
 }
 

@@ -171,8 +171,8 @@ SE_IN_DW_MIN_C = int(os.environ.get('MYDET_SE_IN_DW_MIN_C', '1000'))
 
 
 def se_shares(device, n_pairs):
-    """Per-device, per-lane share buffer of the in-launch squeeze-excite tail (include/mydet.h: mydet_se_tail.hpart): launch
-    counters (1) followed by room for `n_pairs` (value, epoch) pairs (0).  The kernels' own protocol keeps it consistent, so
+    """Per-device, per-lane share buffer of the in-launch squeeze-excite tail (include/mydet.h: mydet_se_tail.hpart): a header
+    (launch counter = 1, finished-image count = 0) followed by room for `n_pairs` (value, epoch) pairs (0).  The kernels' own protocol keeps it consistent, so
     ONE buffer serves every layer of a lane's stream.  Grows to the largest layer seen (not during a stream capture)."""
     key = (device.type, device.index, _LANE)
     buf = _SE_SHARES.get(key)
@@ -181,7 +181,7 @@ def se_shares(device, n_pairs):
         if device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
             raise RuntimeError('se_shares: the share buffer would grow during stream capture; run the model once eagerly first')
         buf = torch.zeros(max(need, 1 << 21), dtype=torch.int32, device=device)
-        buf[:_lib.SE_EPOCH_WORDS] = 1
+        buf[0] = 1                                           # the launch counter; word 1 = images finished in a running launch
         _SE_SHARES[key] = buf = buf.view(torch.float32)
     return buf
 
@@ -193,7 +193,7 @@ def _se_tail(se, B, C, groups, device):
     w1, b1, w2t, b2 = se
     Cse = w1.shape[0]
     assert tuple(w1.shape) == (Cse, C) and tuple(w2t.shape) == (Cse, C) and w1.is_contiguous() and w2t.is_contiguous()
-    assert Cse <= SE_MAX_CSE and groups > 0 and B <= _lib.SE_EPOCH_WORDS
+    assert Cse <= SE_MAX_CSE and groups > 0
     gate = torch.empty((B, C), dtype=torch.float32, device=device)
     hpart = se_shares(device, B * groups * Cse)
     t = _lib.SeTail(w1.data_ptr(), b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), gate.data_ptr(), hpart.data_ptr(), Cse)

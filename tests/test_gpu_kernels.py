@@ -758,16 +758,21 @@ def test_se_gate_inside_depthwise_launch(dev, kind, C, Cse, k, s, H, W):
         y2, gate2 = run((w1, b1, w2t, b2))
         assert torch.equal(gate2, gate1) and torch.equal(y2.contiguous(), y0.contiguous())
     from mydetection_amd import _lib
-    shares = ops.se_shares(dev, 1).view(torch.int32)
-    epochs = shares[:_lib.SE_EPOCH_WORDS]
-    assert bool((epochs[:B] == epochs[0]).all()) and int(epochs[0]) > 1 and bool((epochs[B:] == 1).all())     # one step per launch and image
-    # the launch counters wrap past 2^32 - 1 to 1 (0 is the tag of a fresh buffer): same gate before, across and after the wrap
-    before = int(epochs[0])
-    epochs[:B] = -2                                          # 0xFFFFFFFE
+    hdr = ops.se_shares(dev, 1).view(torch.int32)[:_lib.SE_EPOCH_WORDS]
+    assert int(hdr[0]) > 1 and int(hdr[1]) == 0 and not bool(hdr[2:].any())      # one step of the launch counter per launch
+    # the launch counter wraps past 2^32 - 1 to 1 (0 is the tag of a fresh buffer): same gate before, across and after the wrap
+    before = int(hdr[0])
+    hdr[0] = -2                                              # 0xFFFFFFFE
     for want in (-1, 1, 2):
         _, gate3 = run((w1, b1, w2t, b2))
-        assert torch.equal(gate3, gate1) and bool((epochs[:B] == want).all()), want
-    epochs[:B] = before + 3
+        assert torch.equal(gate3, gate1) and int(hdr[0]) == want and int(hdr[1]) == 0, want
+    hdr[0] = before + 3
+    # a launch with another batch size in between (the epoch is the buffer's, not an image slot's)
+    if kind == 'dw':
+        y4, gate4 = ops.dwconv(x[:2], wd, sc, sh, k, s, pad, ops.ACT_SWISH, se=(w1, b1, w2t, b2))
+        assert torch.equal(gate4, gate1[:2]) and int(hdr[0]) == before + 4
+        _, gate5 = run((w1, b1, w2t, b2))
+        assert torch.equal(gate5, gate1)
 
 
 @pytest.mark.parametrize('Cin,Cout,H,W,gated,res,act', [
