@@ -599,7 +599,8 @@ extern "C" int mydet_sepconv_nodes_f32(int n, const mydet_sepconv_node *nodes, i
         // (to one workgroup per CU, not three -- round 4: with two batch lanes in flight the other lane fills the chip, and every
         // extra slice repeats the node's depthwise phase: D1 +1.2 %, D1-FCOS2-ATSS +1.9 %)
         if (base_tiles < mydet_cu_count()) split = (int)((mydet_cu_count() + base_tiles - 1) / base_tiles);
-        if (const char *e = getenv("MYDET_SEPCONV_SPLIT")) split = atoi(e) > split ? atoi(e) : split;     // tuning knob
+        static const int forced_split = [] { const char *e = getenv("MYDET_SEPCONV_SPLIT"); return e ? atoi(e) : 0; }();     // tuning knob, read once
+        if (forced_split > split) split = forced_split;
         if (split > pairs) split = pairs;
         p.nb_per = 2 * ((pairs + split - 1) / split);
         p.nsplit = (p.nb + p.nb_per - 1) / p.nb_per;
