@@ -301,7 +301,8 @@ extern "C" int mydet_decode_levels_f32(int mode, int nlevels, const mydet_decode
                (p.same || (size_t)pix * p.qb <= MAXV_B * 256);
     };
     p.PIX = 32;
-    if (const char *e = getenv("MYDET_DECODE_PIX")) p.PIX = atoi(e);      // tuning knob
+    static const int forced_pix = [] { const char *e = getenv("MYDET_DECODE_PIX"); return e ? atoi(e) : 0; }();      // tuning knob, read once
+    if (forced_pix > 0) p.PIX = forced_pix;
     while (p.PIX > 1 && !fits(p.PIX)) p.PIX >>= 1;
     if (!fits(p.PIX)) return MYDET_E_UNSUPP;
     if (!getenv("MYDET_DECODE_PIX"))
