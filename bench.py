@@ -76,6 +76,7 @@ def parse_args(argv=None):
     ap.add_argument('--dry-run-launch', action='store_true', help='with --gpus N > 1: print the launcher command as JSON and exit')
     ap.add_argument('--no-other-configs', action='store_true',
                     help='headline run only: skip the short runs of the other single-GPU BASELINE configs (`other_configs`)')
+    ap.add_argument('--no-power-probe', action='store_true', help='skip the 1.5 s of extra replays under rocm-smi sampling (board power, shader clock)')
     ap.add_argument('--lanes', default=None,
                     help="batch lanes of the replayed graph: a number, 'auto' (capture with 1 and 2, keep the faster: rank 0 decides "
                          "for all ranks), default: MYDET_LANES or the model's batch_lanes_hint -- the rule api.Detector uses")
@@ -340,7 +341,7 @@ def main():
             a = argparse.Namespace(**vars(args))
             a.config, a.batch, a.size = name, bsz, size
             a.steps, a.warmup = min(args.steps, 10), min(args.warmup, 3)
-            a.no_cpu_baseline, a.parity_images, a.lanes = True, 2, None
+            a.no_cpu_baseline, a.parity_images, a.lanes, a.no_power_probe = True, 2, None, True
             t0 = time.perf_counter()
             o, c = measure(a, ctx)
             code = code or c
@@ -351,7 +352,7 @@ def main():
         from mydetection_amd import ops
         if ops.SPLIT_BF16:
             a = argparse.Namespace(**vars(args))
-            a.steps, a.warmup, a.no_cpu_baseline, a.parity_images = min(args.steps, 10), min(args.warmup, 3), True, 2
+            a.steps, a.warmup, a.no_cpu_baseline, a.parity_images, a.no_power_probe = min(args.steps, 10), min(args.warmup, 3), True, 2, True
             t0 = time.perf_counter()
             ops.SPLIT_BF16 = False
             try:
@@ -386,6 +387,49 @@ def brief_line(o, wall_s):
             'launches_per_lane': o['launches_per_lane'], 'workload': o['config']['workload'], 'nms_p50_ms': o['nms_p50_ms'],
             'roofline': {k: o['roofline'][k] for k in keep if k in o['roofline']},
             'parity_check': o['parity_check'], 'wall_s': round(wall_s, 1)}
+
+
+def power_probe(step, seconds=1.5):
+    """Board power and shader clock (rocm-smi, a child process, sampled while `step` keeps replaying for `seconds`) -- or None when
+    rocm-smi is not there.  Not part of the timed region.  The headline step runs at the board's power cap: its
+    time is its energy over the cap, which this pair of numbers shows next to the measurement."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+    import torch
+    if shutil.which('rocm-smi') is None:
+        return None
+    samples, stop = [], []
+
+    def sampler():
+        while not stop:
+            try:
+                txt = subprocess.run(['rocm-smi', '--showpower', '--showclocks', '--showmaxpower'], capture_output=True, text=True, timeout=10).stdout
+            except Exception:
+                return
+            pw = re.search(r'Package Power \(W\): ([\d.]+)', txt)
+            ck = re.search(r'sclk clock level: \d+: \((\d+)Mhz\)', txt)
+            cap = re.search(r'Max Graphics Package Power \(W\): ([\d.]+)', txt)
+            if pw and ck:
+                samples.append((float(pw.group(1)), int(ck.group(1)), float(cap.group(1)) if cap else None))
+    th = threading.Thread(target=sampler, daemon=True)
+    t_end = time.perf_counter() + seconds
+    th.start()
+    n = 0
+    while time.perf_counter() < t_end:
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        n += 5
+    stop.append(1)
+    th.join(15)
+    samples = samples[1:] if len(samples) > 2 else samples          # the first sample may predate the load
+    if not samples:
+        return None
+    return {'board_w': round(sum(a for a, _, _ in samples) / len(samples), 1), 'cap_w': samples[-1][2],
+            'sclk_mhz': round(sum(b for _, b, _ in samples) / len(samples)), 'samples': len(samples), 'steps_replayed': n,
+            'note': 'rocm-smi while the step keeps replaying after the timed region; board power at its cap = the step time is its energy / cap'}
 
 
 def measure(args, ctx):
@@ -486,6 +530,9 @@ def measure(args, ctx):
     barrier()
     elapsed = time.perf_counter() - t0
     timer, ops.TIMER = ops.TIMER, None
+    power = None
+    if rank == 0 and world == 1 and not dist_on and not args.profile and not getattr(args, 'no_power_probe', False):
+        power = power_probe(step)
 
     # launches of the step's kernels over the whole process: GraphedPath runs two eager warm-up passes before a capture
     passes = (None if lanes_rule and lanes_rule.startswith('auto') else
@@ -703,6 +750,7 @@ def measure(args, ctx):
         'roofline': roofline,
         'stages': stages,
         'nms_p50_ms': stages['postprocess']['p50_ms'],
+        'power': power,
     }
     n_lanes = graphed.lanes if graphed is not None else 1
     out['launches_per_lane'] = round(sum(v[0] for v in summ.values()) / args.steps / n_lanes, 1)
