@@ -154,7 +154,13 @@ __device__ __forceinline__ void se_tail_finish(const SeTail &t, float *lds, int 
 #pragma unroll
             for (int j = 0; j < 8; ++j)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) asm("v_fma_f32 %0, %1, %2, %0" : "+v"(e[c]) : "v"(w[j][c]), "v"(hid[k + j]));
+                for (int c = 0; c < 4; ++c) {
+#ifdef MYDET_SE_PK       // diagnostic build only (tools/r05_pk_repro.py): the compiler's own form of this loop (v_pk_fma_f32)
+                    e[c] = fmaf(w[j][c], hid[k + j], e[c]);
+#else
+                    asm("v_fma_f32 %0, %1, %2, %0" : "+v"(e[c]) : "v"(w[j][c]), "v"(hid[k + j]));
+#endif
+                }
         }
         for (; k < Cse; ++k) {
             const f32x4 w = *reinterpret_cast<const f32x4 *>(t.w2t + (int64_t)k * C + q * 4);

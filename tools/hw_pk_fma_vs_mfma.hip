@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void probe_compiled_kernel(const float *w, con
     *reinterpret_cast<f32x4 *>(out + (size_t)q * 4) = e;
 }
 
-template <int KIND>      // 0: v_mfma_f32_32x32x16_bf16, 1: v_mfma_f32_32x32x2_f32, 2: plain VALU fma
+template <int KIND>      // 0: v_mfma_f32_32x32x16_bf16, 1: v_mfma_f32_32x32x2_f32, 2: plain VALU fma, 3: SIX independent v_mfma_f32_16x16x32_bf16
 __global__ __launch_bounds__(256) void busy_kernel(float *sink, int iters, float seed) {
     extern __shared__ char busy_lds[];              // 72 KB requested at launch: two workgroups per CU, as the split-bf16 conv
     if (iters < 0) busy_lds[threadIdx.x] = 1;
@@ -52,8 +52,13 @@ __global__ __launch_bounds__(256) void busy_kernel(float *sink, int iters, float
     for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(seed + 0.001f * (threadIdx.x + i)); b[i] = (__bf16)(0.5f - 0.002f * (threadIdx.x * 3 + i)); }
     float fa = seed + 0.001f * threadIdx.x, fb = 0.5f - 0.002f * threadIdx.x;
     float v0 = fa, v1 = fb, v2 = fa * 0.5f, v3 = fb * 0.25f;
+    f32x4 a4[6];
+    for (int q = 0; q < 6; ++q) a4[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int it = 0; it < iters; ++it) {
-        if (KIND == 0) {
+        if (KIND == 3) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) a4[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, a4[q], 0, 0, 0);
+        } else if (KIND == 0) {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc1, 0, 0, 0);
         } else if (KIND == 1) {
@@ -67,6 +72,7 @@ __global__ __launch_bounds__(256) void busy_kernel(float *sink, int iters, float
         }
     }
     float s = v0 + v1 + v2 + v3;
+    for (int q = 0; q < 6; ++q) s += a4[q][0] + a4[q][1] + a4[q][2] + a4[q][3];
     for (int i = 0; i < 16; ++i) s += acc0[i] + acc1[i];
     if (s == 12345.678f) sink[0] = s;
 }
@@ -87,6 +93,7 @@ int main() {
     CHECK(hipFuncSetAttribute((const void *)busy_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
     CHECK(hipFuncSetAttribute((const void *)busy_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
     CHECK(hipFuncSetAttribute((const void *)busy_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+    CHECK(hipFuncSetAttribute((const void *)busy_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
     hipStream_t s1, s2;
     CHECK(hipStreamCreate(&s1)); CHECK(hipStreamCreate(&s2));
     // reference of the compiled form: alone on the chip
@@ -94,14 +101,16 @@ int main() {
     CHECK(hipDeviceSynchronize());
     std::vector<float> ref((size_t)WGS * 256 * 4), got(ref.size());
     CHECK(hipMemcpy(ref.data(), out_ref, ref.size() * 4, hipMemcpyDeviceToHost));
-    const char *names[] = {"nothing else running", "v_mfma_f32_32x32x16_bf16 on the other stream", "v_mfma_f32_32x32x2_f32 on the other stream", "v_fma_f32 on the other stream"};
-    for (int co = 0; co < 4; ++co) {
+    const char *names[] = {"nothing else running", "v_mfma_f32_32x32x16_bf16 on the other stream", "v_mfma_f32_32x32x2_f32 on the other stream", "v_fma_f32 on the other stream",
+                           "SIX independent v_mfma_f32_16x16x32_bf16 on the other stream"};
+    for (int co = 0; co < 5; ++co) {
         unsigned cmp_bad = 0;
         int cmp_lane[64] = {0};
         for (int rep = 0; rep < 20; ++rep) {
             if (co == 1) hipLaunchKernelGGL(busy_kernel<0>, dim3(1024), dim3(256), 72 * 1024, s2, sink, 60000, 0.3f);
             if (co == 2) hipLaunchKernelGGL(busy_kernel<1>, dim3(1024), dim3(256), 72 * 1024, s2, sink, 15000, 0.3f);
             if (co == 3) hipLaunchKernelGGL(busy_kernel<2>, dim3(1024), dim3(256), 72 * 1024, s2, sink, 200000, 0.3f);
+            if (co == 4) hipLaunchKernelGGL(busy_kernel<3>, dim3(1024), dim3(256), 48 * 1024, s2, sink, 40000, 0.3f);
             for (int i = 0; i < 4; ++i) hipLaunchKernelGGL(probe_compiled_kernel, dim3(WGS), dim3(256), 0, s1, w, h, rounds / 20, K, out);
             CHECK(hipDeviceSynchronize());
             CHECK(hipMemcpy(got.data(), out, got.size() * 4, hipMemcpyDeviceToHost));
