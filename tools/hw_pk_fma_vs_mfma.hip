@@ -5,7 +5,8 @@
 //   hipcc --offload-arch=gfx950 -O2 -o hw_pk_fma_vs_mfma tools/hw_pk_fma_vs_mfma.hip && ./hw_pk_fma_vs_mfma
 // Prints, per co-running kernel (none / bf16 MFMA / fp32 MFMA / plain VALU), how many results of the probe loop (fmaf on float4,
 // which hipcc turns into v_pk_fma_f32 -- check with --save-temps) differ from the same loop run alone on the chip.
-// Result on MI355X (round 5): 0 in every case -- the stand-alone probe does NOT reproduce what the model showed.
+// Result on MI355X (round 5): 0 in every case, also with -DPROBE_FAT (a 174-VGPR victim) and with the aggressor that breaks the real
+// kernel outside the model (six independent v_mfma_f32_16x16x32_bf16: tools/r05_pk_repro.py) -- the stand-alone victim does NOT reproduce it.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -26,6 +27,13 @@ __global__ __launch_bounds__(256) void probe_compiled_kernel(const float *w, con
     __syncthreads();
     const int q = blockIdx.x * 256 + threadIdx.x;
     f32x4 e = {0.f, 0.f, 0.f, 0.f};
+#ifdef PROBE_FAT          // ~170 VGPRs like the finishing workgroup of the squeeze-excite tail: 30 float4 kept live across the loop
+    f32x4 fat[30];
+#pragma unroll
+    for (int i = 0; i < 30; ++i) fat[i] = *reinterpret_cast<const f32x4 *>(w + ((size_t)i * gridDim.x * 256 + q) * 4);
+#pragma unroll
+    for (int i = 0; i < 30; ++i) asm volatile("" : "+v"(fat[i]));
+#endif
     for (int r = 0; r < rounds; ++r) {
         e = f32x4{0.25f, -0.5f, 0.125f, 0.75f};
         for (int k = 0; k < K; k += 8) {
@@ -39,6 +47,14 @@ __global__ __launch_bounds__(256) void probe_compiled_kernel(const float *w, con
         }
         asm volatile("" : "+v"(e));
     }
+#ifdef PROBE_FAT
+#pragma unroll
+    for (int i = 0; i < 30; ++i) asm volatile("" : "+v"(fat[i]));
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 30; ++i) acc += fat[i];
+    if (acc[0] == 12345.678f) e[0] += acc[1];
+#endif
     *reinterpret_cast<f32x4 *>(out + (size_t)q * 4) = e;
 }
 
