@@ -370,7 +370,8 @@ __device__ __forceinline__ void split3(const f32x4 v, bf16x4 &p0, bf16x4 &p1, bf
 #ifndef B3_PF
 #define B3_PF 2          // slabs prefetched into registers beyond the one staged (2, 3, 4, 6 measured equal: profiles/HISTORY.md)
 #endif
-template <int BM, int BN, int ACT, bool RES, bool SPLIT = false, int PF = B3_PF, int WN = 2>
+// GATE (1x1 layers): the A operand is x * gate[image][channel] (squeeze-excite, as conv_igemm_kernel's GATE), applied before the split
+template <int BM, int BN, int ACT, bool RES, bool SPLIT = false, int PF = B3_PF, int WN = 2, bool GATE = false>
 __global__ __launch_bounds__(128 * WN, 2) void conv_igemm_b3_kernel(const ConvArgs p) {
     constexpr int NT = 128 * WN, WM = 2, BK = 16;
     // LDS rows of one plane are the 32 bytes of a row's 16 k-values, unpadded; the two 16-byte halves of row r are swapped when
@@ -402,11 +403,14 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm_b3_kernel(const ConvAr
     const int ntaps = p.KH * p.KW;
     int aoff[AI];
     unsigned amask[AI];
+    unsigned goff[AI];                               // GATE: byte offset of the row's image (+ this thread's channel quad) in gate[B][Cin]
+    const __amdgpu_buffer_rsrc_t gr = make_rsrc(GATE ? p.gate : p.x, (int64_t)p.B * p.Cin * 4);
     const bool flat = ntaps == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 && p.Ho == p.H && p.Wo == p.W;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
         const int m = m0 + sr + RP * i;
         const int mm = m < p.M ? m : p.M - 1;
+        goff[i] = GATE ? (unsigned)((mm / hwo) * p.Cin + sc * 4) * 4u : 0u;
         if (flat) {
             aoff[i] = (int)(((int64_t)(mm - b0 * hwo) * p.ldx + sc * 4) * 4);
             amask[i] = m < p.M ? 1u : 0u;
@@ -457,6 +461,11 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm_b3_kernel(const ConvAr
             if (p.C1 & 1) ok = false;
 #endif
             ar[i] = buf_load16(xr, ok ? (unsigned)aoff[i] + uoff : OOB);
+            if (GATE) {                               // (1x1: one tap, c0 is the slab's first channel)
+                const f32x4 gv = buf_load16(gr, ok ? goff[i] + (unsigned)c0 * 4u : OOB);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ar[i][e] *= gv[e];
+            }
         }
         c0 += BK;
         if (c0 == p.Cin) {                            // uniform: next tap
@@ -989,9 +998,9 @@ int launch(const ConvArgs &a0, int slots, hipStream_t stream) {
 }
 
 // ---- split-bf16 launches (conv_igemm_b3_kernel): the same round / split-K-tail rule as `launch`, two workgroups per CU
-template <int BM, int BN, int ACT, bool RES, bool SPLIT, int PF = B3_PF, int WN = 2>
+template <int BM, int BN, int ACT, bool RES, bool SPLIT, int PF = B3_PF, int WN = 2, bool GATE = false>
 int launch_b3_inst(const ConvArgs &a, hipStream_t stream) {
-    auto kern = &conv_igemm_b3_kernel<BM, BN, ACT, RES, SPLIT, PF, WN>;
+    auto kern = &conv_igemm_b3_kernel<BM, BN, ACT, RES, SPLIT, PF, WN, GATE>;
     constexpr int lds = 2 * 3 * (BM + BN) * 32;
     static unsigned long long attr_set = 0;
     if (const int e = mydet_lds_opt_in(attr_set, kern, lds)) return e;
@@ -1020,6 +1029,17 @@ int launch_b3(const ConvArgs &a0, hipStream_t stream) {
     a.nblk = split ? total - rem : total;
     const bool res = a.res != nullptr;
     int rc = 0;
+    if (a.gate) {           // squeeze-excite project convs: no activation (MYDET_E_UNSUPP otherwise: the caller's float32 kernel takes it)
+        if (a.act != MYDET_ACT_NONE || WN != 2) return MYDET_E_UNSUPP;
+        if (a.nblk > 0)
+            rc = res ? launch_b3_inst<BM, BN, MYDET_ACT_NONE, true, false, B3_PF, 2, true>(a, stream)
+                     : launch_b3_inst<BM, BN, MYDET_ACT_NONE, false, false, B3_PF, 2, true>(a, stream);
+        if (rc || !split) return rc;
+        a.tile0 = total - rem; a.splits = splits; a.nblk = rem * splits;
+        rc = launch_b3_inst<BM, BN, MYDET_ACT_NONE, false, true, B3_PF, 2, true>(a, stream);
+        if (rc) return rc;
+        return launch_fixup_act<BM, BN, 2, WN>(a, rem, stream);
+    }
     if (a.nblk > 0) {
         switch (a.act) {
             case MYDET_ACT_LEAKY: rc = res ? launch_b3_inst<BM, BN, MYDET_ACT_LEAKY, true, false, (WN == 4 ? 2 : B3_PF), WN>(a, stream) : launch_b3_inst<BM, BN, MYDET_ACT_LEAKY, false, false, (WN == 4 ? 2 : B3_PF), WN>(a, stream); break;
@@ -1227,7 +1247,7 @@ extern "C" int mydet_conv_b3_reload_tuning(void) {
 }
 
 extern "C" int mydet_conv2d_igemm_b3_f32(const float *x, int64_t ldx, const uint16_t *w_planes, const float *scale,
-                                         const float *shift, const float *residual, int64_t ldr, void *workspace,
+                                         const float *shift, const float *residual, int64_t ldr, const float *a_gate, void *workspace,
                                          int64_t workspace_bytes, float *y, int64_t ldy, int B, int H, int W, int Cin, int Cout,
                                          int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, void *stream) {
     if (!x || !w_planes || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 ||
@@ -1238,6 +1258,7 @@ extern "C" int mydet_conv2d_igemm_b3_f32(const float *x, int64_t ldx, const uint
         (scale && ((uintptr_t)scale & 15)) || (shift && ((uintptr_t)shift & 15)))
         return MYDET_E_BADARG;
     if (act < 0 || act > 2) return MYDET_E_BADARG;
+    if (a_gate && (KH != 1 || KW != 1 || ((uintptr_t)a_gate & 15))) return MYDET_E_BADARG;
     if ((Cin & 15) || (ldy & 3) || (residual && (ldr & 3))) return MYDET_E_UNSUPP;   // a 16-channel slab never straddles taps
     const int64_t M64 = (int64_t)B * Ho * Wo, K64 = (int64_t)KH * KW * Cin;
     if (M64 > (int64_t)1 << 30 || K64 > (int64_t)1 << 30) return MYDET_E_BADARG;
@@ -1246,7 +1267,7 @@ extern "C" int mydet_conv2d_igemm_b3_f32(const float *x, int64_t ldx, const uint
     if (M64 * ldy * 4 >= 0x7FFFFFF0ll || (residual && M64 * ldr * 4 >= 0x7FFFFFF0ll)) return MYDET_E_UNSUPP;
     if (KH * KW > 31 || img_bytes * span_imgs >= 0x7FFFFFF0ll || mydet_split_bf16_elems(Cout, (int)K64) * 2 >= 0x7FFFFFF0ll) return MYDET_E_UNSUPP;
     ConvArgs a;
-    a.x = x; a.w = nullptr; a.scale = scale; a.shift = shift; a.res = residual; a.gate = nullptr; a.y = y;
+    a.x = x; a.w = nullptr; a.scale = scale; a.shift = shift; a.res = residual; a.gate = a_gate; a.y = y;
     a.ldx = ldx; a.ldr = ldr; a.ldy = ldy;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride;
     a.pad_t = pad_t; a.pad_l = pad_l; a.Ho = Ho; a.Wo = Wo; a.act = act;
@@ -1263,7 +1284,7 @@ extern "C" int mydet_conv2d_igemm_b3_f32(const float *x, int64_t ldx, const uint
     //                    / 0.66 ms vs 0.65 / 0.69 / 0.69 on the three deep stride-2 layers, 1 538 vs 1 545 images/s in the model;
     //   MYDET_B3_WAVES=8 8-wave workgroups (wave tile 64 x 32, four waves per SIMD) -- 5-10 % faster back to back, 0.7 % slower
     //                    in the model (1 510 vs 1 520 images/s, twice each in one call)
-    const int form = b3_form();
+    const int form = a_gate ? 0 : b3_form();            // (the opt-in forms have no gated instances)
     if ((form & 1) && Cout > 192) return launch_b3w(a, (hipStream_t)stream);
     if (form & 2) return launch_b3<128, 128, 4>(a, (hipStream_t)stream);
     return launch_b3<128, 128>(a, (hipStream_t)stream);

@@ -275,11 +275,17 @@ B3_MIN_FLOP = float(os.environ.get('MYDET_B3_MIN_FLOP', '3e9'))
 # lanes (tools/r05_b3_effnet.sh, two runs each): expand convs on the float32 instruction 3 721 / 4 211 images/s (D1 batch 16 /
 # D1-FCOS batch 32), split-bf16 from 8 192 rows 3 761 / 4 268, from 3 000 rows 3 859 / 4 350.  MYDET_B3_EXPAND_MIN_ROWS=0 = off.
 B3_EXPAND_MIN_ROWS = int(os.environ.get('MYDET_B3_EXPAND_MIN_ROWS', '3000'))
+# ... and the gated project convs (1x1, no activation, the squeeze-excite gate applied to the activations before they are split) from 64
+# output channels and 20 000 rows -- on a lane of 16 images the 40^2 layers (480->80, 672->112): D1-FCOS batch 32 4 407 -> 4 455 images/s
+# (four runs each, one call); from 6 000 / 3 000 rows the same there and D1 batch 16 (lanes of 8: 12 800 / 3 200 rows) 1-2 % SLOWER
+# (tools/r05_b3_gate.sh).  MYDET_B3_GATED_MIN_COUT=0 keeps them all on the float32 kernel.
+B3_GATED_MIN_COUT = int(os.environ.get('MYDET_B3_GATED_MIN_COUT', '64'))
+B3_GATED_MIN_ROWS = int(os.environ.get('MYDET_B3_GATED_MIN_ROWS', '20000'))
 
 
-def b3_takes(M, Cin, Cout, k, min_rows=None):
+def b3_takes(M, Cin, Cout, k, min_rows=None, min_cout=128):
     """True when `conv2d(..., b3=)` runs the split-bf16 kernel for a layer of this shape."""
-    if not SPLIT_BF16 or Cin % 16 or not (k > 1 or Cout >= 128):
+    if not SPLIT_BF16 or Cin % 16 or not (k > 1 or Cout >= min_cout):
         return False
     if min_rows is not None:
         return M >= min_rows
@@ -314,7 +320,8 @@ def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None
     interior: 'in' / 'out' marks the input / output as a tensor that lives only inside a block (bookkeeping of the
     fused-minimum byte count of KernelTimer; no effect on the launch).
     b3: optional `split_bf16(w_ohwi)`: a layer that stays on the direct implicit GEMM then runs it on the bfloat16 matrix
-    instructions with float32-exact split operands (include/mydet.h: mydet_conv2d_igemm_b3_f32; Cin % 16 == 0, no gate), from
+    instructions with float32-exact split operands (include/mydet.h: mydet_conv2d_igemm_b3_f32; Cin % 16 == 0; with a gate: 1x1 layers
+    without activation), from
     B3_MIN_ROWS output pixels up (`b3_min_rows` overrides)."""
     require_gpu(x, 'conv2d')
     if x.shape[1] % 4:
@@ -360,10 +367,11 @@ def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None
         _lib.check(code, 'mydet_conv2d_wino_f32')
         return out
     ws = conv_workspace(x.device)
-    if b3 is not None and gate is None and b3_takes(B * Ho * Wo, Cin, Cout, k, b3_min_rows):
+    if (b3 is not None and b3_takes(B * Ho * Wo, Cin, Cout, k, b3_min_rows, min_cout=B3_GATED_MIN_COUT if gate is not None else 128)
+            and (gate is None or (k == 1 and act == ACT_NONE))):
         t0 = TIMER.start() if TIMER else None
         code = _lib.lib().mydet_conv2d_igemm_b3_f32(
-            _ptr(x), ldx, _ptr(b3), _ptr(scale), _ptr(shift), _ptr(residual), ldr, _ptr(ws), ws.numel() * 4, _ptr(out), ldy,
+            _ptr(x), ldx, _ptr(b3), _ptr(scale), _ptr(shift), _ptr(residual), ldr, _ptr(gate), _ptr(ws), ws.numel() * 4, _ptr(out), ldy,
             B, H, W, Cin, Cout, k, k, stride, pad[0], pad[1], Ho, Wo, act, _stream())
         if code != -2:                              # MYDET_E_UNSUPP: the float32 kernel below
             if t0:

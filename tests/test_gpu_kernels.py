@@ -85,6 +85,10 @@ def test_conv_igemm_vs_fp64(dev, case):
     dict(B=12, Cin=256, Cout=320, k=1, s=1, H=27, W=29, act=2, form='wide'),     # ragged rows, a quarter-full second channel tile (320)
     dict(B=32, Cin=128, Cout=256, k=3, s=2, H=40, W=40, act=1, form='waves8'),   # 8-wave workgroups (wave tile 64 x 32)
     dict(B=9, Cin=512, Cout=255, k=1, s=1, H=31, W=33, act=0, bias_only=True, form='waves8'),
+    dict(B=16, Cin=1152, Cout=192, k=1, s=1, H=20, W=20, act=0, residual=True, gate=True),     # MBConv project conv: SE gate on the A operand, small grid cut along K
+    dict(B=16, Cin=672, Cout=112, k=1, s=1, H=40, W=40, act=0, gate=True),                     # ragged channel tile (112 of 128), gate, no skip
+    dict(B=8, Cin=480, Cout=80, k=1, s=1, H=40, W=40, act=0, residual=True, gate=True),
+    dict(B=5, Cin=96, Cout=64, k=1, s=1, H=33, W=31, act=0, gate=True),                        # 128 x 64 tile, ragged rows crossing image borders
 ])
 def test_conv_split_bf16_vs_fp64(dev, case, monkeypatch):
     """The implicit GEMM on the bfloat16 matrix instructions with float32-exact split operands (conv_igemm_b3_kernel;
@@ -111,7 +115,9 @@ def _split_bf16_case(dev, case):
     scale = None if case.get('bias_only') else torch.rand(Cout, generator=g) + 0.5
     shift = torch.randn(Cout, generator=g) * 0.1
     p = (k - 1) // 2
-    ref = F.conv2d(F.pad(x, (p, p, p, p)).double(), w.double(), None, s)
+    gate = torch.rand(B, Cin, generator=g) if case.get('gate') else None
+    xg = x.double() * gate.double().view(B, Cin, 1, 1) if gate is not None else x.double()
+    ref = F.conv2d(F.pad(xg, (p, p, p, p)), w.double(), None, s)
     ref = ref * (scale.double().view(1, -1, 1, 1) if scale is not None else 1.0) + shift.double().view(1, -1, 1, 1)
     if case['act'] == 1:
         ref = F.leaky_relu(ref, 0.1)
@@ -122,7 +128,7 @@ def _split_bf16_case(dev, case):
         res = torch.randn(ref.shape, generator=g)
         ref = ref + res.double()
     Ho, Wo = ref.shape[2:]
-    assert ops.b3_takes(B * Ho * Wo, Cin, Cout, k, min_rows=1)        # (the kernel, not the dispatch rule, is under test)
+    assert ops.b3_takes(B * Ho * Wo, Cin, Cout, k, min_rows=1, min_cout=64)        # (the kernel, not the dispatch rule, is under test)
     xd = x.to(dev).contiguous(memory_format=torch.channels_last)
     wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
     w3 = ops.split_bf16(wd)
@@ -136,6 +142,8 @@ def _split_bf16_case(dev, case):
     assert (back - wd).abs().max().item() <= 2.0 ** -24 * wd.abs().max().item()
     assert not bool(rows.permute(1, 2, 0, 3, 4).reshape(CoutP, K)[Cout:].any())
     kw = dict(residual=res.to(dev).contiguous(memory_format=torch.channels_last) if res is not None else None)
+    if gate is not None:
+        kw['gate'] = gate.to(dev)
     args = (xd, wd, scale.to(dev) if scale is not None else None, shift.to(dev), k, s, (p, p, p, p), case['act'])
     ops.TIMER = ops.KernelTimer()
     try:
