@@ -1284,6 +1284,10 @@ extern "C" int mydet_conv2d_igemm_b3_f32(const float *x, int64_t ldx, const uint
     //                    / 0.66 ms vs 0.65 / 0.69 / 0.69 on the three deep stride-2 layers, 1 538 vs 1 545 images/s in the model;
     //   MYDET_B3_WAVES=8 8-wave workgroups (wave tile 64 x 32, four waves per SIMD) -- 5-10 % faster back to back, 0.7 % slower
     //                    in the model (1 510 vs 1 520 images/s, twice each in one call)
+    // at most half as many 128-row tiles as CUs (the EfficientNet project convs on a lane of 8-16 images): 64-row tiles, twice the
+    // workgroups.  MYDET_B3_HALF_TILES overrides the limit (0 = never; tuning)
+    static const int half_tiles = [] { const char *e = getenv("MYDET_B3_HALF_TILES"); return e ? atoi(e) : mydet_cu_count() / 2; }();
+    if (((M64 + 127) / 128) * ((Cout + 127) / 128) <= half_tiles) return launch_b3<64, 128>(a, (hipStream_t)stream);
     const int form = a_gate ? 0 : b3_form();            // (the opt-in forms have no gated instances)
     if ((form & 1) && Cout > 192) return launch_b3w(a, (hipStream_t)stream);
     if (form & 2) return launch_b3<128, 128, 4>(a, (hipStream_t)stream);

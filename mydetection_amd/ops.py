@@ -276,11 +276,12 @@ B3_MIN_FLOP = float(os.environ.get('MYDET_B3_MIN_FLOP', '3e9'))
 # D1-FCOS batch 32), split-bf16 from 8 192 rows 3 761 / 4 268, from 3 000 rows 3 859 / 4 350.  MYDET_B3_EXPAND_MIN_ROWS=0 = off.
 B3_EXPAND_MIN_ROWS = int(os.environ.get('MYDET_B3_EXPAND_MIN_ROWS', '3000'))
 # ... and the gated project convs (1x1, no activation, the squeeze-excite gate applied to the activations before they are split) from 64
-# output channels and 20 000 rows -- on a lane of 16 images the 40^2 layers (480->80, 672->112): D1-FCOS batch 32 4 407 -> 4 455 images/s
-# (four runs each, one call); from 6 000 / 3 000 rows the same there and D1 batch 16 (lanes of 8: 12 800 / 3 200 rows) 1-2 % SLOWER
-# (tools/r05_b3_gate.sh).  MYDET_B3_GATED_MIN_COUT=0 keeps them all on the float32 kernel.
+# output channels and the same 3 000 rows.  Their grids are small (80-320 output channels: 50-200 tiles of 128 x 128 on a lane), so the
+# launcher cuts a layer of at most cus / 2 such tiles into 64-row tiles.  Measured (tools/r05_b3_gate.sh, tools/r05_b3_half.sh; two to four
+# runs each, one call): D1 batch 16 3 854 -> 3 893, D1-FCOS batch 32 4 407 -> 4 500 images/s; with 128-row tiles only, D1 LOST 1-2 %
+# (3 851 -> 3 782) while D1-FCOS gained 1 %.  MYDET_B3_GATED_MIN_COUT=0 keeps them all on the float32 kernel.
 B3_GATED_MIN_COUT = int(os.environ.get('MYDET_B3_GATED_MIN_COUT', '64'))
-B3_GATED_MIN_ROWS = int(os.environ.get('MYDET_B3_GATED_MIN_ROWS', '20000'))
+B3_GATED_MIN_ROWS = int(os.environ.get('MYDET_B3_GATED_MIN_ROWS', '3000'))
 
 
 def b3_takes(M, Cin, Cout, k, min_rows=None, min_cout=128):

@@ -89,6 +89,8 @@ def test_conv_igemm_vs_fp64(dev, case):
     dict(B=16, Cin=672, Cout=112, k=1, s=1, H=40, W=40, act=0, gate=True),                     # ragged channel tile (112 of 128), gate, no skip
     dict(B=8, Cin=480, Cout=80, k=1, s=1, H=40, W=40, act=0, residual=True, gate=True),
     dict(B=5, Cin=96, Cout=64, k=1, s=1, H=33, W=31, act=0, gate=True),                        # 128 x 64 tile, ragged rows crossing image borders
+    dict(B=8, Cin=192, Cout=1152, k=1, s=1, H=10, W=10, act=2),                                # 63 tiles of 128 rows: the 64-row tile without a gate, swish, ragged last row tile
+    dict(B=40, Cin=672, Cout=112, k=1, s=1, H=40, W=40, act=0, residual=True, gate=True),        # 500 tiles: the 128-row tile with the gate (the four above run 64-row tiles)
 ])
 def test_conv_split_bf16_vs_fp64(dev, case, monkeypatch):
     """The implicit GEMM on the bfloat16 matrix instructions with float32-exact split operands (conv_igemm_b3_kernel;

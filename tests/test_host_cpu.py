@@ -608,7 +608,7 @@ def test_split_bf16_dispatch_rule():
         assert not ops.b3_takes(M, cin, cout, k), (M, cin, cout, k)
     # the EfficientNet expand convs carry their own row limit: a lane of 8 images at 20^2 is in, a 10^2 map is not
     assert ops.b3_takes(px(8, 20), 192, 1152, 1, ops.B3_EXPAND_MIN_ROWS) and not ops.b3_takes(px(8, 10), 192, 1152, 1, ops.B3_EXPAND_MIN_ROWS)
-    # the gated project convs: from 64 output channels and 20 000 rows (a lane of 16 images at 40^2), not on a lane of 8
+    # the gated project convs: from 64 output channels and 3 000 rows (a lane of 8 images at 20^2), not the 40-channel layers
     assert ops.b3_takes(px(16, 40), 672, 112, 1, ops.B3_GATED_MIN_ROWS, min_cout=ops.B3_GATED_MIN_COUT)
-    assert not ops.b3_takes(px(8, 40), 672, 112, 1, ops.B3_GATED_MIN_ROWS, min_cout=ops.B3_GATED_MIN_COUT)
+    assert ops.b3_takes(px(8, 20), 1152, 192, 1, ops.B3_GATED_MIN_ROWS, min_cout=ops.B3_GATED_MIN_COUT)
     assert not ops.b3_takes(px(16, 80), 240, 40, 1, ops.B3_GATED_MIN_ROWS, min_cout=ops.B3_GATED_MIN_COUT)
