@@ -665,7 +665,16 @@ def measure(args, ctx):
                             f'{kernels[dom][1]:.4g}) / HIP-event time vs the dense peak of the instruction used; algorithmic_* = direct-form FLOPs / time vs the FP32-MFMA peak',
                     'algorithmic_gflop_per_launch': round(flops_k / n_k / 1e9, 3)}
     else:
-        fams = {k: summ[k] for k in summ if timer.bytes.get(k)}
+        # the dense / pointwise convs are ONE family here, whichever matrix instruction a layer's launch uses (conv_igemm_kernel on
+        # FP32 MFMA, conv_igemm_b3_kernel with split operands on BF16 MFMA): times, FLOPs and bytes added
+        merged = 'conv_igemm_b3' in summ and 'conv_igemm' in summ
+        if merged:
+            a_, b_ = summ['conv_igemm'], summ['conv_igemm_b3']
+            summ = dict(summ)
+            summ['conv_igemm'] = (a_[0] + b_[0], a_[1] + b_[1], a_[2] + b_[2])
+            timer.bytes = dict(timer.bytes)
+            timer.bytes['conv_igemm'] = timer.bytes.get('conv_igemm', 0.0) + timer.bytes.get('conv_igemm_b3', 0.0)
+        fams = {k: summ[k] for k in summ if timer.bytes.get(k) and not (merged and k == 'conv_igemm_b3')}
         dom = max(fams, key=lambda k: fams[k][1])
         n_k, ms_k, _ = fams[dom]
         gbs = timer.bytes[dom] / (ms_k * 1e-3) / 1e9
@@ -683,7 +692,9 @@ def measure(args, ctx):
         mfma_frac = stages[dom].get('mfma_frac', 0.0) if dom in conv_fams else 0.0
         by_mfma = mfma_frac > hbm_frac
         roofline = {'bound': 'mfma' if by_mfma else 'hbm',
-                    'kernel': {'conv_igemm': 'conv_igemm_kernel (pointwise / dense convs, FP32 MFMA)',
+                    'kernel': {'conv_igemm': ('conv_igemm_kernel + conv_igemm_b3_kernel (pointwise / dense convs: FP32 MFMA, and split-bf16 '
+                                              'operands on BF16 MFMA; mfma_frac = algorithmic FLOPs / time vs the FP32-MFMA peak)') if merged
+                               else 'conv_igemm_kernel (pointwise / dense convs, FP32 MFMA)',
                                'dwconv': 'dwconv kernels (depthwise k3/k5 + BN + swish)'}.get(dom, dom),
                     'achieved': round(mfma_frac * PEAK_FP32_MFMA_TFLOPS, 2) if by_mfma else round(gbs, 1),
                     'peak': PEAK_FP32_MFMA_TFLOPS if by_mfma else PEAK_HBM_GBS, 'unit': 'TFLOP/s' if by_mfma else 'GB/s',
@@ -705,7 +716,13 @@ def measure(args, ctx):
         name = f'{rnd}_pmc_traffic_{tag}_b{batch}_{args.size}.json' if rnd != 'r01' else 'r01_pmc_traffic_b32_640.json'
         path = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(path) and (rnd != 'r01' or (args.config == 'yolov3_80' and batch == 32 and args.size == 640)):
-            pmc = json.load(open(path)).get(dom)
+            pmc_all = json.load(open(path))
+            pmc = pmc_all.get(dom)
+            if pmc and dom == 'conv_igemm' and args.config != 'yolov3_80' and pmc_all.get('conv_igemm_b3'):     # the merged family
+                q = pmc_all['conv_igemm_b3']
+                n_a, n_b = pmc.get('launches', 0), q.get('launches', 0)
+                if n_a + n_b:
+                    pmc = {'hbm_bytes_per_launch': (pmc.get('hbm_bytes_per_launch', 0) * n_a + q.get('hbm_bytes_per_launch', 0) * n_b) / (n_a + n_b)}
             if pmc:
                 traffic = round(pmc.get('hbm_bytes_per_launch', pmc.get('hbm_read_bytes_per_launch_x2corr', 0) + pmc.get('hbm_write_bytes_per_launch', 0)))
                 traffic_src = f'profiles/{name} (offline rocprofv3 --pmc passes' + (', an earlier round' if rnd != 'r05' else '') + ')'
