@@ -389,7 +389,7 @@ def brief_line(o, wall_s):
             'parity_check': o['parity_check'], 'wall_s': round(wall_s, 1)}
 
 
-def power_probe(step, seconds=1.5):
+def power_probe(step, seconds=3.0):
     """Board power and shader clock (rocm-smi, a child process, sampled while `step` keeps replaying for `seconds`) -- or None when
     rocm-smi is not there.  Not part of the timed region.  The headline step runs at the board's power cap: its
     time is its energy over the cap, which this pair of numbers shows next to the measurement."""
@@ -408,7 +408,7 @@ def power_probe(step, seconds=1.5):
                 txt = subprocess.run(['rocm-smi', '--showpower', '--showclocks', '--showmaxpower'], capture_output=True, text=True, timeout=10).stdout
             except Exception:
                 return
-            pw = re.search(r'Package Power \(W\): ([\d.]+)', txt)
+            pw = re.search(r'Current Socket Graphics Package Power \(W\): ([\d.]+)', txt) or re.search(r'Average Graphics Package Power \(W\): ([\d.]+)', txt)
             ck = re.search(r'sclk clock level: \d+: \((\d+)Mhz\)', txt)
             cap = re.search(r'Max Graphics Package Power \(W\): ([\d.]+)', txt)
             if pw and ck:
@@ -424,12 +424,13 @@ def power_probe(step, seconds=1.5):
         n += 5
     stop.append(1)
     th.join(15)
-    samples = samples[1:] if len(samples) > 2 else samples          # the first sample may predate the load
     if not samples:
         return None
-    return {'board_w': round(sum(a for a, _, _ in samples) / len(samples), 1), 'cap_w': samples[-1][2],
-            'sclk_mhz': round(sum(b for _, b, _ in samples) / len(samples)), 'samples': len(samples), 'steps_replayed': n,
-            'note': 'rocm-smi while the step keeps replaying after the timed region; board power at its cap = the step time is its energy / cap'}
+    tail = samples[len(samples) // 2:]                                # rocm-smi reports a running average: the second half has settled
+    return {'board_w': round(sum(a for a, _, _ in tail) / len(tail), 1), 'board_w_max': max(a for a, _, _ in samples), 'cap_w': samples[-1][2],
+            'sclk_mhz': round(sum(b for _, b, _ in tail) / len(tail)), 'samples': len(samples), 'steps_replayed': n,
+            'note': 'rocm-smi while the step keeps replaying after the timed region (second half of the samples); near cap_w = the step is '
+                    'power-bound: its time is its energy over the cap (DESIGN.md section 5; a 14 s run reads 1 366-1 374 W on the headline)'}
 
 
 def measure(args, ctx):
