@@ -89,6 +89,8 @@ def test_conv_igemm_vs_fp64(dev, case):
     dict(B=16, Cin=672, Cout=112, k=1, s=1, H=40, W=40, act=0, gate=True),                     # ragged channel tile (112 of 128), gate, no skip
     dict(B=8, Cin=480, Cout=80, k=1, s=1, H=40, W=40, act=0, residual=True, gate=True),
     dict(B=5, Cin=96, Cout=64, k=1, s=1, H=33, W=31, act=0, gate=True),                        # 128 x 64 tile, ragged rows crossing image borders
+    dict(B=16, Cin=256, Cout=128, k=1, s=1, H=40, W=40, act=1, residual=True, strided=True),      # input a channel slice of a wider map (ldx > Cin), output rows padded (ldy > Cout)
+    dict(B=12, Cin=64, Cout=160, k=3, s=2, H=64, W=64, act=1, strided=True),
     dict(B=8, Cin=192, Cout=1152, k=1, s=1, H=10, W=10, act=2),                                # 63 tiles of 128 rows: the 64-row tile without a gate, swish, ragged last row tile
     dict(B=40, Cin=672, Cout=112, k=1, s=1, H=40, W=40, act=0, residual=True, gate=True),        # 500 tiles: the 128-row tile with the gate (the four above run 64-row tiles)
 ])
@@ -132,6 +134,11 @@ def _split_bf16_case(dev, case):
     Ho, Wo = ref.shape[2:]
     assert ops.b3_takes(B * Ho * Wo, Cin, Cout, k, min_rows=1, min_cout=64)        # (the kernel, not the dispatch rule, is under test)
     xd = x.to(dev).contiguous(memory_format=torch.channels_last)
+    if case.get('strided'):             # the same values as channels [8, 8 + Cin) of a map with 24 more channels
+        wide = torch.randn(B, Cin + 24, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        wide[:, 8:8 + Cin] = xd
+        xd = wide[:, 8:8 + Cin]
+        assert ops.to_nhwc(xd)[1] == Cin + 24
     wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
     w3 = ops.split_bf16(wd)
     # the operand's layout (slab-major, 256-row padding, DMA swizzle): undone here, p0 + p1 + p2 == w to 2^-27
@@ -146,6 +153,8 @@ def _split_bf16_case(dev, case):
     kw = dict(residual=res.to(dev).contiguous(memory_format=torch.channels_last) if res is not None else None)
     if gate is not None:
         kw['gate'] = gate.to(dev)
+    if case.get('strided'):
+        kw['out_ld'] = Cout + 12
     args = (xd, wd, scale.to(dev) if scale is not None else None, shift.to(dev), k, s, (p, p, p, p), case['act'])
     ops.TIMER = ops.KernelTimer()
     try:
