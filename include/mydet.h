@@ -197,9 +197,10 @@ int mydet_conv1x1_upcat_f32(const float *x_lo, int64_t ld_lo, int C_lo, const fl
  * rate.  Same arguments as mydet_conv2d_igemm_f32 except: w_planes = the OHWI weight [Cout][K = KH*KW*Cin] as three bfloat16
  * planes in the kernels' slab-major, DMA-swizzled order (csrc/conv_igemm.hip: split_bf16_kernel; Cout padded to 256 rows),
  * made ONCE per layer by mydet_split_bf16_f32 into mydet_split_bf16_elems(Cout, K) uint16; a_gate (optional, 1x1 layers without an
- * activation: the squeeze-excite project convs) multiplies the activations per image and channel before they are split.  Cin % 16 == 0;
+ * activation: the squeeze-excite project convs) multiplies the activations per image and channel before they are split.  Cin % 16 == 0 (1x1 layers: Cin % 4 == 0, the
+ * last 16-channel slab of the planes zero-filled by mydet_split_bf16_f32);
  * MYDET_E_UNSUPP otherwise (the caller then uses mydet_conv2d_igemm_f32).  Replaces the same reference lines. */
-int64_t mydet_split_bf16_elems(int Cout, int K);      /* uint16 elements of the operand below (0: K % 16 != 0) */
+int64_t mydet_split_bf16_elems(int Cout, int K);      /* uint16 elements of the operand below (0: K % 4 != 0) */
 int mydet_split_bf16_f32(const float *w, int Cout, int K, uint16_t *planes, void *stream);
 int mydet_conv2d_igemm_b3_f32(const float *x, int64_t ldx, const uint16_t *w_planes, const float *scale, const float *shift,
                               const float *residual, int64_t ldr, const float *a_gate, void *workspace, int64_t workspace_bytes, float *y,

@@ -395,7 +395,7 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm_b3_kernel(const ConvAr
     const int64_t img = (int64_t)p.H * p.W * p.ldx;
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x + b0 * img, (p.B - b0) * img * 4);
     const int CoutP = (p.Cout + B3_COUT_PAD - 1) / B3_COUT_PAD * B3_COUT_PAD;
-    const __amdgpu_buffer_rsrc_t wr = make_rsrc(reinterpret_cast<const float *>(p.wsplit), (int64_t)(p.K >> 4) * 3 * CoutP * 32);
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(reinterpret_cast<const float *>(p.wsplit), (int64_t)((p.K + 15) >> 4) * 3 * CoutP * 32);
 
     // ---- staging roles.  A: chunk (4 floats) sc of rows sr + RP i.  B: chunk (8 bf16) bh of row br, all three planes.
     constexpr int RP = NT / 4;
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm_b3_kernel(const ConvAr
 
     f32x4 areg[PF][AI];
     u32x4 breg[PF][3];
-    const int nk_all = p.K / BK;
+    const int nk_all = (p.K + BK - 1) / BK;          // (1x1 layers may have Cin % 16 == 4, 8, 12: the last slab's missing channels are zeros)
     int kt0 = 0, nk = nk_all;
     if (SPLIT) {
         const int sp = (int)blockIdx.x % p.splits;
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm_b3_kernel(const ConvAr
         const unsigned uoff = (unsigned)(tapoff + c0 * 4);
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
-            bool ok = (amask[i] >> tap) & 1u;
+            bool ok = ((amask[i] >> tap) & 1u) && c0 + sc * 4 < p.Cin;
 #ifdef MYDET_SE_PK
             if (p.C1 & 1) ok = false;
 #endif
@@ -807,12 +807,12 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_b3w_kernel(const ConvArgs p
 //     order), a fragment read of eight consecutive rows then touches eight different 16-byte bank groups.
 __global__ __launch_bounds__(256) void split_bf16_kernel(const float *w, int Cout, int K, int CoutP, unsigned short *out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (kt, n, k % 16) over the padded rows
-    const int64_t total = (int64_t)(K >> 4) * CoutP * 16;
+    const int64_t total = (int64_t)((K + 15) >> 4) * CoutP * 16;         // the last slab of a K that is no multiple of 16 is zero-filled
     if (i >= total) return;
     const int kk = (int)(i & 15);
     const int64_t t = i >> 4;
     const int n = (int)(t % CoutP), kt = (int)(t / CoutP);
-    const float v = n < Cout ? w[(int64_t)n * K + kt * 16 + kk] : 0.f;
+    const float v = (n < Cout && kt * 16 + kk < K) ? w[(int64_t)n * K + kt * 16 + kk] : 0.f;
     const __bf16 h0 = (__bf16)v;
     const float r1 = v - (float)h0;
     const __bf16 h1 = (__bf16)r1;
@@ -1015,7 +1015,7 @@ int launch_b3(const ConvArgs &a0, hipStream_t stream) {
     const int mtiles = (a.M + BM - 1) / BM;
     a.ntiles = (a.Cout + BN - 1) / BN;
     const int total = mtiles * a.ntiles;
-    const int nk = a.K / 16;
+    const int nk = (a.K + 15) / 16;
     const int rounds = total / slots;
     const int rem = total % slots;
     const bool small = rounds == 0 && total * 4 <= slots && nk >= 32;
@@ -1217,15 +1217,15 @@ extern "C" int mydet_conv2d_igemm_f32(const float *x, int64_t ldx, const float *
 }
 
 extern "C" int64_t mydet_split_bf16_elems(int Cout, int K) {
-    if (Cout <= 0 || K <= 0 || (K & 15)) return 0;
-    return (int64_t)(K >> 4) * 3 * ((Cout + B3_COUT_PAD - 1) / B3_COUT_PAD * B3_COUT_PAD) * 16;
+    if (Cout <= 0 || K <= 0 || (K & 3)) return 0;
+    return (int64_t)((K + 15) >> 4) * 3 * ((Cout + B3_COUT_PAD - 1) / B3_COUT_PAD * B3_COUT_PAD) * 16;
 }
 
 extern "C" int mydet_split_bf16_f32(const float *w, int Cout, int K, uint16_t *planes, void *stream) {
     if (!w || !planes || Cout <= 0 || K <= 0) return MYDET_E_BADARG;
-    if (K & 15) return MYDET_E_UNSUPP;
+    if (K & 3) return MYDET_E_UNSUPP;
     const int CoutP = (Cout + B3_COUT_PAD - 1) / B3_COUT_PAD * B3_COUT_PAD;
-    const int64_t total = (int64_t)(K >> 4) * CoutP * 16;
+    const int64_t total = (int64_t)((K + 15) >> 4) * CoutP * 16;
     if ((total + 255) / 256 > 0x7fffffff) return MYDET_E_UNSUPP;
     hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, K,
                        CoutP, planes);
@@ -1259,7 +1259,9 @@ extern "C" int mydet_conv2d_igemm_b3_f32(const float *x, int64_t ldx, const uint
         return MYDET_E_BADARG;
     if (act < 0 || act > 2) return MYDET_E_BADARG;
     if (a_gate && (KH != 1 || KW != 1 || ((uintptr_t)a_gate & 15))) return MYDET_E_BADARG;
-    if ((Cin & 15) || (ldy & 3) || (residual && (ldr & 3))) return MYDET_E_UNSUPP;   // a 16-channel slab never straddles taps
+    // a 16-channel slab never straddles taps: Cin % 16 == 0, or ONE tap (1x1) with Cin % 4 == 0 (the last slab's missing channels: zeros)
+    if (((Cin & 15) && !(KH == 1 && KW == 1 && !(Cin & 3))) || (ldy & 3) || (residual && (ldr & 3))) return MYDET_E_UNSUPP;
+    if ((Cin & 15) && (Cout > 192 ? b3_form() & 1 : 0)) return MYDET_E_UNSUPP;          // (the opt-in wide form has no padded-K instance)
     const int64_t M64 = (int64_t)B * Ho * Wo, K64 = (int64_t)KH * KW * Cin;
     if (M64 > (int64_t)1 << 30 || K64 > (int64_t)1 << 30) return MYDET_E_BADARG;
     const int64_t img_bytes = (int64_t)H * W * ldx * 4;

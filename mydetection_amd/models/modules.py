@@ -65,8 +65,8 @@ def prepare_wino(owner, slot, w_ohwi):
 
 def prepare_b3(owner, slot, w_ohwi):
     """Three-plane bfloat16 copy of a prepared OHWI weight for the split-bf16 implicit GEMM (ops.split_bf16; cached on `owner`
-    next to the weight it was made from), or None when no shape of the layer can take that kernel (Cin % 16)."""
-    if not ops.SPLIT_BF16 or w_ohwi.shape[3] % 16:
+    next to the weight it was made from), or None when no shape of the layer can take that kernel (Cin % 16; 1x1 layers: Cin % 4)."""
+    if not ops.SPLIT_BF16 or (w_ohwi.shape[3] % 16 and not (w_ohwi.shape[1] == 1 and w_ohwi.shape[2] == 1 and w_ohwi.shape[3] % 4 == 0)):
         return None
     cache = owner.__dict__.setdefault('_prep_cache', {})
     hit = cache.get(slot)

@@ -270,6 +270,7 @@ SPLIT_BF16 = os.environ.get('MYDET_CONV_SPLIT_BF16', '1') != '0'
 # 128->64 @160^2 0.197 vs 0.187 ms for the float32 kernel; every wider shape of the headline 1.25-1.35 x faster)
 B3_MIN_ROWS = int(os.environ.get('MYDET_B3_MIN_ROWS', '8192'))
 B3_MIN_FLOP = float(os.environ.get('MYDET_B3_MIN_FLOP', '3e9'))
+B3_KPAD = os.environ.get('MYDET_B3_KPAD', '1') != '0'      # 1x1 layers with Cin % 16 == 4, 8, 12 (last slab zero-filled)
 # The EfficientNet expand convs (1x1, 6 x Cin output channels, swish) take it from fewer rows: on a batch lane of 8 / 16 images
 # the 20^2 layers have 3 200 / 6 400 rows and still fill the chip (225-750 tiles of 128 x 128).  Measured in the model, two
 # lanes (tools/r05_b3_effnet.sh, two runs each): expand convs on the float32 instruction 3 721 / 4 211 images/s (D1 batch 16 /
@@ -286,7 +287,9 @@ B3_GATED_MIN_ROWS = int(os.environ.get('MYDET_B3_GATED_MIN_ROWS', '3000'))
 
 def b3_takes(M, Cin, Cout, k, min_rows=None, min_cout=128):
     """True when `conv2d(..., b3=)` runs the split-bf16 kernel for a layer of this shape."""
-    if not SPLIT_BF16 or Cin % 16 or not (k > 1 or Cout >= min_cout):
+    if not SPLIT_BF16 or not (k > 1 or Cout >= min_cout):
+        return False
+    if Cin % 16 and not (B3_KPAD and k == 1 and Cin % 4 == 0):           # a 16-channel slab never straddles taps; a 1x1 layer's last slab may be short
         return False
     if min_rows is not None:
         return M >= min_rows
@@ -299,12 +302,13 @@ def b3_takes(M, Cin, Cout, k, min_rows=None, min_cout=128):
 def split_bf16(w_ohwi):
     """The weight operand of `conv2d(..., b3=)`: the OHWI weight [Cout, kh, kw, Cin] as three bfloat16 planes, w = p0 + p1 + p2 to
     2^-27 |w|, in the split-bf16 kernels' slab-major order (include/mydet.h: mydet_split_bf16_f32); int16 storage.
-    None when Cin % 16."""
+    None when Cin % 16 (a 1x1 weight: when Cin % 4; its last 16-channel slab is zero-filled)."""
     require_gpu(w_ohwi, 'split_bf16')
     Cout = w_ohwi.shape[0]
     K = w_ohwi.numel() // Cout
     n = _lib.lib().mydet_split_bf16_elems(Cout, K)
-    if n <= 0 or w_ohwi.shape[-1] % 16:
+    one_tap = w_ohwi.shape[1] == 1 and w_ohwi.shape[2] == 1
+    if n <= 0 or (w_ohwi.shape[-1] % 16 and not (one_tap and w_ohwi.shape[-1] % 4 == 0)):
         return None
     w = w_ohwi.contiguous().float()
     out = torch.empty(n, dtype=torch.int16, device=w.device)

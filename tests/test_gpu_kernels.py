@@ -91,6 +91,8 @@ def test_conv_igemm_vs_fp64(dev, case):
     dict(B=5, Cin=96, Cout=64, k=1, s=1, H=33, W=31, act=0, gate=True),                        # 128 x 64 tile, ragged rows crossing image borders
     dict(B=16, Cin=256, Cout=128, k=1, s=1, H=40, W=40, act=1, residual=True, strided=True),      # input a channel slice of a wider map (ldx > Cin), output rows padded (ldy > Cout)
     dict(B=12, Cin=64, Cout=160, k=3, s=2, H=64, W=64, act=1, strided=True),
+    dict(B=8, Cin=40, Cout=240, k=1, s=1, H=80, W=80, act=2),                                    # Cin % 16 == 8: the last slab of a 1x1 layer zero-filled (EfficientNet 40 -> 240)
+    dict(B=4, Cin=24, Cout=144, k=1, s=1, H=50, W=46, act=2, strided=True),                      # Cin % 16 == 8 again, a channel slice: what lies behind the 24 channels must not enter
     dict(B=8, Cin=192, Cout=1152, k=1, s=1, H=10, W=10, act=2),                                # 63 tiles of 128 rows: the 64-row tile without a gate, swish, ragged last row tile
     dict(B=40, Cin=672, Cout=112, k=1, s=1, H=40, W=40, act=0, residual=True, gate=True),        # 500 tiles: the 128-row tile with the gate (the four above run 64-row tiles)
 ])
@@ -143,13 +145,15 @@ def _split_bf16_case(dev, case):
     w3 = ops.split_bf16(wd)
     # the operand's layout (slab-major, 256-row padding, DMA swizzle): undone here, p0 + p1 + p2 == w to 2^-27
     K, CoutP = wd.numel() // Cout, (Cout + 255) // 256 * 256
-    pl = w3.view(torch.bfloat16).float().view(K // 16, 3, CoutP // 32, 64, 8).sum(1)          # [kt][blk][unit][8]
+    Kp = (K + 15) // 16 * 16
+    pl = w3.view(torch.bfloat16).float().view(Kp // 16, 3, CoutP // 32, 64, 8).sum(1)          # [kt][blk][unit][8]
     rr = torch.arange(32, device=dev)
     unit = torch.stack([2 * rr + (h ^ ((rr >> 2) & 1)) for h in (0, 1)], 1)                    # [row in block][k-half]
     rows = pl[:, :, unit]                                                                     # [kt][blk][32][2][8]
-    back = rows.permute(1, 2, 0, 3, 4).reshape(CoutP, K)[:Cout].view_as(wd)
+    full = rows.permute(1, 2, 0, 3, 4).reshape(CoutP, Kp)
+    back = full[:Cout, :K].reshape(wd.shape)
     assert (back - wd).abs().max().item() <= 2.0 ** -24 * wd.abs().max().item()
-    assert not bool(rows.permute(1, 2, 0, 3, 4).reshape(CoutP, K)[Cout:].any())
+    assert not bool(full[Cout:].any()) and not bool(full[:, K:].any())
     kw = dict(residual=res.to(dev).contiguous(memory_format=torch.channels_last) if res is not None else None)
     if gate is not None:
         kw['gate'] = gate.to(dev)
