@@ -457,9 +457,6 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm_b3_kernel(const ConvAr
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             bool ok = ((amask[i] >> tap) & 1u) && c0 + sc * 4 < p.Cin;
-#ifdef MYDET_SE_PK
-            if (p.C1 & 1) ok = false;
-#endif
             ar[i] = buf_load16(xr, ok ? (unsigned)aoff[i] + uoff : OOB);
             if (GATE) {                               // (1x1: one tap, c0 is the slab's first channel)
                 const f32x4 gv = buf_load16(gr, ok ? goff[i] + (unsigned)c0 * 4u : OOB);
@@ -476,17 +473,11 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm_b3_kernel(const ConvAr
         }
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
-            brg[pl] = __builtin_amdgcn_raw_buffer_load_b128(wr,
-#ifdef MYDET_SE_PK
-                                                            (p.C1 & 2) ? OOB :
-#endif
-                                                            boff,
+            brg[pl] = __builtin_amdgcn_raw_buffer_load_b128(wr, kt < nk_all ? boff : OOB,      // (the range check sees the voffset only: the
+                                                            // look-ahead past the last slab must not leave the planes: ADVICE r05)
                                                             __builtin_amdgcn_readfirstlane((unsigned)kt * slab_bytes + (unsigned)pl * plane_bytes), 0);
     };
     auto store_slab = [&](int buf, const f32x4 (&ar)[AI], const u32x4 (&brg)[3]) {
-#ifdef MYDET_SE_PK
-        if (p.C1 & 16) return;
-#endif
         char *a = smem_b3 + buf * BUF, *b = a + 3 * PLANE_A;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
@@ -526,9 +517,6 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm_b3_kernel(const ConvAr
         psft[j] = (!SPLIT && p.shift) ? p.shift[nc] : 0.0f;
     }
     auto compute = [&](int buf) {
-#ifdef MYDET_SE_PK
-        if (p.C1 & 32) return;
-#endif
         const char *a = smem_b3 + buf * BUF + a_off;
         const char *b = smem_b3 + buf * BUF + b_off;
         bf16x8 af[TM][3], bf[TN][3];
@@ -543,15 +531,6 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm_b3_kernel(const ConvAr
         // the six piece products, small ones first (the running sum absorbs them at its own rounding either way); a piece pair
         // sweeps all blocks of the wave tile before the next pair, so MFMAs on one accumulator are TM * TN instructions apart
         constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-#ifdef MYDET_SE_PK
-        if (p.C1 & 4) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j][0] += (float)af[i][0][0] + (float)bf[j][0][0];
-            return;
-        }
-#endif
 #pragma unroll
         for (int t = 0; t < 6; ++t)
 #pragma unroll
@@ -593,9 +572,6 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm_b3_kernel(const ConvAr
         return;
     }
     const int m_base = m0 + wm * TM * 32, n_base = n0 + wn * TN * 32;
-#ifdef MYDET_SE_PK
-    if (p.C1 & 8) { if (acc[0][0][0] == 12345.678f) p.y[0] = 1.f; return; }
-#endif
     if ((m0 + BM <= p.M) && (n0 + BN <= p.Cout))
         epilogue<ACT, RES, true, TM, TN>(p, acc, m_base, n_base, fr, fh, pscl, psft);
     else
@@ -1275,9 +1251,6 @@ extern "C" int mydet_conv2d_igemm_b3_f32(const float *x, int64_t ldx, const uint
     a.pad_t = pad_t; a.pad_l = pad_l; a.Ho = Ho; a.Wo = Wo; a.act = act;
     a.M = (int)M64; a.K = (int)K64; a.ntiles = 0; a.nblk = 0; a.tile0 = 0; a.splits = 1;
     a.x1 = nullptr; a.ldx1 = 0; a.C1 = 0; a.wsplit = w_planes;
-#ifdef MYDET_SE_PK
-    { const char *e = getenv("MYDET_B3_DBG"); a.C1 = e ? atoi(e) : 0; }      // diagnostic build only (tools/r05_pk_repro.py)
-#endif
     a.ws = ((uintptr_t)workspace & 15) ? nullptr : (float *)workspace;
     a.ws_bytes = workspace_bytes > 0 ? (size_t)workspace_bytes : 0;
     if (Cout <= 64) return launch_b3<128, 64>(a, (hipStream_t)stream);

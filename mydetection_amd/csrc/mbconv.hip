@@ -917,84 +917,3 @@ extern "C" int mydet_bifpn_fuse_f32(int n, const float *in0, int64_t ld0, int mo
     hipLaunchKernelGGL(bifpn_fuse_kernel, dim3(grid_for(p.total)), dim3(256), 0, (hipStream_t)stream, p);
     return mydet_launch_status();
 }
-
-#ifdef MYDET_SE_PK
-// ---- diagnostic build only (tools/r05_pk_repro.py): synthetic aggressors for the squeeze-excite tail finding of round 5
-namespace {
-typedef float dg_f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 dg_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 dg_bf16x4 __attribute__((ext_vector_type(4)));
-template <int KIND>
-__global__ __launch_bounds__(256) void diag_busy_kernel(float *sink, int iters, float seed) {
-    extern __shared__ __attribute__((aligned(16))) char dg_lds[];
-    dg_f32x16 acc0, acc1, accs[6];
-    f32x4 accs4[6];
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-    for (int q = 0; q < 6; ++q) { for (int i = 0; i < 16; ++i) accs[q][i] = 0.f; accs4[q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    dg_bf16x8 a, b;
-    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(seed + 0.001f * (threadIdx.x + i)); b[i] = (__bf16)(0.5f - 0.002f * (threadIdx.x * 3 + i)); }
-    float fa = seed + 0.001f * threadIdx.x, fb = 0.5f - 0.002f * threadIdx.x;
-    f32x4 v = {fa, fb, fa * 0.5f, fb * 0.25f};
-    if (KIND == 2) {
-        for (int i = threadIdx.x; i < 4096; i += 256) reinterpret_cast<f32x4 *>(dg_lds)[i] = f32x4{fa, fb, fa, fb};
-        __syncthreads();
-    }
-    for (int it = 0; it < iters; ++it) {
-        if (KIND == 0 || KIND == 2) {
-            if (KIND == 2) {
-                a = *reinterpret_cast<const dg_bf16x8 *>(dg_lds + ((threadIdx.x * 16 + it * 4096) & 0xFFF0));
-                b = *reinterpret_cast<const dg_bf16x8 *>(dg_lds + ((threadIdx.x * 16 + it * 4096 + 2048) & 0xFFF0));
-            }
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc1, 0, 0, 0);
-        } else if (KIND == 1) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fb, fa, acc1, 0, 0, 0);
-        } else if (KIND == 4 || KIND == 5 || KIND == 6) {     // independent accumulators: the matrix pipe never waits for a result
-#pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                if (KIND == 4) accs[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, accs[q], 0, 0, 0);
-                else if (KIND == 5) accs[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, accs[q], 0, 0, 0);
-                else accs4[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, accs4[q], 0, 0, 0);
-            }
-        } else {            // 3: the float32 -> three bfloat16 pieces arithmetic of the split-bf16 kernel's staging, no MFMA
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const __bf16 h0 = (__bf16)v[e];
-                const float r1 = v[e] - (float)h0;
-                const __bf16 h1 = (__bf16)r1;
-                const float r2 = r1 - (float)h1;
-                v[e] = (float)h0 * 1.0001f + (float)h1 + (float)(__bf16)r2 + 1e-3f;
-            }
-        }
-    }
-    float s = v[0] + v[1] + v[2] + v[3];
-    for (int i = 0; i < 16; ++i) s += acc0[i] + acc1[i];
-    for (int q = 0; q < 6; ++q) { for (int i = 0; i < 16; ++i) s += accs[q][i]; s += accs4[q][0] + accs4[q][3]; }
-    if (s == 12345.678f) sink[0] = s;
-}
-}  // namespace
-
-extern "C" int mydet_diag_busy(int kind, int iters, int lds_bytes, int blocks, float *sink, void *stream) {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)diag_busy_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute((const void *)diag_busy_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute((const void *)diag_busy_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute((const void *)diag_busy_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute((const void *)diag_busy_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute((const void *)diag_busy_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute((const void *)diag_busy_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr = true;
-    }
-    hipStream_t st = (hipStream_t)stream;
-    if (kind == 0) hipLaunchKernelGGL(diag_busy_kernel<0>, dim3(blocks), dim3(256), lds_bytes, st, sink, iters, 0.3f);
-    else if (kind == 1) hipLaunchKernelGGL(diag_busy_kernel<1>, dim3(blocks), dim3(256), lds_bytes, st, sink, iters, 0.3f);
-    else if (kind == 2) hipLaunchKernelGGL(diag_busy_kernel<2>, dim3(blocks), dim3(256), lds_bytes, st, sink, iters, 0.3f);
-    else if (kind == 4) hipLaunchKernelGGL(diag_busy_kernel<4>, dim3(blocks), dim3(256), lds_bytes, st, sink, iters, 0.3f);
-    else if (kind == 5) hipLaunchKernelGGL(diag_busy_kernel<5>, dim3(blocks), dim3(256), lds_bytes, st, sink, iters, 0.3f);
-    else if (kind == 6) hipLaunchKernelGGL(diag_busy_kernel<6>, dim3(blocks), dim3(256), lds_bytes, st, sink, iters, 0.3f);
-    else hipLaunchKernelGGL(diag_busy_kernel<3>, dim3(blocks), dim3(256), lds_bytes, st, sink, iters, 0.3f);
-    return mydet_launch_status();
-}
-#endif

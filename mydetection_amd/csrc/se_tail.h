@@ -138,12 +138,10 @@ __device__ __forceinline__ void se_tail_finish(const SeTail &t, float *lds, int 
     }
     __syncthreads();
     // expand conv + sigmoid: a thread per channel QUAD (16-byte rows of the transposed weight), k in order, eight rows in flight.
-    // The multiply-adds are written as v_fma_f32, one per channel: left to the compiler this loop became v_pk_fma_f32 pairs, and
-    // that build -- and only that one -- returned wrong LOW halves in lanes 48-63 of the finishing workgroup whenever the other
-    // batch lane's split-bf16 convs ran on the same CUs (found with two lanes + split-bf16 expand convs: a third of the gates off
-    // by 1e-2..2e-1 in every replay; sums of the shares and the hidden layer were right every time; with this form 0 of 2 x 400
-    // replays differ and every gate equals the one recomputed on the host: profiles/HISTORY.md, round 5).  Not understood beyond
-    // that; a stand-alone probe of v_pk_fma_f32 beside MFMA kernels (tools/hw_pk_fma_vs_mfma.hip) did not reproduce it.
+    // One v_fma_f32 per channel.  Round 5's build let the compiler pair these into v_pk_fma_f32, and THAT instruction returned
+    // wrong low halves in lanes 48-63 whenever waves of another kernel issued dense bf16 MFMAs on the same SIMD (the other batch
+    // lane's split-bf16 convs): reproduced stand-alone by tools/hw_pk_probe.hip, written up in profiles/r06_pk_fma_finding.md.
+    // The whole library is built without packed-f32 VALU ops since (csrc/Makefile: NOPK; a CPU test disassembles the library).
     for (int q = tid; q < Q; q += 256) {
         f32x4 e = *reinterpret_cast<const f32x4 *>(t.b2 + q * 4);
         int k = 0;
@@ -154,18 +152,12 @@ __device__ __forceinline__ void se_tail_finish(const SeTail &t, float *lds, int 
 #pragma unroll
             for (int j = 0; j < 8; ++j)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-#ifdef MYDET_SE_PK       // diagnostic build only (tools/r05_pk_repro.py): the compiler's own form of this loop (v_pk_fma_f32)
-                    e[c] = fmaf(w[j][c], hid[k + j], e[c]);
-#else
-                    asm("v_fma_f32 %0, %1, %2, %0" : "+v"(e[c]) : "v"(w[j][c]), "v"(hid[k + j]));
-#endif
-                }
+                for (int c = 0; c < 4; ++c) e[c] = fmaf(w[j][c], hid[k + j], e[c]);
         }
         for (; k < Cse; ++k) {
             const f32x4 w = *reinterpret_cast<const f32x4 *>(t.w2t + (int64_t)k * C + q * 4);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) asm("v_fma_f32 %0, %1, %2, %0" : "+v"(e[c]) : "v"(w[c]), "v"(hid[k]));
+            for (int c = 0; c < 4; ++c) e[c] = fmaf(w[c], hid[k], e[c]);
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) e[c] = mydet_sigmoid(e[c]);

@@ -319,6 +319,24 @@ def test_no_store_data_hazard_in_the_shipped_library():
     assert hazards == 0
 
 
+def test_no_packed_f32_valu_in_the_shipped_library():
+    """No v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 in any kernel of libmydet_hip.so (csrc/Makefile: NOPK for every translation
+    unit).  On MI355X the packed-f32 fma of one wave returned wrong low halves in lanes 48-63 while another wave of the SIMD
+    issued dense bf16 MFMAs (the other batch lane's split-bf16 convs; profiles/r06_pk_fma_finding.md, tools/hw_pk_probe.hip):
+    every kernel here can share a CU with those convs, so none may contain the packed forms -- no allow-list."""
+    import importlib.util
+    from mydetection_amd import _lib
+    if not os.path.exists('/opt/rocm/lib/llvm/bin/llvm-objdump'):
+        pytest.skip('no llvm-objdump on this machine')
+    spec = importlib.util.spec_from_file_location('check_store_hazard', os.path.join(ROOT, 'tools', 'check_store_hazard.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.PACKED_F32.match('v_pk_fma_f32 v[0:1], v[10:11], v[48:49], v[0:1] op_sel_hi:[1,0,1]')
+    assert not mod.PACKED_F32.match('v_pk_mov_b32 v[0:1], v[2:3], v[4:5]')
+    users = mod.packed_f32_users(_lib.LIB_PATH)
+    assert users == {}, sorted(users.items(), key=lambda kv: -kv[1])[:10]
+
+
 def test_no_kernel_spills_beyond_a_few_registers():
     """Scratch (private segment) use of every kernel in the shipped library, read from the code objects' metadata
     (tools/check_store_hazard.py: scratch_users).  A spilled register set runs through memory on every use: round 5 found the

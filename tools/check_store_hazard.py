@@ -59,6 +59,22 @@ def scratch_users(lib):
     return out
 
 
+PACKED_F32 = re.compile(r'^v_pk_(fma|mul|add)_f32\b')
+
+
+def packed_f32_users(lib):
+    """{kernel name: count} of v_pk_fma/mul/add_f32 instructions in `lib`.  Round 5/6 finding (profiles/r06_pk_fma_finding.md):
+    on MI355X a v_pk_fma_f32 of one wave returned wrong low halves in lanes 48-63 while ANOTHER wave of the SIMD issued dense
+    bf16 MFMAs; every kernel of this library can run beside the split-bf16 convs (two batch lanes), so the library is built
+    with -packed-fp32-ops off and must contain none."""
+    out = {}
+    for _, text in code_objects(lib):
+        for fn, ins in instructions(text):
+            if PACKED_F32.match(ins):
+                out[fn] = out.get(fn, 0) + 1
+    return out
+
+
 def instructions(text):
     """(function, mnemonic line) for every instruction line of an llvm-objdump listing."""
     fn = '?'
@@ -108,7 +124,11 @@ def main(lib):
           'directly by a VALU write of their data registers')
     for fn, st, nx in bad[:20]:
         print(f'  {fn[:70]}\n      {st}\n      {nx}')
-    return 1 if bad else 0
+    pk = packed_f32_users(lib)
+    print(f'{sum(pk.values())} packed-f32 VALU instructions (v_pk_fma/mul/add_f32) in {len(pk)} kernels')
+    for fn, c in sorted(pk.items(), key=lambda kv: -kv[1])[:20]:
+        print(f'  {c:5d}  {fn[:100]}')
+    return 1 if bad or pk else 0
 
 
 if __name__ == '__main__':
