@@ -365,6 +365,7 @@ def main():
                                         'note': 'the same step with every direct conv on v_mfma_f32_32x32x2_f32 (no split-bf16 kernels)',
                                         'wall_s': round(time.perf_counter() - t0, 1)}
     if out is not None:
+        out['summary'] = summary_of(out)          # LAST key, < 1 500 characters: what a 2 000-character tail of this line still shows
         print(json.dumps(out))
     if dist_on:
         torch.distributed.destroy_process_group()
@@ -375,6 +376,32 @@ def main():
 OTHER_CONFIGS = (('efficientdet-d1', 'efficientdet-d1_b16_640', 16, 640),        # BASELINE configs[2]
                  ('d1_fcs2_atss', 'd1_fcs2_atss_b32_640', 32, 640),             # BASELINE configs[3]
                  ('yolov3_80', 'yolov3_80_b32_512', 32, 512))                   # north_star: 512 x 512 batches as well
+
+
+def summary_of(out):
+    """Compact digest of the whole line (the driver's record keeps the tail of stdout only).  Per other config:
+    [images/s, ms_per_step, roofline frac, fused_min_frac, launches_per_lane, parity ok, margin_safe_pairs, detections per image at
+    the three thresholds of image 0]."""
+    def pc(o):
+        p_ = o.get('parity_check') or {}
+        d = p_.get('detections_per_image') or {}
+        return [p_.get('ok'), p_.get('margin_safe_pairs'), [v[0] for v in d.values() if v]]
+    s = {'value': out['value'], 'ms': out['ms_per_step'], 'frac': out['roofline'].get('frac'),
+         'traffic_x': (round(out['roofline']['traffic'] / out['roofline']['algorithmic_bytes_per_launch'], 2)
+                       if out['roofline'].get('traffic') and out['roofline'].get('algorithmic_bytes_per_launch') else None),
+         'launches_per_lane': out.get('launches_per_lane'), 'parity': pc(out),
+         'decode_frac_hbm': (out['stages'].get('decode') or {}).get('frac_hbm_peak'), 'nms_p50_ms': out.get('nms_p50_ms'),
+         'cpu_img_s': (out.get('cpu_baseline') or {}).get('value'), 'cpu_cores': (out.get('cpu_baseline') or {}).get('cores')}
+    if out.get('power'):
+        s['board_w'], s['sclk_mhz'] = out['power'].get('board_w'), out['power'].get('sclk_mhz')
+    if out.get('float32_mfma_only'):
+        s['float32_mfma_only'] = out['float32_mfma_only']['value']
+    if out.get('rccl_ranks') is not None:
+        s['rccl_ranks'], s['exchange_ms'] = out['rccl_ranks'], out.get('exchange_ms_per_step')
+    for k, o in (out.get('other_configs') or {}).items():
+        r = o['roofline']
+        s[k] = [o['value'], o['ms_per_step'], r.get('frac'), r.get('fused_min_frac'), o['launches_per_lane']] + pc(o)
+    return s
 
 
 def brief_line(o, wall_s):
