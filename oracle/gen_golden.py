@@ -100,8 +100,7 @@ def _gen_yolov3(model, cfg, batch, size, name, seed, thresholds):
             out[f'pp_{tag}_cats_{b}'] = _np(d.cats)
             out[f'pp_{tag}_scores_{b}'] = _np(d.scores)
             from oracle.postprocess import decision_margins
-            safe = [e for e in (1e-4, 5e-5, 2e-5, 1e-5, 5e-6, 2e-6, 1e-6, 5e-7, 2e-7)
-                    if decision_margins(out[f'scores_{b}'], out[f'cats_{b}'], conf, eps=e) is None]
+            safe = [e for e in MARGIN_LADDER if decision_margins(out[f'scores_{b}'], out[f'cats_{b}'], conf, eps=e) is None]
             out[f'pp_{tag}_margin'] = np.float64(min(float(out.get(f'pp_{tag}_margin', 1.0)), safe[0] if safe else 0.0))
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
     print(name, 'seed', seed, {t: float(out[f'pp_{t}_margin']) for t, _, _ in thresholds}, {k: (v.shape if hasattr(v, 'shape') else v) for k, v in out.items() if k.startswith('pp_ap')})
@@ -119,16 +118,35 @@ def _check_decision_margins(scores, cats, conf, what, eps=2e-5):
     assert why is None, f'{what}: {why}'
 
 
-def gen_efficientdet(config, size=256, batch=1, seeds=16):
-    """efficientdet-d1 / d1_fcs2_atss: stage samples, all candidates, post-processed detections.  The image seed is
-    the first one whose decisions are all margin-safe (_check_decision_margins); the fixture records it."""
+MARGIN_LADDER = (1e-4, 5e-5, 2e-5, 1e-5, 5e-6, 2e-6, 1e-6, 5e-7, 2e-7)
+
+
+def _margin(scores, cats, conf):
+    """Largest eps of the ladder at which no post-processing decision of these candidates hinges on round-off (0.0: none)."""
+    from oracle.postprocess import decision_margins
+    safe = [e for e in MARGIN_LADDER if decision_margins(scores, cats, conf, eps=e) is None]
+    return safe[0] if safe else 0.0
+
+
+def gen_efficientdet(config, size=256, batch=1, seeds=48):
+    """efficientdet-d1 / d1_fcs2_atss and the compositions: stage samples, all candidates, post-processed detections at three
+    settings.  The image seed is the one of the first `seeds` whose post-processing decisions are furthest from a boundary
+    (the smallest of the three settings' margins, first seed on ties); the fixture records the seed and the margins."""
     model, cfg = _refimport.build_reference_model(config)
+    best = (-1.0, None)
     for seed in range(seeds):
-        try:
-            return _gen_efficientdet(model, cfg, config, size, batch, seed)
-        except AssertionError as e:
-            print('  seed', seed, 'rejected:', e)
-    raise RuntimeError('no margin-safe image seed found')
+        x = (synth.make_images(batch, size, seed=seed) - MEAN) / STD
+        with torch.no_grad():
+            d = model(x)[0]
+        sc, ct = _np(d.scores), _np(d.cats)
+        m = min(_margin(sc, ct, conf) for conf in (0.005, 0.05, cfg['test.default_conf_thres']))
+        if m > best[0]:
+            best = (m, seed)
+        if m >= MARGIN_LADDER[0]:
+            break
+    print(' ', config, size, 'seed', best[1], 'margin', best[0])
+    assert best[0] >= 2e-5, 'no margin-safe image seed found'
+    return _gen_efficientdet(model, cfg, config, size, batch, best[1])
 
 
 def _gen_efficientdet(model, cfg, config, size, batch, seed):
@@ -185,10 +203,13 @@ def _gen_efficientdet(model, cfg, config, size, batch, seed):
             out[f'pp_{tag}_conf'], out[f'pp_{tag}_nms'] = np.float64(conf), np.float64(nms)
             out[f'pp_{tag}_bboxes_{b}'], out[f'pp_{tag}_cats_{b}'], out[f'pp_{tag}_scores_{b}'] = \
                 _np(d.bboxes), _np(d.cats), _np(d.scores)
-            _check_decision_margins(out[f'scores_{b}'], out[f'cats_{b}'], conf, f'{config} {tag}')
+            out[f'pp_{tag}_margin'] = np.float64(min(float(out.get(f'pp_{tag}_margin', 1.0)), _margin(out[f'scores_{b}'], out[f'cats_{b}'], conf)))
     name = config.replace('-', '_') + f'_b{batch}_{size}'
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
-    print(name, 'N', out['bboxes_0'].shape[0], 'dets', {t: out[f'pp_{t}_cats_0'].shape[0] for t in ('ap', 'mid', 'demo')})
+    print(name, 'N', out['bboxes_0'].shape[0], 'dets', {t: out[f'pp_{t}_cats_0'].shape[0] for t in ('ap', 'mid', 'demo')},
+          'classes', {t: len(np.unique(out[f'pp_{t}_cats_0'])) for t in ('ap', 'mid', 'demo')},
+          'pass', {t: int((out['scores_0'] >= float(out[f'pp_{t}_conf'])).sum()) for t in ('ap', 'mid', 'demo')},
+          'margins', {t: float(out[f'pp_{t}_margin']) for t in ('ap', 'mid', 'demo')})
 
 
 def gen_detlayers():
@@ -408,8 +429,8 @@ if __name__ == '__main__':
         gen_efficientdet('efficientdet-d1')
         gen_efficientdet('d1_fcs2_atss')
     if 'efficientdet_640' in which:     # BASELINE configs[2] / [3] resolution, pinned by the reference itself (batch 1)
-        gen_efficientdet('efficientdet-d1', size=640, seeds=40)
-        gen_efficientdet('d1_fcs2_atss', size=640, seeds=40)
+        gen_efficientdet('efficientdet-d1', size=640, seeds=int(os.environ.get('SCAN_SEEDS_N', '40')))
+        gen_efficientdet('d1_fcs2_atss', size=640, seeds=int(os.environ.get('SCAN_SEEDS_N', '40')))
     if 'fcos_variants' in which:        # registry plug-ins 'FCOS2' and 'effrpn_ct' + 'FCOS' 
         gen_efficientdet('d1_fcs2')
         gen_efficientdet('d1_fcs')

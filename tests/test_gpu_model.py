@@ -341,14 +341,44 @@ def _check_effdet_golden(name, m, g):
     np.testing.assert_allclose(d.scores.cpu().numpy(), g['scores_0'], rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(d.bboxes.cpu().numpy(), g['bboxes_0'], rtol=RTOL, atol=ATOL)
     _class_ids_exact_where_safe(d.cats.cpu().numpy(), g['cats_0'], g['cls_margin_0'], name)
+    # Detections at the three settings.  Round 6 (VERDICT r05 #2a): the head recipe (synth._EFDET_TARGETS) gives an objectness-like
+    # score distribution, so the settings decide different things -- at 640^2 more than 512 candidates pass 0.005 (the top-512 cut
+    # applies), fewer than 512 pass 0.05, 50-150 pass the demo threshold, >= 30 classes among the detections.  Each fixture
+    # records how far its decisions are from a boundary (pp_<tag>_margin): where that exceeds twice the score error observed
+    # here the detections must equal the reference's exactly; the 640^2 fixtures (margins >= 5e-5) must be exact at all three.
+    from oracle import postprocess as opp
+    cats, scores, boxes = d.cats.cpu().numpy(), d.scores.cpu().numpy(), d.bboxes.cpu().numpy()
+    err = float(np.abs(scores - g['scores_0']).max())
+    big = int(g['size']) >= 640
+    n_ap, n_mid, n_demo = (len(g[f'pp_{t}_cats_0']) for t in ('ap', 'mid', 'demo'))
+    p_ap, p_mid, p_demo = (int((g['scores_0'] >= float(g[f'pp_{t}_conf'])).sum()) for t in ('ap', 'mid', 'demo'))
+    assert n_ap > n_mid > n_demo >= 10, f'{name}: the three settings keep {n_ap} / {n_mid} / {n_demo} detections (vacuous fixture)'
+    if big:
+        assert p_ap > 512 > p_mid > p_demo >= 50 and n_demo >= 50, (p_ap, p_mid, p_demo, n_demo)
+        assert len(np.unique(g['pp_ap_cats_0'])) >= 30 and len(np.unique(g['pp_demo_cats_0'])) >= 10
+    exact_tags = 0
     for tag in ('ap', 'mid', 'demo'):
-        r = d.post_process(float(g[f'pp_{tag}_conf']), float(g[f'pp_{tag}_nms']))
+        conf, nms = float(g[f'pp_{tag}_conf']), float(g[f'pp_{tag}_nms'])
+        margin = float(g[f'pp_{tag}_margin'])
+        r = d.post_process(conf, nms)
+        ob, oc, os_, _ = opp.post_process(boxes, cats, scores, conf, nms)      # always: == the oracle's post-process of THESE candidates
+        assert len(r) == len(oc)
+        np.testing.assert_array_equal(r.cats.cpu().numpy(), oc)
+        np.testing.assert_array_equal(r.scores.cpu().numpy(), os_)
+        np.testing.assert_array_equal(r.bboxes.cpu().numpy(), ob)
         ref_c, ref_s, ref_b = g[f'pp_{tag}_cats_0'], g[f'pp_{tag}_scores_0'], g[f'pp_{tag}_bboxes_0']
-        assert len(ref_c) >= 50, 'vacuous fixture'
-        assert len(r) == len(ref_c), f'{tag}: {len(r)} vs {len(ref_c)} detections'
-        np.testing.assert_array_equal(r.cats.cpu().numpy(), ref_c)
-        np.testing.assert_allclose(r.scores.cpu().numpy(), ref_s, rtol=RTOL, atol=ATOL)
-        np.testing.assert_allclose(r.bboxes.cpu().numpy(), ref_b, rtol=RTOL, atol=ATOL)
+        same = len(r) == len(ref_c) and np.array_equal(r.cats.cpu().numpy(), ref_c)
+        if big:
+            assert margin > 2 * err, f'{name} {tag}: score error {err:.1e} is not inside the fixture margin {margin:.1e}'
+        if margin > 2 * err:
+            assert same, f'{name} {tag}: {len(r)} vs {len(ref_c)} detections although the margin {margin:.1e} > 2 x {err:.1e}'
+        if same:
+            exact_tags += 1
+            np.testing.assert_allclose(r.scores.cpu().numpy(), ref_s, rtol=RTOL, atol=ATOL)
+            np.testing.assert_allclose(r.bboxes.cpu().numpy(), ref_b, rtol=RTOL, atol=ATOL)
+        else:       # a decision inside the round-off band flipped: the sets may differ by the candidates involved
+            assert abs(len(r) - len(ref_c)) <= 4, f'{name} {tag}: {len(r)} vs {len(ref_c)} detections'
+    assert exact_tags >= (3 if big else 2), f'{name}: detections equal the reference\'s at only {exact_tags} of 3 settings (score error {err:.1e})'
 
 
 def _wino4_launches(fn):
@@ -398,6 +428,51 @@ def test_f4x4_kernels_vs_reference_goldens(model, golden, monkeypatch):
     _check_effdet_golden(name, m2, g2)
 
 
+def _family_launches(fn, family):
+    """Run fn() with the per-launch timer on; returns (result, number of launches of `family` it issued)."""
+    from mydetection_amd import ops
+    ops.TIMER = ops.KernelTimer()
+    try:
+        out = fn()
+    finally:
+        timer, ops.TIMER = ops.TIMER, None
+    torch.cuda.synchronize()
+    return out, len(timer.spans.get(family, []))
+
+
+def test_split_bf16_kernels_vs_reference_goldens(model, golden, monkeypatch):
+    """conv_igemm_b3_kernel (float32-exact three-piece bfloat16 operands on the bf16 matrix instruction; the SE-gated form for the
+    project convs) against the imported reference end to end (VERDICT r05 #2c).  The dispatch rules hand a layer to it only at
+    production sizes (8 192 rows and 3 GFLOP; 3 000 rows for the EfficientNet expand / gated project convs), so the batch-1
+    fixtures never reach it; with the limits at 1 every eligible direct conv takes it -- YOLOv3: the 1x1 layers, the stride-2 3x3
+    layers and the heads; EfficientNet-B1: every expand conv and every gated project conv with >= 64 outputs -- and the same
+    reference gates apply: every candidate within 1e-4, class ids, detections at the three settings
+    (reference: models/modules.py:76-95, external/efficientnet/model.py:71-98)."""
+    from mydetection_amd import ops, synth
+    from mydetection_amd.models.general import name_to_model
+    m, cfg = model
+    assert ops.SPLIT_BF16
+    for k, v in (('B3_MIN_ROWS', 1), ('B3_MIN_FLOP', 0.0), ('B3_EXPAND_MIN_ROWS', 1), ('B3_GATED_MIN_ROWS', 1)):
+        monkeypatch.setattr(ops, k, v)
+    g = golden('yolov3_b1_640')
+    x = synth.make_images(1, 640, seed=int(g['image_seed'])).cuda()
+    with torch.no_grad():
+        _, n3 = _family_launches(lambda: m.forward_candidates(x), 'conv_igemm_b3')
+    assert n3 >= 40, f'{n3} split-bf16 launches in the YOLOv3 forward (1x1, stride-2 3x3 and head convs expected)'
+    _check_yolo_golden(m, g, 'yolov3 640 on split-bf16', strict='margin-permitting')
+    _check_yolo_golden(m, golden('yolov3_b1_512'), 'yolov3 512 on split-bf16', strict='margin-permitting')
+    for name, least in (('efficientdet-d1', 30), ('d1_fcs2_atss', 30)):
+        m2, _ = name_to_model(name)
+        m2.load_state_dict(synth.make_state_dict(m2.state_dict(), name), strict=True)
+        m2 = m2.eval().cuda()
+        g2 = golden(name.replace('-', '_') + '_b1_640')
+        x2 = synth.make_normalized_images(1, 640, seed=int(g2['image_seed'])).cuda()
+        with torch.no_grad():
+            _, n3 = _family_launches(lambda: m2.forward_candidates(x2), 'conv_igemm_b3')
+        assert n3 >= least, f'{name}: {n3} split-bf16 launches (expand convs and gated project convs of the 23 MBConv blocks expected)'
+        _check_effdet_golden(name, m2, g2)
+
+
 def test_effdet_family_vs_oracle_640(effdet):
     """640x640 (benchmark resolution), batch 2, against the float32 CPU oracle (= the reference's arithmetic,
     tests/test_oracle_golden.py): every score and box within 1e-4 (rtol and atol), class ids exact wherever the
@@ -413,15 +488,15 @@ def test_effdet_family_vs_oracle_640(effdet):
     # two images all of whose decisions are margin-safe under the ORACLE's own float32 scores at both thresholds (a detection
     # set is only defined then): chosen here, deterministically, from the seed sequence 7, 8, ...
     chosen = []
-    for seed in range(7, 31):
+    for seed in range(7, 47):
         xi = synth.make_normalized_images(1, 640, seed=seed)
         with torch.no_grad():
             _, c1, s1 = oe.forward(xi, sd, name)
-        if all(opp.decision_margins(s1[0].numpy(), c1[0].numpy(), conf, eps=1e-5) is None for conf in (0.005, 0.5)):
+        if all(opp.decision_margins(s1[0].numpy(), c1[0].numpy(), conf, eps=4e-5) is None for conf in (0.005, 0.05, 0.5)):
             chosen.append(xi)
             if len(chosen) == 2:
                 break
-    assert len(chosen) == 2, f'{name}: no two margin-safe image seeds in 7..30'
+    assert len(chosen) == 2, f'{name}: no two margin-safe image seeds in 7..46'
     x = torch.cat(chosen, dim=0)
     with torch.no_grad():
         ob, oc, os_, margin = oe.forward(x, sd, name, with_margin=True)
@@ -432,12 +507,14 @@ def test_effdet_family_vs_oracle_640(effdet):
     for i in range(2):
         _class_ids_exact_where_safe(ci[i].cpu().numpy(), oc[i].numpy(), margin[i].numpy(), f'{name} 640 image {i}')
     flips = (ci.cpu() != oc)
-    for conf in (0.005, 0.5):
+    counts = []
+    for conf in (0.005, 0.05, 0.5):
         rec = batched_post_process(bb, ci, sc, conf, nms)
         for i in range(2):
             rb, rc, rs, src = opp.post_process(ob[i].numpy(), oc[i].numpy(), os_[i].numpy(), conf, nms)
             k = int(rec['count'][i])
-            assert len(src) >= 50
+            counts.append(k)
+            assert len(src) >= (50 if conf < 0.5 else 8)
             order = torch.argsort(os_[i], descending=True, stable=True)
             sel = order[os_[i][order] >= conf][:512]             # the candidates that enter NMS
             assert not flips[i][sel].any(), 'a class tie among the candidates that enter NMS'
@@ -448,6 +525,7 @@ def test_effdet_family_vs_oracle_640(effdet):
             np.testing.assert_array_equal(rec['class_idx'][i, :k].cpu().numpy(), rc)
             np.testing.assert_allclose(rec['score'][i, :k].cpu().numpy(), rs, rtol=RTOL, atol=ATOL)
             np.testing.assert_allclose(rec['bbox'][i, :k].cpu().numpy(), rb, rtol=RTOL, atol=ATOL)
+    assert counts[0] > counts[2] > counts[4] and counts[1] > counts[3] > counts[5], f'{name}: the thresholds decide the same thing: {counts}'
 
 
 @pytest.mark.parametrize('name', ['efficientdet-d1', 'd1_fcs2_atss'])
@@ -504,7 +582,9 @@ def test_effdet_full_size_properties_640(name, batch):
       * the hipGraph replay of the step equals the eager records;
       * NMS invariants per image (count <= 512, score >= conf, class ascending / score descending inside a class,
         kept boxes of one class pairwise IoU <= thr, unique indices pointing at their candidates), idempotence;
-      * the batched records equal the oracle's post_process on the GPU candidates for a sample of images."""
+      * the batched records equal the oracle's post_process on the GPU candidates for a sample of images;
+      * four images of the batch, evaluated as bench.py does (two batch lanes, split-bf16 expand / gated project convs, in-launch
+        squeeze-excite gates), against the CPU oracle forward: candidates 1e-4, class ids, detection sets (round 6)."""
     from mydetection_amd import synth
     from mydetection_amd.graph import GraphedPath
     from mydetection_amd.models.general import name_to_model
@@ -567,6 +647,54 @@ def test_effdet_full_size_properties_640(name, batch):
         k = int(cnt[i])
         assert k == len(src)
         np.testing.assert_array_equal(rec['index'][i, :k].cpu().numpy().astype(np.int64), src)
+    # Four images of THIS production batch against the CPU oracle forward (VERDICT r05 #2b), evaluated the way bench.py runs the
+    # step: two batch lanes replayed from one hipGraph, so the lane-sized dispatch is live -- split-bf16 expand convs, gated
+    # split-bf16 project convs, in-launch squeeze-excite gates (asserted below).  Every candidate within north_star's 1e-4, class
+    # ids exact where the oracle's two best classes are further apart than round-off; at each of three thresholds the kept
+    # candidates agree with the oracle's detections to >= 97 % (Jaccard), and exactly -- count, ids, classes, order -- on every
+    # (image, threshold) pair whose decisions are all further than twice the observed score error from flipping: at least three.
+    from mydetection_amd import ops
+    from oracle import efficientdet as oe
+    lane = batch // 2
+    assert ops.SPLIT_BF16 and ops.SE_IN_DW
+    assert ops.b3_takes(lane * 400, 192, 1152, 1, ops.B3_EXPAND_MIN_ROWS)                                     # expand conv, 20^2 stage
+    assert ops.b3_takes(lane * 400, 1152, 192, 1, ops.B3_GATED_MIN_ROWS, min_cout=ops.B3_GATED_MIN_COUT)       # gated project conv
+    run = GraphedPath(m, x, conf, thr, lanes=2)
+    assert run.lanes == 2
+    run()
+    torch.cuda.synchronize()
+    lb, lc, ls = (t.clone() for t in run.cand)
+    np.testing.assert_allclose(ls.cpu().numpy(), sc.cpu().numpy(), rtol=3e-5, atol=1e-5)         # lanes vs one stream: solo-vs-batch kind
+    sd_cpu = {k: v.cpu() for k, v in m.state_dict().items()}
+    pick = [0, lane - 1, lane, batch - 1]
+    with torch.no_grad():
+        ob, oc, os_, margin = oe.forward(x[pick].cpu(), sd_cpu, name, with_margin=True)
+    got_s, got_b, got_c = ls[pick].cpu().numpy(), lb[pick].cpu().numpy(), lc[pick].cpu().numpy()
+    np.testing.assert_allclose(got_s, os_.numpy(), rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(got_b, ob.numpy(), rtol=RTOL, atol=ATOL)
+    err = float(np.abs(got_s - os_.numpy()).max())
+    n_safe, worst, kept = 0, 1.0, []
+    for j, i in enumerate(pick):
+        _class_ids_exact_where_safe(got_c[j], oc[j].numpy(), margin[j].numpy(), f'{name} batch-{batch} image {i}')
+        for t in (conf, 0.05, 0.5):
+            _, rc, _, ri = pp.post_process(ob[j].numpy(), oc[j].numpy(), os_[j].numpy(), t, thr)
+            r_t = batched_post_process(lb[i:i + 1], lc[i:i + 1], ls[i:i + 1], t, thr)
+            k = int(r_t['count'][0])
+            kept.append(k)
+            mine = r_t['index'][0, :k].cpu().numpy().astype(np.int64)
+            assert k >= 8 and len(ri) >= 8, f'image {i} conf {t}: vacuous ({k} / {len(ri)} detections)'
+            jac = len(np.intersect1d(mine, ri)) / len(np.union1d(mine, ri))
+            worst = min(worst, jac)
+            assert jac >= 0.97, f'image {i} conf {t}: kept candidates agree to {jac:.3f} only ({k} vs {len(ri)})'
+            if pp.decision_margins(os_[j].numpy(), oc[j].numpy(), t, eps=max(2.0 * err, 2e-6)) is None:
+                n_safe += 1
+                assert k == len(ri), f'image {i} conf {t}: {k} vs {len(ri)} detections'
+                np.testing.assert_array_equal(mine, ri)
+                np.testing.assert_array_equal(r_t['class_idx'][0, :k].cpu().numpy(), rc)
+    print(f'{name} batch {batch} (two lanes) vs oracle: score error {err:.1e}, {n_safe} of {3 * len(pick)} pairs margin-safe and exact, '
+          f'worst Jaccard {worst:.4f}, detections per (image, threshold) {kept}')
+    assert all(kept[3 * j] > kept[3 * j + 1] > kept[3 * j + 2] for j in range(len(pick))), f'the thresholds decide the same thing: {kept}'
+    assert n_safe >= 3, f'only {n_safe} of {3 * len(pick)} (image, threshold) pairs are margin-safe at score error {err:.1e}'
 
 
 def test_device_preprocess_and_batched_detector(model):
@@ -802,7 +930,7 @@ def test_full_size_properties_batch32_640(model):
                 np.testing.assert_array_equal(mine, ri)
                 np.testing.assert_array_equal(r_t['class_idx'][0, :k].cpu().numpy(), rc)
     print(f'batch-32 vs oracle: score error {err:.1e}, {n_safe} of {3 * n_p} pairs margin-safe and exact, worst Jaccard {worst:.4f}')
-    assert n_safe >= 1, f'only {n_safe} of {3 * n_p} (image, threshold) pairs are margin-safe at score error {err:.1e}'
+    assert n_safe >= 3, f'only {n_safe} of {3 * n_p} (image, threshold) pairs are margin-safe at score error {err:.1e}'
 
 
 def test_hipgraph_replay_equals_eager(model):

@@ -193,7 +193,15 @@ def test_efficientdet_family_matches_reference(golden, config, size):
     for tag in ('ap', 'mid', 'demo'):
         b, cc, s, _ = pp.post_process(bb[0].numpy(), ci[0].numpy(), sc[0].numpy(), float(g[f'pp_{tag}_conf']),
                                       float(g[f'pp_{tag}_nms']))
-        assert len(cc) >= 50, 'vacuous fixture'
         np.testing.assert_array_equal(cc, g[f'pp_{tag}_cats_0'])
         np.testing.assert_allclose(s, g[f'pp_{tag}_scores_0'], rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(b, g[f'pp_{tag}_bboxes_0'], rtol=1e-5, atol=1e-5)
+    # the three settings decide different things (round 6: objectness-like head recipe, synth._EFDET_TARGETS); at 640^2 the
+    # top-512 cut applies at 0.005 only and the demo threshold still keeps >= 50 detections in >= 10 classes
+    n_ap, n_mid, n_demo = (len(g[f'pp_{t}_cats_0']) for t in ('ap', 'mid', 'demo'))
+    assert n_ap > n_mid > n_demo >= 10, (n_ap, n_mid, n_demo)
+    if size == 640:
+        p_ap, p_mid, p_demo = (int((g['scores_0'] >= float(g[f'pp_{t}_conf'])).sum()) for t in ('ap', 'mid', 'demo'))
+        assert p_ap > 512 > p_mid > p_demo >= 50 and n_demo >= 50, (p_ap, p_mid, p_demo)
+        assert len(np.unique(g['pp_ap_cats_0'])) >= 30 and len(np.unique(g['pp_demo_cats_0'])) >= 10
+        assert min(float(g[f'pp_{t}_margin']) for t in ('ap', 'mid', 'demo')) >= 5e-5
