@@ -222,10 +222,13 @@ D1_YV3_ANCHORS = [[12.6, 13.2], [23.5, 38.1], [57.3, 32.3], [42.9, 75.5], [106.6
 
 
 def class_margin(cls):
-    """Gap between the two largest class probabilities of every candidate, [B, n] in the decoders' flatten order
-    (class ids are only defined where it exceeds float32 round-off); cls [..., n_cls] logits."""
+    """How well defined the class id of every candidate is, [B, n] in the decoders' flatten order; cls [..., n_cls] logits.
+    The gap between the two largest class probabilities p1 - p2 where p1 >= 0.05; below that, the gap RELATIVE to p1, scaled so
+    that a relative gap of 4e-4 reads as 2e-5: round-off moves a probability by eps * p (1 - p) for a logit error eps, i.e. by a
+    fixed amount near p ~ 0.5 and by a fixed FRACTION where p is tiny (background candidates: p ~ 1e-9, gaps ~ 1e-10 absolute
+    and still a hundred times wider than round-off).  Class ids are compared where this exceeds 2e-5."""
     top2 = torch.sigmoid(cls).reshape(cls.shape[0], -1, cls.shape[-1]).topk(2, dim=-1).values
-    return top2[..., 0] - top2[..., 1]
+    return (top2[..., 0] - top2[..., 1]) * torch.clamp(0.05 / top2[..., 0].clamp_min(1e-38), min=1.0)
 
 
 def forward(x, sd, config, with_margin=False):

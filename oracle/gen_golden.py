@@ -177,8 +177,9 @@ def _gen_efficientdet(model, cfg, config, size, batch, seed):
             flat = _np(raw[k]).reshape(-1)
             idx = rng.integers(0, flat.size, size=256)
             out[f'head_{lvl}_{k}_idx'], out[f'head_{lvl}_{k}_val'] = idx, flat[idx]
-        top2 = torch.sigmoid(raw['class']).reshape(batch, -1, raw['class'].shape[-1]).topk(2, dim=-1).values
-        margins.append(top2[..., 0] - top2[..., 1])
+        # (gap of the two largest class probabilities; relative to the larger one where that is below 0.05: oracle.efficientdet.class_margin)
+        from oracle.efficientdet import class_margin
+        margins.append(class_margin(raw['class']))
     margins = torch.cat(margins, dim=1)
     for b in range(batch):
         out[f'cls_margin_{b}'] = _np(margins[b])
