@@ -458,7 +458,7 @@ def test_split_bf16_kernels_vs_reference_goldens(model, golden, monkeypatch):
     x = synth.make_images(1, 640, seed=int(g['image_seed'])).cuda()
     with torch.no_grad():
         _, n3 = _family_launches(lambda: m.forward_candidates(x), 'conv_igemm_b3')
-    assert n3 >= 40, f'{n3} split-bf16 launches in the YOLOv3 forward (1x1, stride-2 3x3 and head convs expected)'
+    assert n3 >= 35, f'{n3} split-bf16 launches in the YOLOv3 forward (1x1, stride-2 3x3 and head convs expected)'
     _check_yolo_golden(m, g, 'yolov3 640 on split-bf16', strict='margin-permitting')
     _check_yolo_golden(m, golden('yolov3_b1_512'), 'yolov3 512 on split-bf16', strict='margin-permitting')
     for name, least in (('efficientdet-d1', 30), ('d1_fcs2_atss', 30)):
@@ -525,7 +525,12 @@ def test_effdet_family_vs_oracle_640(effdet):
             np.testing.assert_array_equal(rec['class_idx'][i, :k].cpu().numpy(), rc)
             np.testing.assert_allclose(rec['score'][i, :k].cpu().numpy(), rs, rtol=RTOL, atol=ATOL)
             np.testing.assert_allclose(rec['bbox'][i, :k].cpu().numpy(), rb, rtol=RTOL, atol=ATOL)
-    assert counts[0] > counts[2] > counts[4] and counts[1] > counts[3] > counts[5], f'{name}: the thresholds decide the same thing: {counts}'
+    # (the two BASELINE configurations: three different sets per image; the registry compositions share the recipe but not its
+    # tuning -- d1_yv3 has 25 575 candidates and more than 512 of them can pass 0.05 as well)
+    if name in ('efficientdet-d1', 'd1_fcs2_atss'):
+        assert counts[0] > counts[2] > counts[4] and counts[1] > counts[3] > counts[5], f'{name}: the thresholds decide the same thing: {counts}'
+    else:
+        assert counts[0] >= counts[2] > counts[4] and counts[1] >= counts[3] > counts[5], f'{name}: the thresholds decide the same thing: {counts}'
 
 
 @pytest.mark.parametrize('name', ['efficientdet-d1', 'd1_fcs2_atss'])
@@ -891,7 +896,7 @@ def test_full_size_properties_batch32_640(model):
         k = int(cnt[i])
         assert k == len(src)
         np.testing.assert_array_equal(rec['index'][i, :k].cpu().numpy().astype(np.int64), src)
-    # six images of THIS production batch (F(4x4) on 31 layers, K-cut tails, the 128 x 128 tiles) against the CPU oracle
+    # sixteen images of THIS production batch (F(4x4) on 31 layers, K-cut tails, the 128 x 128 tiles) against the CPU oracle
     # forward: every candidate within north_star's 1e-4, class ids exact where the oracle's two best classes are further
     # apart than round-off; at each of three thresholds the kept candidates agree with the oracle's own detections to
     # >= 97 % (Jaccard index of the kept candidate ids: what differs are decisions inside the round-off band), and
@@ -899,7 +904,7 @@ def test_full_size_properties_batch32_640(model):
     # twice the observed score error from flipping (oracle.postprocess.decision_margins)
     from oracle import yolov3 as oy
     sd_cpu = {k: v.cpu() for k, v in m.state_dict().items()}
-    pick = [0, 5, 13, 20, 27, 31]
+    pick = list(range(0, 32, 2))        # sixteen images (~4 s of oracle forward on the box's 16 threads): 48 (image, threshold) pairs
     with torch.no_grad():
         ob, oc, os_, raws = oy.forward(x[pick].cpu(), sd_cpu, return_raw=True)
     got_s, got_b, got_c = sc[pick].cpu().numpy(), bb[pick].cpu().numpy(), ci[pick].cpu().numpy()
@@ -997,12 +1002,12 @@ def test_fused_retina_decode_equals_two_launch_path(monkeypatch, variant):
             w[0, 7], b[0, 7] = w[0, 3], b[0, 3]            # anchor 0: classes 3 and 7 are the same function
             b[0, 3] += 3.0
             b[0, 7] += 3.0                                  # ... and usually the maximum
-            b[1, 70:80] += 9.0                              # anchor 1: several classes above 5
-            b[2, 5] += 30.0
-            b[2, 60] += 31.0                                # anchor 2: two classes at sigmoid == 1.0: class 5 wins
+            b[1, 70:80] = 16.0                              # anchor 1: several classes above 5 (absolute: the recipe's own class bias is -7 .. -23 by level)
+            b[2, 5] = 45.0
+            b[2, 60] = 46.0                                 # anchor 2: two classes at sigmoid == 1.0: class 5 wins
             w[3, 70], b[3, 70] = w[3, 20], b[3, 20]         # anchor 3: a tie between lanes (classes 20 and 70)
-            b[3, 20] += 12.0
-            b[3, 70] += 12.0
+            b[3, 20] = 12.0
+            b[3, 70] = 12.0
             sd[wk], sd[bk] = w.view(A * C, -1, 1, 1), b.view(-1)
     m.load_state_dict(sd, strict=True)
     m = m.eval().cuda()
