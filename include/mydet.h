@@ -206,6 +206,19 @@ int mydet_conv2d_igemm_b3_f32(const float *x, int64_t ldx, const uint16_t *w_pla
                               const float *residual, int64_t ldr, const float *a_gate, void *workspace, int64_t workspace_bytes, float *y,
                               int64_t ldy, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_t,
                               int pad_l, int Ho, int Wo, int act, void *stream);
+/* 3x3 convolution, pad 1, stride 1 or 2, on the bfloat16 matrix instructions with the float32-exact split operands of
+ * mydet_conv2d_igemm_b3_f32 -- same w_planes, same six piece products, float32 accumulation -- but with the workgroup's INPUT
+ * PATCH resident in LDS (csrc/conv_p3.hip): a workgroup owns 8 x 16 output pixels x (64 | 128) output channels, loads and
+ * splits the patch of a 16-channel slab once and the nine taps read their matrix operands out of it at tap offsets, instead of
+ * gathering and splitting every input element once per tap (2.25 x at stride 2, 9 x at stride 1).  K order (slab, tap) instead of
+ * (tap, slab): results equal the other kernels' to float32 round-off (tests: 2e-5 * max|y| against float64).
+ *   y = act((conv3x3(x) * scale + shift)) + residual,  Ho = (H - 1) / stride + 1, Wo likewise;  act: MYDET_ACT_NONE | _LEAKY.
+ * Cin % 16 == 0, ldx % 4 == 0; MYDET_E_UNSUPP otherwise (the caller then uses mydet_conv2d_igemm_b3_f32 / _igemm_f32).
+ * Replaces the ATen chain of models/modules.py:76-95 for the stride-2 ConvBnLeaky layers of models/backbones.py:14-30 and the
+ * 32 -> 64 layer of the first DarkBlock (models/modules.py:56-73). */
+int mydet_conv3x3_p3_f32(const float *x, int64_t ldx, const uint16_t *w_planes, const float *scale, const float *shift,
+                         const float *residual, int64_t ldr, float *y, int64_t ldy, int B, int H, int W, int Cin, int Cout,
+                         int stride, int act, void *stream);
 /* Test hook: the split-bf16 launcher reads MYDET_B3_WIDE / MYDET_B3_WAVES once per process; this reads them again.
  * Returns the form bits (1 = wide 128 x 256 tiles from 192 output channels, 2 = 8-wave workgroups). */
 int mydet_conv_b3_reload_tuning(void);

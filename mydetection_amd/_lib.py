@@ -30,6 +30,7 @@ SIGNATURES = {
     'mydet_split_bf16_elems': [c_int, c_int],
     'mydet_split_bf16_f32': [c_ptr, c_int, c_int, c_ptr, c_ptr],
     'mydet_conv2d_igemm_b3_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_i64] + [c_int] * 13 + [c_ptr],
+    'mydet_conv3x3_p3_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64] + [c_int] * 7 + [c_ptr],
     'mydet_wino4_tail_plan': [c_int, c_int, c_int, c_int, c_int, c_int, c_ptr],
     'mydet_conv2d_wino4_f32': [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64] + [c_int] * 6 + [c_ptr],
     'mydet_dwconv_slices': [c_int, c_int, c_int, c_int, c_int],

@@ -1,0 +1,336 @@
+// 3x3 convolution (pad 1, stride 1 or 2) with float32-exact split-bf16 operands and an LDS-RESIDENT INPUT PATCH (round 6).
+//
+// conv_igemm_b3_kernel (conv_igemm.hip) gathers, for every one of the 9 taps, the tile's 128 x 16 activations from global
+// memory, cuts them into three bfloat16 pieces and stages them: every input element is loaded and split once per tap that
+// uses it -- 2.25 times for a stride-2 layer, 9 times for a stride-1 layer -- and that staging, not the matrix pipe, bounds
+// the launch (stride-2 128->256 @160^2: 0.36 ms of 0.66 are staging alone; profiles/HISTORY.md, round 5).
+// Here a workgroup owns a SPATIAL tile of TH x TW = 8 x 16 output pixels (128 MFMA rows) x BN output channels.  Per
+// 16-channel slab it loads the tile's input patch (17 x 33 pixels at stride 2, 10 x 18 at stride 1) ONCE, splits it once into
+// three bf16 planes in LDS, and the 9 taps read their MFMA A fragments straight out of that patch at a tap-dependent offset --
+// no im2col tile is ever written.  The weights come pre-split (mydet_split_bf16_f32: the planes conv_igemm_b3_kernel uses,
+// slab kt = tap * Cin/16 + slab) through a small LDS buffer per (slab, tap).
+//   global loads + split arithmetic per output pixel and slab: 561 / 128 = 4.4 pixels (stride 2; 9 before), 180 / 128 = 1.4
+//   (stride 1; 9 before).
+// Patch layout (one plane; 32 bytes = 16 bf16 per position, the two 16-byte halves swapped where sigma = 1):
+//   stride 2: position = py * 36 + (px & 1) * 17 + (px >> 1), sigma = ((px >> 1) >> 3) & 1   (columns split by parity: the 16
+//             pixels an MFMA row block reads for one tap are consecutive positions)
+//   stride 1: position = py * 24 + px, sigma = (px >> 3) & 1
+//   found by exhaustive search over (row length, swizzle) against the ds_read_b128 lane groups of MI355X_MICROARCH.md: every
+//   fragment read of every tap touches sixteen distinct 16-byte bank slots per lane group (conflict-free); the staging
+//   writes of 4 consecutive positions are 128 contiguous bytes.
+// Arithmetic: exactly conv_igemm_b3_kernel's (six piece products per k-step, small ones first, float32 accumulation), but
+// the K order is (slab, tap) instead of (tap, slab): results agree to float32 round-off, both are held to 2e-5 * max|y|
+// against float64 (tests/test_gpu_kernels.py).
+// Replaces the ATen conv2d / batch_norm / leaky_relu chain of models/modules.py:76-95 for the stride-2 layers of
+// models/backbones.py:14-30 and the 32 -> 64 layer of the first DarkBlock.
+#include <cstdlib>
+
+#include "common.h"
+
+namespace {
+
+constexpr unsigned OOB = 0xFFFFFFFFu;
+constexpr int P3_COUT_PAD = 256;                 // rows of the weight planes (split_bf16_kernel)
+
+struct P3Args {
+    const float *x, *scale, *shift, *res;
+    const unsigned short *wsplit;
+    float *y;
+    int64_t ldx, ldr, ldy;
+    int B, H, W, Cin, Cout, Ho, Wo;
+    int tx_n, ty_n, ntn, nblk;                   // spatial tiles per image row / column, channel tiles, workgroups
+};
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t p3_rsrc(const void *base, int64_t bytes) {
+    const uint64_t a = (uint64_t)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const int64_t capped = bytes > 0x7FFFFFF0ll ? 0x7FFFFFF0ll : bytes;
+    const int n = __builtin_amdgcn_readfirstlane((int)capped);
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, n, 0x00020000);
+}
+
+__device__ __forceinline__ void p3_split3(const f32x4 v, bf16x4 &p0, bf16x4 &p1, bf16x4 &p2) {       // == conv_igemm.hip: split3
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 h0 = (__bf16)v[e];
+        const float r1 = v[e] - (float)h0;
+        const __bf16 h1 = (__bf16)r1;
+        const float r2 = r1 - (float)h1;
+        p0[e] = h0; p1[e] = h1; p2[e] = (__bf16)r2;
+    }
+}
+
+template <int S> struct P3Geom;
+template <> struct P3Geom<2> { static constexpr int PH = 17, ROWLEN = 36, PJ0 = 17; };
+template <> struct P3Geom<1> { static constexpr int PH = 10, ROWLEN = 24, PJ0 = 0; };
+
+// S: stride.  BN: output channels per workgroup (64 | 128).  NBUF: LDS buffers of the weight tile (1: two barriers per tap).
+template <int S, int BN, int NBUF, int ACT, bool RES>
+__global__ __launch_bounds__(256, 2) void conv_p3_kernel(const P3Args p) {
+    constexpr int TH = 8, TW = 16, WM = 2, WN = 2, ROWB = 32;
+    constexpr int TM = 2, TN = BN / (WN * 32);
+    constexpr int PH = P3Geom<S>::PH, ROWLEN = P3Geom<S>::ROWLEN, PJ0 = P3Geom<S>::PJ0;
+    constexpr int PW = S * (TW - 1) + 3;
+    constexpr int NPOS = PH * ROWLEN;
+    constexpr int PLANE_P = NPOS * ROWB, PLANE_B = BN * ROWB;
+    constexpr int NCH = (NPOS * 4 + 255) / 256;      // 16-byte float4 chunks of the patch per thread and slab
+    constexpr int BCH = BN * 2;                      // 16-byte units of one weight plane per (slab, tap)
+    extern __shared__ __attribute__((aligned(16))) char smem_p3[];
+    char *patch = smem_p3, *bbase = smem_p3 + 3 * PLANE_P;
+
+    const int tid = threadIdx.x;
+    const int id = mydet_xcd_remap(blockIdx.x, p.nblk);
+    const int nt = id % p.ntn;                       // channel tiles of one spatial tile run together: the patch is shared through L2
+    int t = id / p.ntn;
+    const int tx = t % p.tx_n; t /= p.tx_n;
+    const int ty = t % p.ty_n;
+    const int b = t / p.ty_n;
+    const int oy0 = ty * TH, ox0 = tx * TW, n0 = nt * BN;
+    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+
+    // ---- descriptors.  x: the buffer starts one row + one pixel before image b, so that a patch origin of (-1, -1) is a
+    // non-negative offset (the range check sees the voffset only; those addresses are masked to OOB below and never touched)
+    const int64_t img = (int64_t)p.H * p.W * p.ldx;
+    const int64_t lead = (int64_t)(p.W + 1) * p.ldx;
+    const __amdgpu_buffer_rsrc_t xr = p3_rsrc(p.x + b * img - lead, ((p.B - b) * img + lead) * 4);
+    const int CoutP = (p.Cout + P3_COUT_PAD - 1) / P3_COUT_PAD * P3_COUT_PAD;
+    const int nsl = p.Cin >> 4;                      // 16-channel slabs
+    const __amdgpu_buffer_rsrc_t wr = p3_rsrc(p.wsplit, (int64_t)9 * nsl * 3 * CoutP * 32);
+
+    // ---- patch staging roles: chunk q = tid + 256 i = (position q >> 2, channel quad q & 3)
+    unsigned goff[NCH];                              // byte offset of the chunk's pixel (+ quad) in xr, OOB outside the image / padding
+    int ldst[NCH];                                   // byte offset of the chunk in a patch plane
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int q = tid + 256 * i, pos = q >> 2, sc = q & 3;
+        const int py = pos / ROWLEN, rem = pos - py * ROWLEN;
+        int px, sig;
+        bool ok = pos < NPOS;
+        if (S == 2) {
+            const int par = rem >= PJ0 ? 1 : 0, j = rem - par * PJ0;
+            px = 2 * j + par;
+            sig = (j >> 3) & 1;
+            ok = ok && px < PW && j < (par ? 16 : 17);
+        } else {
+            px = rem;
+            sig = (px >> 3) & 1;
+            ok = ok && px < PW;
+        }
+        const int iy = iy0 + py, ix = ix0 + px;
+        ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        goff[i] = ok ? (unsigned)((((int64_t)iy * p.W + ix) * p.ldx + sc * 4 + lead) * 4) : OOB;
+        ldst[i] = pos < NPOS ? pos * ROWB + (((sc >> 1) ^ sig) * 16) + (sc & 1) * 8 : -1;
+    }
+    // ---- weight staging role (as conv_igemm_b3_kernel): 16-byte unit `tid` of the tile's plane-slab
+    const bool bact = tid < BCH;
+    const int bu = tid & 63, brr = bu >> 1;
+    const int br = (tid >> 6) * 32 + brr, bh = (bu & 1) ^ ((brr >> 2) & 1);
+    const unsigned boff = bact ? (unsigned)(n0 * 32 + tid * 16) : OOB;
+    const int bdst = br * ROWB + ((bh ^ ((br >> 3) & 1)) * 16);
+    const unsigned plane_bytes = (unsigned)CoutP * 32u, slab_bytes = 3u * plane_bytes;
+
+    // ---- compute role
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int oxl = fr & 15;
+    int apos[TM];                                    // patch position of the lane's row for tap (0, 0)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int oyl = wm * (TM * 2) + i * 2 + (fr >> 4);
+        apos[i] = S == 2 ? (2 * oyl) * ROWLEN + oxl : oyl * ROWLEN + oxl;
+    }
+    const int b_off = (wn * TN * 32 + fr) * ROWB + ((fh ^ ((fr >> 3) & 1)) * 16);
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float pscl[TN], psft[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + fr;
+        const int nc = n < p.Cout ? n : 0;
+        pscl[j] = p.scale ? p.scale[nc] : 1.0f;
+        psft[j] = p.shift ? p.shift[nc] : 0.0f;
+    }
+
+    f32x4 preg[NCH];
+    u32x4 breg[3][3];                                // ring of three (slab, tap) steps in flight
+    auto load_patch = [&](int cs) {
+        const unsigned coff = (unsigned)cs * 64u;    // 16 channels * 4 bytes
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+            preg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (goff[i] != OOB && cs < nsl) ? goff[i] + coff : OOB, 0, 0));
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            if (ldst[i] < 0) continue;
+            bf16x4 q0, q1, q2;
+            p3_split3(preg[i], q0, q1, q2);
+            char *d = patch + ldst[i];
+            *reinterpret_cast<bf16x4 *>(d) = q0;
+            *reinterpret_cast<bf16x4 *>(d + PLANE_P) = q1;
+            *reinterpret_cast<bf16x4 *>(d + 2 * PLANE_P) = q2;
+        }
+    };
+    auto load_b = [&](int cs, int tap, u32x4 (&brg)[3]) {              // weights of (slab cs, tap): slab kt = tap * nsl + cs of the planes
+        const unsigned kt = (unsigned)(tap * nsl + cs);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            brg[pl] = __builtin_amdgcn_raw_buffer_load_b128(wr, cs < nsl ? boff : OOB,
+                                                            __builtin_amdgcn_readfirstlane(kt * slab_bytes + (unsigned)pl * plane_bytes), 0);
+    };
+    auto store_b = [&](int buf, const u32x4 (&brg)[3]) {
+        if (bact) {
+            char *d = bbase + buf * 3 * PLANE_B + bdst;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4 *>(d + pl * PLANE_B) = brg[pl];
+        }
+    };
+    auto compute = [&](int tap, int buf) {
+        const int kh = tap / 3, kw = tap - kh * 3;
+        bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            int pos, sig;
+            if (S == 2) {
+                pos = apos[i] + kh * ROWLEN + (kw & 1) * PJ0 + (kw >> 1);
+                sig = ((oxl + (kw >> 1)) >> 3) & 1;
+            } else {
+                pos = apos[i] + kh * ROWLEN + kw;
+                sig = ((oxl + kw) >> 3) & 1;
+            }
+            const char *a = patch + pos * ROWB + ((fh ^ sig) * 16);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) af[i][pl] = *reinterpret_cast<const bf16x8 *>(a + pl * PLANE_P);
+        }
+        const char *bb = bbase + buf * 3 * PLANE_B + b_off;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8 *>(bb + pl * PLANE_B + j * 32 * ROWB);
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};          // small piece products first
+#pragma unroll
+        for (int tt = 0; tt < 6; ++tt)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[tt]], bf[j][PB[tt]], acc[i][j], 0, 0, 0);
+    };
+
+    load_patch(0);
+    load_b(0, 0, breg[0]);
+    load_b(0, 1, breg[1]);
+    load_b(0, 2, breg[2]);
+    for (int cs = 0; cs < nsl; ++cs) {
+        if (cs > 0) __syncthreads();                 // every wave is done with the previous slab's patch (and its last weight tile)
+        store_patch();
+        load_patch(cs + 1);                          // in flight under the nine taps below
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int buf = NBUF == 2 ? (tap & 1) : 0;          // (nine taps per slab: with two buffers the parity flips from slab to slab,
+            const int rb = NBUF == 2 ? ((cs & 1) ^ buf) : 0;    //  so the buffer of a step is (cs + tap) & 1)
+            if (NBUF == 1 && tap > 0) __syncthreads();          // the single weight buffer is free again
+            store_b(rb, breg[tap % 3]);
+            const int t3 = tap + 3;
+            load_b(cs + t3 / 9, t3 % 9, breg[tap % 3]);
+            __syncthreads();
+            compute(tap, rb);
+        }
+    }
+
+    // ---- epilogue: lane = output channel, register = output pixel of the 2-row x 16-column block (row r of the block:
+    // (r >> 4, r & 15)); scale / shift / activation / residual as conv_igemm's
+    const int64_t opix = (int64_t)p.Ho * p.Wo;       // (descriptors per image: byte offsets stay inside one image's output)
+    const __amdgpu_buffer_rsrc_t yr = p3_rsrc(p.y + b * opix * p.ldy, opix * p.ldy * 4);
+    const __amdgpu_buffer_rsrc_t rr = p3_rsrc(RES ? p.res + b * opix * p.ldr : p.y, opix * (RES ? p.ldr : p.ldy) * 4);
+    const unsigned ldy4 = (unsigned)p.ldy * 4u, ldr4 = (unsigned)p.ldr * 4u;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + fr;
+        const bool nok = n < p.Cout;
+        const float scl = pscl[j], sft = psft[j];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int oyb = oy0 + wm * (TM * 2) + i * 2;         // first output row of the block
+            float rv[16];
+            unsigned off_y[16], off_r[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dr = (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int oy = oyb + (dr >> 4), ox = ox0 + (dr & 15);
+                const bool ok = nok && oy < p.Ho && ox < p.Wo;
+                const unsigned pix = (unsigned)(oy * p.Wo + ox);
+                off_y[r] = ok ? pix * ldy4 + (unsigned)n * 4u : OOB;
+                off_r[r] = ok ? pix * ldr4 + (unsigned)n * 4u : OOB;
+                if (RES) rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, off_r[r], 0, 0));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][j][r] * scl + sft;
+                if (ACT == MYDET_ACT_LEAKY) v = v > 0.0f ? v : v * 0.1f;
+                if (ACT == MYDET_ACT_SWISH) v = v * mydet_sigmoid_fast(v);
+                if (RES) v += rv[r];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, off_y[r], 0, 0);
+            }
+        }
+    }
+}
+
+template <int S, int BN, int NBUF, int ACT, bool RES>
+int p3_launch(const P3Args &p, hipStream_t st) {
+    constexpr int PLANE_P = P3Geom<S>::PH * P3Geom<S>::ROWLEN * 32, PLANE_B = BN * 32;
+    constexpr int LDS = 3 * PLANE_P + NBUF * 3 * PLANE_B;
+    auto kern = &conv_p3_kernel<S, BN, NBUF, ACT, RES>;
+    static bool attr = false;
+    if (!attr) {
+        const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(256), LDS, st, p);
+    return mydet_launch_status();
+}
+
+template <int S, int BN, int NBUF>
+int p3_dispatch(const P3Args &p, int act, bool res, hipStream_t st) {
+    if (act == MYDET_ACT_LEAKY) return res ? p3_launch<S, BN, NBUF, MYDET_ACT_LEAKY, true>(p, st) : p3_launch<S, BN, NBUF, MYDET_ACT_LEAKY, false>(p, st);
+    if (act == MYDET_ACT_NONE) return res ? p3_launch<S, BN, NBUF, MYDET_ACT_NONE, true>(p, st) : p3_launch<S, BN, NBUF, MYDET_ACT_NONE, false>(p, st);
+    return MYDET_E_UNSUPP;
+}
+
+}  // namespace
+
+extern "C" int mydet_conv3x3_p3_f32(const float *x, int64_t ldx, const uint16_t *w_planes, const float *scale, const float *shift,
+                                    const float *residual, int64_t ldr, float *y, int64_t ldy, int B, int H, int W, int Cin, int Cout,
+                                    int stride, int act, void *stream) {
+    if (!x || !w_planes || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return MYDET_E_BADARG;
+    if ((stride != 1 && stride != 2) || (Cin & 15) || (ldx & 3) || ldx < Cin || ldy < Cout || (residual && ldr < Cout)) return MYDET_E_UNSUPP;
+    if (((uintptr_t)x & 15) || ((uintptr_t)w_planes & 15)) return MYDET_E_BADARG;
+    P3Args p;
+    p.x = x; p.scale = scale; p.shift = shift; p.res = residual; p.wsplit = w_planes; p.y = y;
+    p.ldx = ldx; p.ldr = ldr; p.ldy = ldy;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.Ho = (H + 2 - 3) / stride + 1; p.Wo = (W + 2 - 3) / stride + 1;
+    // 32-bit byte offsets inside the kernel, relative to the workgroup's image: one image's input and output stay below 2 GB
+    if ((int64_t)(H + 1) * (W + 1) * ldx * 4 > 0x7FFFFFF0ll || (int64_t)p.Ho * p.Wo * (ldy > ldr ? ldy : ldr) * 4 > 0x7FFFFFF0ll) return MYDET_E_UNSUPP;
+    const bool wide = Cout > 64;
+    const int BN = wide ? 128 : 64;
+    p.tx_n = (p.Wo + 15) / 16; p.ty_n = (p.Ho + 7) / 8; p.ntn = (Cout + BN - 1) / BN;
+    const int64_t nblk = (int64_t)B * p.tx_n * p.ty_n * p.ntn;
+    if (nblk > 0x7FFFFFFF) return MYDET_E_UNSUPP;
+    p.nblk = (int)nblk;
+    hipStream_t st = (hipStream_t)stream;
+    if (stride == 2) return wide ? p3_dispatch<2, 128, 1>(p, act, residual != nullptr, st) : p3_dispatch<2, 64, 2>(p, act, residual != nullptr, st);
+    return wide ? p3_dispatch<1, 128, 2>(p, act, residual != nullptr, st) : p3_dispatch<1, 64, 2>(p, act, residual != nullptr, st);
+}

@@ -401,6 +401,39 @@ def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None
     return out
 
 
+def conv3x3_p3(x, b3, scale, shift, stride, act, residual=None, out=None, out_ld=None, cout=None):
+    """y = act(conv3x3_pad1(x) * scale + shift) + residual on the patch-resident split-bf16 kernel (csrc/conv_p3.hip,
+    include/mydet.h: mydet_conv3x3_p3_f32).  b3 = split_bf16(w_ohwi) of the [Cout, 3, 3, Cin] weight; cout = Cout (default: len(shift)).
+    Returns None when the kernel does not cover the shape (Cin % 16, activation): the caller then uses conv2d."""
+    require_gpu(x, 'conv3x3_p3')
+    x, ldx = to_nhwc(x)
+    B, Cin, H, W = x.shape
+    Cout = int(cout if cout is not None else (shift if shift is not None else scale).shape[0])
+    if Cin % 16 or stride not in (1, 2) or act not in (ACT_NONE, ACT_LEAKY) or b3 is None:
+        return None
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if out is None:
+        out, ldy = empty_nhwc(B, Cout, Ho, Wo, x.device, out_ld)
+    else:
+        ldy = nhwc_ld(out)
+        assert ldy is not None and out.shape == (B, Cout, Ho, Wo)
+    ldr = 0
+    if residual is not None:
+        residual, ldr = to_nhwc(residual)
+        assert residual.shape == out.shape
+    t0 = TIMER.start() if TIMER else None
+    code = _lib.lib().mydet_conv3x3_p3_f32(_ptr(x), ldx, _ptr(b3), _ptr(scale), _ptr(shift), _ptr(residual), ldr, _ptr(out), ldy,
+                                           B, H, W, Cin, Cout, stride, act, _stream())
+    if code == -2:
+        return None
+    if t0:
+        name = f'conv_p3 {Cin}->{Cout} k3s{stride} {H}x{W}' if TIMER_DETAIL else 'conv_p3'
+        b_in, b_out = 4.0 * B * H * W * Cin, 4.0 * B * Ho * Wo * Cout
+        TIMER.stop(name, t0, 2.0 * B * Ho * Wo * Cout * 9 * Cin, b_in + b_out + 4.0 * 9 * Cin * Cout + (b_out if residual is not None else 0.0))
+    _lib.check(code, 'mydet_conv3x3_p3_f32')
+    return out
+
+
 def conv2d_stem(x, w_ohwi, scale, shift, stride, pad, act):
     """3->32 3x3 first layer; reads x with its own strides (NCHW or channels-last)."""
     require_gpu(x, 'conv2d_stem')

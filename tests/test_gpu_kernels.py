@@ -112,6 +112,59 @@ def test_conv_split_bf16_vs_fp64(dev, case, monkeypatch):
         assert _lib.lib().mydet_conv_b3_reload_tuning() == 0
 
 
+@pytest.mark.parametrize('case', [
+    dict(B=4, Cin=32, Cout=64, s=2, H=64, W=64, act=1),                         # BN = 64 form, two slabs, whole tiles
+    dict(B=3, Cin=64, Cout=128, s=2, H=80, W=96, act=1),                        # BN = 128 form (single weight buffer)
+    dict(B=2, Cin=128, Cout=256, s=2, H=40, W=40, act=1),                       # 20 x 20 outputs: ragged tiles in both directions, two channel tiles
+    dict(B=3, Cin=48, Cout=192, s=2, H=37, W=53, act=0, bias_only=True),        # odd sizes, no activation, half-empty second channel tile
+    dict(B=2, Cin=32, Cout=64, s=1, H=48, W=64, act=1, residual=True),          # stride 1 (the 32 -> 64 layer of the first DarkBlock) + residual
+    dict(B=2, Cin=64, Cout=160, s=1, H=21, W=35, act=1, strided=True),          # stride 1, BN = 128, ragged, input a channel slice / padded output rows
+    dict(B=5, Cin=16, Cout=40, s=2, H=30, W=18, act=1, residual=True, strided=True),   # one slab, ragged channels (40 of 64), residual
+    dict(B=32, Cin=64, Cout=128, s=2, H=64, W=64, act=1),                       # 4 096 workgroups (XCD remap, several rounds)
+])
+def test_conv_p3_vs_fp64(dev, case):
+    """conv_p3_kernel (csrc/conv_p3.hip: 3x3 conv with the workgroup's input patch resident in LDS, split-bf16 operands): held to the
+    same 2e-5 * max|y| against float64 as conv_igemm_kernel / conv_igemm_b3_kernel, agrees with the float32 kernel to float32
+    round-off, and is bit-repeatable."""
+    from mydetection_amd import ops
+    B, Cin, Cout, s, H, W = (case[n] for n in ('B', 'Cin', 'Cout', 's', 'H', 'W'))
+    g = torch.Generator().manual_seed(3 * Cin + Cout + s)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    scale = None if case.get('bias_only') else torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g) * 0.1
+    ref = F.conv2d(F.pad(x.double(), (1, 1, 1, 1)), w.double(), None, s)
+    ref = ref * (scale.double().view(1, -1, 1, 1) if scale is not None else 1.0) + shift.double().view(1, -1, 1, 1)
+    if case['act'] == 1:
+        ref = F.leaky_relu(ref, 0.1)
+    res = None
+    if case.get('residual'):
+        res = torch.randn(ref.shape, generator=g)
+        ref = ref + res.double()
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last)
+    if case.get('strided'):
+        wide = torch.randn(B, Cin + 24, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        wide[:, 8:8 + Cin] = xd
+        xd = wide[:, 8:8 + Cin]
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    w3 = ops.split_bf16(wd)
+    rd = res.to(dev).contiguous(memory_format=torch.channels_last) if res is not None else None
+    kw = dict(out_ld=Cout + 12) if case.get('strided') else {}
+    sc_d, sh_d = (scale.to(dev) if scale is not None else None), shift.to(dev)
+    y = ops.conv3x3_p3(xd, w3, sc_d, sh_d, s, case['act'], residual=rd, **kw)
+    assert y is not None and tuple(y.shape) == tuple(ref.shape)
+    y2 = ops.conv3x3_p3(xd, w3, sc_d, sh_d, s, case['act'], residual=rd, **kw)
+    assert torch.equal(y, y2)
+    y32 = ops.conv2d(xd, wd, sc_d, sh_d, 3, s, (1, 1, 1, 1), case['act'], residual=rd, **kw)
+    tol = 2e-5 * ref.abs().max().item()
+    err = (y.cpu().double() - ref).abs().max().item()
+    err32 = (y32.cpu().double() - ref).abs().max().item()
+    assert err <= tol, f'{case}: {err:.2e} vs tol {tol:.2e} (float32 kernel: {err32:.2e})'
+    assert err <= 4.0 * err32 + 1e-6, (err, err32)
+    if case.get('strided'):              # nothing written behind the Cout channels of a padded output row
+        assert ops.nhwc_ld(y) == Cout + 12
+
+
 def _split_bf16_case(dev, case):
     from mydetection_amd import ops
     B, Cin, Cout, k, s, H, W = (case[n] for n in ('B', 'Cin', 'Cout', 'k', 's', 'H', 'W'))
