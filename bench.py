@@ -669,6 +669,8 @@ def measure(args, ctx):
                    'conv_igemm_b3': ('conv_igemm_b3_kernel (the same implicit GEMM with float32-exact split operands: three bfloat16 '
                                      'pieces per operand, six v_mfma_f32_32x32x16_bf16 piece products per k-step, float32 accumulation)',
                                      6.0, PEAK_BF16_MFMA_TFLOPS),
+                   'conv_p3': ('conv_p3_kernel (3x3 conv, input patch resident in LDS, split-bf16 operands: six v_mfma_f32_32x32x16_bf16 piece products per k-step)',
+                               6.0, PEAK_BF16_MFMA_TFLOPS),
                    'conv_wino': ('conv_wino_kernel (fused Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32)', 1 / 2.25, PEAK_FP32_MFMA_TFLOPS),
                    'conv_wino4': ('wino4_input_kernel + conv_wino4_kernel (Winograd F(4x4,3x3): input-transform launch + DMA-fed '
                                   'v_mfma_f32_16x16x4_f32 GEMMs with fused output transform, + the K-cut tail\'s piece and fixup '
@@ -680,7 +682,7 @@ def measure(args, ctx):
         for k, (n_f, ms_f, fl_f) in fams.items():
             stages[k]['algorithmic_TFLOPs'] = round(fl_f / (ms_f * 1e-3) / 1e12, 2)
             stages[k]['mfma_frac'] = round(fl_f * kernels[k][1] / (ms_f * 1e-3) / 1e12 / kernels[k][2], 4)
-            if k == 'conv_igemm_b3':
+            if k in ('conv_igemm_b3', 'conv_p3'):
                 stages[k]['mfma_frac_note'] = ('6 x the algorithmic FLOPs issued on the bfloat16 pipe / its 2 516.6 TFLOP/s dense peak; the '
                                                'float32 matrix instruction would need algorithmic_TFLOPs / 157.3 = '
                                                f'{fl_f / (ms_f * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS:.2f} of its peak for this time')

@@ -324,13 +324,20 @@ extern "C" int mydet_conv3x3_p3_f32(const float *x, int64_t ldx, const uint16_t 
     p.Ho = (H + 2 - 3) / stride + 1; p.Wo = (W + 2 - 3) / stride + 1;
     // 32-bit byte offsets inside the kernel, relative to the workgroup's image: one image's input and output stay below 2 GB
     if ((int64_t)(H + 1) * (W + 1) * ldx * 4 > 0x7FFFFFF0ll || (int64_t)p.Ho * p.Wo * (ldy > ldr ? ldy : ldr) * 4 > 0x7FFFFFF0ll) return MYDET_E_UNSUPP;
-    const bool wide = Cout > 64;
+    // MYDET_P3_FORM (experiments): 1 = 64-channel tiles whatever Cout, 2 = 128-channel tiles with two weight buffers (one workgroup per CU at stride 2)
+    const char *fe = getenv("MYDET_P3_FORM");
+    const int form = fe ? atoi(fe) : 0;
+    const bool wide = Cout > 64 && form != 1;
     const int BN = wide ? 128 : 64;
     p.tx_n = (p.Wo + 15) / 16; p.ty_n = (p.Ho + 7) / 8; p.ntn = (Cout + BN - 1) / BN;
     const int64_t nblk = (int64_t)B * p.tx_n * p.ty_n * p.ntn;
     if (nblk > 0x7FFFFFFF) return MYDET_E_UNSUPP;
     p.nblk = (int)nblk;
     hipStream_t st = (hipStream_t)stream;
-    if (stride == 2) return wide ? p3_dispatch<2, 128, 1>(p, act, residual != nullptr, st) : p3_dispatch<2, 64, 2>(p, act, residual != nullptr, st);
-    return wide ? p3_dispatch<1, 128, 2>(p, act, residual != nullptr, st) : p3_dispatch<1, 64, 2>(p, act, residual != nullptr, st);
+    const bool res = residual != nullptr;
+    if (stride == 2) {
+        if (!wide) return p3_dispatch<2, 64, 2>(p, act, res, st);
+        return form == 2 ? p3_dispatch<2, 128, 2>(p, act, res, st) : p3_dispatch<2, 128, 1>(p, act, res, st);
+    }
+    return wide ? p3_dispatch<1, 128, 2>(p, act, res, st) : p3_dispatch<1, 64, 2>(p, act, res, st);
 }

@@ -299,6 +299,25 @@ def b3_takes(M, Cin, Cout, k, min_rows=None, min_cout=128):
     return M >= B3_MIN_ROWS and 2.0 * M * k * k * Cin * Cout >= B3_MIN_FLOP
 
 
+# conv_p3_kernel (csrc/conv_p3.hip: 3x3 conv with the workgroup's input patch resident in LDS, split-bf16 operands) takes a 3x3 pad-1
+# layer when its 8 x 16-pixel output tiles are whole (Ho % 8 == 0, Wo % 16 == 0: ragged tiles waste their rows -- 256->512 @80->40
+# runs 0.67 vs 0.64 ms, 512->1024 @40->20 0.94 vs 0.69), the launch is production-sized (P3_MIN_ROWS output pixels) and
+#   stride 2: always (the first three stride-2 layers of Darknet-53 at 640^2: 1.07-1.11 x over conv_igemm_b3_kernel);
+#   stride 1: only below WINO4_MIN_CIN input channels, where F(4x4) does not go (32->64 @320^2: 1.16-1.18 x over F(2x2)).
+# profiles/r06_conv_p3.txt.  MYDET_CONV_P3=0 turns it off.
+CONV_P3 = os.environ.get('MYDET_CONV_P3', '1') != '0'
+P3_MIN_ROWS = int(os.environ.get('MYDET_P3_MIN_ROWS', '65536'))
+
+
+def p3_takes(B, Ho, Wo, Cin, Cout, k, stride, pad):
+    """True when conv2d(..., b3=) hands the layer to conv3x3_p3."""
+    if not (CONV_P3 and SPLIT_BF16) or k != 3 or stride not in (1, 2) or tuple(pad) != (1, 1, 1, 1) or Cin % 16:
+        return False
+    if Ho % 8 or Wo % 16 or B * Ho * Wo < P3_MIN_ROWS:
+        return False
+    return stride == 2 or Cin < WINO4_MIN_CIN
+
+
 def split_bf16(w_ohwi):
     """The weight operand of `conv2d(..., b3=)`: the OHWI weight [Cout, kh, kw, Cin] as three bfloat16 planes, w = p0 + p1 + p2 to
     2^-27 |w|, in the split-bf16 kernels' slab-major order (include/mydet.h: mydet_split_bf16_f32); int16 storage.
@@ -346,6 +365,10 @@ def conv2d(x, w_ohwi, scale, shift, k, stride, pad, act, residual=None, out=None
     if residual is not None:
         residual, ldr = to_nhwc(residual)
         assert residual.shape == out.shape
+    if b3 is not None and gate is None and act in (ACT_NONE, ACT_LEAKY) and p3_takes(B, Ho, Wo, Cin, Cout, k, stride, pad):
+        y = conv3x3_p3(x, b3, scale, shift, stride, act, residual=residual, out=out, cout=Cout)
+        if y is not None:
+            return y
     if (wino4 is not None and WINOGRAD and WINOGRAD4 and gate is None and k == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1)
             and ldy % 4 == 0 and ldr % 4 == 0 and (wino is None or wino4_items(B, H, W, Cout) >= WINO4_MIN_ITEMS)):
         ws = wino4_workspace(x.device, _lib.lib().mydet_wino4_workspace_bytes(B, H, W, Cin, Cout))
