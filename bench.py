@@ -804,6 +804,10 @@ def measure(args, ctx):
     if dist_on:
         out['rccl_ranks'] = torch.distributed.get_world_size()
         out['exchange_backend'] = str(torch.distributed.get_backend())
+        # the line's n_gpus is a claim about what exchanged records: every rank of the RCCL group is one of the N GPUs
+        assert out['rccl_ranks'] == world == args.gpus, (out['rccl_ranks'], world, args.gpus)
+        assert out['exchange_backend'] == 'nccl', out['exchange_backend']
+        out['rccl_ranks_equal_n_gpus'] = True
         out['exchange_ms_per_step'] = round(sum(a.elapsed_time(b) for a, b in exchange) / max(1, len(exchange)), 4)
         out['exchange_note'] = ('HIP events on the launch stream around the one all_gather_into_tensor of the step (rank 0; it includes '
                                 'waiting for the slowest rank to arrive)')

@@ -130,6 +130,7 @@ typedef struct {
     const float *w1, *b1, *w2t, *b2;
     float *gate, *hpart;
     int Cse;
+    int64_t hpart_bytes;      /* size of hpart: >= 4 * (MYDET_SE_EPOCH_WORDS + 2 * B * groups * Cse), checked by every entry point */
 } mydet_se_tail;
 int mydet_dwconv_slices(int Ho, int Wo, int C, int K, int stride);
 /* workgroups per image of the kernel mydet_dwconv_f32 picks for the layer when it also emits the squeeze (sizes se->hpart) */
@@ -199,7 +200,9 @@ int mydet_conv1x1_upcat_f32(const float *x_lo, int64_t ld_lo, int C_lo, const fl
  * made ONCE per layer by mydet_split_bf16_f32 into mydet_split_bf16_elems(Cout, K) uint16; a_gate (optional, 1x1 layers without an
  * activation: the squeeze-excite project convs) multiplies the activations per image and channel before they are split.  Cin % 16 == 0 (1x1 layers: Cin % 4 == 0, the
  * last 16-channel slab of the planes zero-filled by mydet_split_bf16_f32);
- * MYDET_E_UNSUPP otherwise (the caller then uses mydet_conv2d_igemm_f32).  Replaces the same reference lines. */
+ * MYDET_E_UNSUPP otherwise (the caller then uses mydet_conv2d_igemm_f32).  Replaces the same reference lines.
+ * Finite tensors only: an infinite operand, or a finite one of magnitude >= 3.39e38 (it rounds to a bfloat16 inf), yields NaN where
+ * the float32 kernel and the reference yield inf (the split forms inf - inf); NaN propagates as NaN. */
 int64_t mydet_split_bf16_elems(int Cout, int K);      /* uint16 elements of the operand below (0: K % 4 != 0) */
 int mydet_split_bf16_f32(const float *w, int Cout, int K, uint16_t *planes, void *stream);
 int mydet_conv2d_igemm_b3_f32(const float *x, int64_t ldx, const uint16_t *w_planes, const float *scale, const float *shift,

@@ -91,7 +91,8 @@ class DecodeLevel(ctypes.Structure):
 
 class SeTail(ctypes.Structure):
     """mydet_se_tail (include/mydet.h): the squeeze-excite tail finished inside the depthwise launch."""
-    _fields_ = [('w1', c_ptr), ('b1', c_ptr), ('w2t', c_ptr), ('b2', c_ptr), ('gate', c_ptr), ('hpart', c_ptr), ('Cse', c_int)]
+    _fields_ = [('w1', c_ptr), ('b1', c_ptr), ('w2t', c_ptr), ('b2', c_ptr), ('gate', c_ptr), ('hpart', c_ptr), ('Cse', c_int),
+                ('hpart_bytes', c_i64)]
 
 
 SE_EPOCH_WORDS = 1024               # MYDET_SE_EPOCH_WORDS of include/mydet.h

@@ -349,8 +349,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
 // Workgroup = 4 waves, tile BM x BN = 128 x (128 | 64), wave tile 64 x (64 | 32), K in slabs of 16 (one MFMA k-step).
 // Activations are split while they are staged (global float32 -> registers -> three bf16 planes in LDS: ~7 VALU per
 // element, once per element and tile), the weights arrive pre-split from `wsplit` (mydet_split_bf16_f32, once per layer).
-// LDS rows of a plane: 16 bf16 + 8 pad = 48 bytes (fragment ds_read_b128 conflict-free); two slab buffers = 72 KB at 128 x 128:
-// two workgroups per CU as for the float32 tiles.  Cin % 16 == 0 (a slab never straddles taps).
+// LDS rows of a plane: the 32 bytes of a row's 16 k-values, unpadded, the two 16-byte halves swapped where bit 3 of the row is set
+// (fragment reads AND staging writes conflict-free); two slab buffers = 48 KB at 128 x 128: two to three workgroups per CU.
+// Cin % 16 == 0 (a slab never straddles taps; 1x1 layers: Cin % 4 == 0, the last slab zero-filled).
+// Non-finite inputs: bf16(inf) = inf and inf - inf = NaN, so an infinite activation or weight becomes NaN (the float32 kernel and
+// the reference propagate inf), and a finite |x| >= 2^127 * (2 - 2^-8) ~ 3.39e38 rounds up to a bfloat16 inf -> NaN as well;
+// NaN stays NaN.  A deliberate deviation (pinned by test_split_bf16_non_finite_semantics): the kernels are for
+// finite tensors, and guarding the split costs two vector-ALU instructions per element in the loop that bounds these kernels.
 constexpr int B3_COUT_PAD = 256;            // rows of the weight operand are padded to this (split_bf16_kernel)
 __device__ __host__ __forceinline__ int b3_unit(int rr, int h) { return 2 * rr + (h ^ ((rr >> 2) & 1)); }
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

@@ -18,7 +18,7 @@
 
 namespace {
 
-const SeTail NO_SE_TAIL = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+const SeTail NO_SE_TAIL = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
 
 // --------------------------------------------------------------------------------------------- depthwise
 struct DwArgs {
@@ -842,7 +842,7 @@ extern "C" int mydet_dwconv_f32(const float *x, int64_t ldx, const float *w, con
     p.x = x; p.w = w; p.scale = scale; p.shift = shift; p.y = y; p.partial = se_partial; p.ldx = ldx; p.ldy = ldy;
     p.C = C; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.pad_t = pad_t; p.pad_l = pad_l; p.act = act; p.S = S; p.total = 0;
     p.se = se ? *se : NO_SE_TAIL;
-    if (const int e = mydet_se_tail_check(p.se, C, B)) return e;
+    if (const int e = mydet_se_tail_check(p.se, C, B, p.se.gate ? mydet_dwconv_se_groups(Ho, Wo, C, K, stride) : 1)) return e;
     if (p.se.gate && (S <= 0 || S > 4096 || B > 65535)) return MYDET_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     if ((se_partial || p.se.gate) && S != mydet_dwconv_slices(Ho, Wo, C, K, stride)) return MYDET_E_BADARG;

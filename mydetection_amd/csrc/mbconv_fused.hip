@@ -283,9 +283,9 @@ extern "C" int mydet_mbconv_expand_dw_f32(const float *x, int64_t ldx, const flo
     p.x = x; p.we = w_expand; p.shift0 = shift0; p.wd = w_dw; p.shift1 = shift1;
     p.y = y; p.partial = se_partial; p.ldx = ldx; p.ldy = ldy; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.Cin = Cin;
     p.Cexp = Cexp; p.pad_t = pad_t; p.pad_l = pad_l; p.S = S;
-    const SeTail none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    const SeTail none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
     p.se = se ? *se : none;
-    if (const int e = mydet_se_tail_check(p.se, Cexp, B)) return e;
+    if (const int e = mydet_se_tail_check(p.se, Cexp, B, S)) return e;
     hipStream_t st = (hipStream_t)stream;
     // the (kernel, stride, Cin) combinations of EfficientNet-B0..B2 stages 2-4 (external/efficientnet/utils.py:258-263)
     if (K == 3 && stride == 2 && Cin == 16) return launch<3, 2, 16>(p, B, st);

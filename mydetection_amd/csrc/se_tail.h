@@ -64,7 +64,8 @@ __device__ __forceinline__ void se_fc1_accumulate(const SeTail &t, int C, const 
 // The share buffer (include/mydet.h: mydet_se_tail.hpart), 8-byte aligned, 32-bit words:
 //     [0]                         the launch counter (never 0; 1 when the buffer is made)
 //     [1]                         images finished in the running launch (0 between launches)
-//     [2, MYDET_SE_EPOCH_WORDS)   unused
+//     [2]                         finishing workgroups that gave up their poll and wrote a NaN gate (never reset; 0 in a healthy run)
+//     [3, MYDET_SE_EPOCH_WORDS)   unused
 //     then [B][nwg][Cse] pairs    (value, epoch) of workgroup wg's share of hidden unit o; all zero when the buffer is made
 constexpr int MYDET_SE_EPOCHS = MYDET_SE_EPOCH_WORDS;
 
@@ -118,7 +119,11 @@ __device__ __forceinline__ void se_tail_finish(const SeTail &t, float *lds, int 
             }
         }
         if (!__syncthreads_or(missing)) break;
-        if (++spins >= (1 << 14)) { ok = false; break; }        // (uniform: every thread sees the same vote and count)
+        if (++spins >= (1 << 14)) {                              // (uniform: every thread sees the same vote and count)
+            ok = false;                                          // the gate becomes NaN below AND the give-up is counted in the header,
+            if (tid == 0) __hip_atomic_fetch_add(reinterpret_cast<unsigned *>(t.hpart) + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;                                               // where ops.se_tail_timeouts / a C caller can see it
+        }
         __builtin_amdgcn_s_sleep(2);
     }
     if (tid == 0) {      // this image is finished; the last one of the launch hands the next launch a new epoch (never 0)
@@ -166,12 +171,13 @@ __device__ __forceinline__ void se_tail_finish(const SeTail &t, float *lds, int 
 }
 
 // host side: arguments of an in-launch tail are complete and inside the kernels' limits
-static inline int mydet_se_tail_check(const SeTail &t, int C, int B) {
+static inline int mydet_se_tail_check(const SeTail &t, int C, int B, int groups) {
     if (!t.gate) return 0;
-    (void)B;
     if (!t.w1 || !t.b1 || !t.w2t || !t.b2 || !t.hpart) return MYDET_E_BADARG;
     if (((uintptr_t)t.w1 & 15) || ((uintptr_t)t.w2t & 15) || ((uintptr_t)t.b2 & 15) || ((uintptr_t)t.gate & 15) || (C & 3)) return MYDET_E_BADARG;
     if ((uintptr_t)t.hpart & 7) return MYDET_E_BADARG;
     if (t.Cse < 1 || t.Cse > MYDET_SE_MAX_CSE) return MYDET_E_UNSUPP;
+    // the share buffer holds the header and one (value, epoch) pair per image, workgroup of the image and hidden unit
+    if (B < 1 || groups < 1 || t.hpart_bytes < 4 * ((int64_t)MYDET_SE_EPOCH_WORDS + 2 * (int64_t)B * groups * t.Cse)) return MYDET_E_BADARG;
     return 0;
 }

@@ -212,9 +212,9 @@ extern "C" int mydet_stem_dw_f32(const float *x, int64_t sxb, int64_t sxc, int64
     p.tiles_x = (Ws + SD_TW - 1) / SD_TW;
     p.tiles_per_img = p.tiles_x * ((Hs + SD_TH - 1) / SD_TH);
     p.S = S;
-    const SeTail none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    const SeTail none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
     p.se = se ? *se : none;
-    if (const int e = mydet_se_tail_check(p.se, C, B)) return e;
+    if (const int e = mydet_se_tail_check(p.se, C, B, S)) return e;
     if ((se_partial || p.se.gate) && S != p.tiles_per_img) return MYDET_E_BADARG;
     const int64_t grid = (int64_t)B * p.tiles_per_img;
     if (grid > 0x7fffffff) return MYDET_E_UNSUPP;

@@ -8,6 +8,7 @@ input in a foreign layout is re-laid out with one tensor copy before the launch)
 """
 import ctypes
 import os
+import threading
 
 import numpy as np
 import torch
@@ -132,9 +133,16 @@ class lane:
         _LANE = self.prev
 
 
+def _scratch_key(device):
+    """(device, lane, host thread): scratch buffers are reused in stream order by ONE launch sequence, so a second host thread that
+    happens to be on the same lane index gets buffers of its own.  Not keyed by stream: a hipGraph is warmed
+    up on one stream and captured on another, and must find the buffers its warm-up sized (growth during capture raises)."""
+    return (device.type, device.index, _LANE, threading.get_ident())
+
+
 def conv_workspace(device):
-    """Per-device, per-lane scratch for the split-K tail of conv2d (stream-ordered reuse; one stream per lane)."""
-    key = (device.type, device.index, _LANE)
+    """Per-device, per-lane, per-stream scratch for the split-K tail of conv2d (stream-ordered reuse)."""
+    key = _scratch_key(device)
     if key not in _WORKSPACE:
         _WORKSPACE[key] = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
     return _WORKSPACE[key]
@@ -149,7 +157,7 @@ def wino4_workspace(device, nbytes):
     Growth REPLACES the buffer: whoever recorded its address (a captured hipGraph) keeps the superseded tensor alive
     through `live_workspaces` -- graph.GraphedPath does -- so a replay never writes into memory the caching allocator
     has handed to someone else."""
-    key = (device.type, device.index, _LANE)
+    key = _scratch_key(device)
     ws = _WINO4_WS.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         if device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
@@ -174,7 +182,7 @@ def se_shares(device, n_pairs):
     """Per-device, per-lane share buffer of the in-launch squeeze-excite tail (include/mydet.h: mydet_se_tail.hpart): a header
     (launch counter = 1, finished-image count = 0) followed by room for `n_pairs` (value, epoch) pairs (0).  The kernels' own protocol keeps it consistent, so
     ONE buffer serves every layer of a lane's stream.  Grows to the largest layer seen (not during a stream capture)."""
-    key = (device.type, device.index, _LANE)
+    key = _scratch_key(device)
     buf = _SE_SHARES.get(key)
     need = _lib.SE_EPOCH_WORDS + 2 * int(n_pairs)
     if buf is None or buf.numel() < need:
@@ -184,6 +192,17 @@ def se_shares(device, n_pairs):
         buf[0] = 1                                           # the launch counter; word 1 = images finished in a running launch
         _SE_SHARES[key] = buf = buf.view(torch.float32)
     return buf
+
+
+def se_tail_timeouts(device):
+    """Number of in-launch squeeze-excite tails (summed over this thread's lanes' share buffers) whose finishing workgroup gave up
+    waiting for a share and wrote a NaN gate (header word 2 of the share buffer, csrc/se_tail.h): 0 unless a launch was starved
+    for ~2^14 polls.  Synchronises."""
+    n = 0
+    for k, buf in _SE_SHARES.items():
+        if k[:2] == (device.type, device.index):
+            n += int(buf.view(torch.int32)[2].item())
+    return n
 
 
 def _se_tail(se, B, C, groups, device):
@@ -196,7 +215,7 @@ def _se_tail(se, B, C, groups, device):
     assert Cse <= SE_MAX_CSE and groups > 0
     gate = torch.empty((B, C), dtype=torch.float32, device=device)
     hpart = se_shares(device, B * groups * Cse)
-    t = _lib.SeTail(w1.data_ptr(), b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), gate.data_ptr(), hpart.data_ptr(), Cse)
+    t = _lib.SeTail(w1.data_ptr(), b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), gate.data_ptr(), hpart.data_ptr(), Cse, hpart.numel() * 4)
     return t, gate, (hpart, w1, b1, w2t, b2)
 
 

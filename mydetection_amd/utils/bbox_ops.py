@@ -24,8 +24,12 @@ def cxcywh_to_x1y1x2y2(cxcywh):
     launch of the to-corners kernel of csrc/boxops.hip: float32 `c - s / 2`, `c + s / 2` in the reference's operation
     order, so the result is bit-identical; extra columns (a rotated box's angle) are carried over."""
     assert cxcywh.shape[-1] >= 4
+    # the reference returns a tensor of the input's device and dtype for any dtype (ADVICE r05): the kernel computes in float32
+    # on the GPU; the result goes back to where and what the input was (float64 / integer inputs through a float32 round trip)
+    src_device, src_dtype = cxcywh.device, cxcywh.dtype
     if not cxcywh.is_cuda:
         if not torch.cuda.is_available():
             raise RuntimeError('cxcywh_to_x1y1x2y2 runs on MI355X only; no GPU is visible')
         cxcywh = cxcywh.cuda()
-    return ops.cxcywh_to_x1y1x2y2(cxcywh)
+    out = ops.cxcywh_to_x1y1x2y2(cxcywh if src_dtype == torch.float32 else cxcywh.float())
+    return out.to(device=src_device, dtype=src_dtype)

@@ -165,6 +165,33 @@ def test_conv_p3_vs_fp64(dev, case):
         assert ops.nhwc_ld(y) == Cout + 12
 
 
+def test_split_bf16_non_finite_semantics(dev):
+    """Deliberate deviation, pinned (include/mydet.h: mydet_conv2d_igemm_b3_f32): the split-bf16
+    kernels are for finite tensors.  Where the float32 kernel and the reference propagate an infinite activation as inf, the
+    three-piece split forms inf - inf: NaN; a finite |x| >= ~3.39e38 rounds up to a bfloat16 inf and becomes NaN as well; NaN stays
+    NaN; every output that does not touch the offending element is unaffected and finite."""
+    from mydetection_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, Cin, Cout, H = 2, 64, 128, 16
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = (torch.randn(Cout, 1, 1, Cin, generator=g) / Cin ** 0.5).to(dev)
+    sc, sh = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
+    x[0, 3, 2, 5] = float('inf')
+    x[0, 7, 9, 1] = 3.395e38                       # finite in float32, beyond the largest bfloat16
+    x[1, 0, 0, 0] = float('nan')
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last)
+    w3 = ops.split_bf16(w)
+    y3 = ops.conv2d(xd, w, sc, sh, 1, 1, (0, 0, 0, 0), ops.ACT_NONE, b3=w3, b3_min_rows=1)
+    y32 = ops.conv2d(xd, w, sc, sh, 1, 1, (0, 0, 0, 0), ops.ACT_NONE)
+    assert torch.isinf(y32[0, :, 2, 5]).all() and torch.isnan(y3[0, :, 2, 5]).all()          # inf -> NaN (float32 kernel: inf)
+    assert torch.isfinite(y32[0, :, 9, 1]).all() and torch.isnan(y3[0, :, 9, 1]).all()        # 3.395e38 -> NaN (float32 kernel: finite)
+    assert torch.isnan(y32[1, :, 0, 0]).all() and torch.isnan(y3[1, :, 0, 0]).all()           # NaN -> NaN in both
+    clean = torch.ones(B, H, H, dtype=torch.bool, device=dev)
+    clean[0, 2, 5] = clean[0, 9, 1] = clean[1, 0, 0] = False
+    a, b = y3.permute(0, 2, 3, 1)[clean], y32.permute(0, 2, 3, 1)[clean]
+    assert torch.isfinite(a).all() and (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+
+
 def _split_bf16_case(dev, case):
     from mydetection_amd import ops
     B, Cin, Cout, k, s, H, W = (case[n] for n in ('B', 'Cin', 'Cout', 'k', 's', 'H', 'W'))
@@ -496,6 +523,16 @@ def test_cxcywh_to_x1y1x2y2_golden(dev, golden):
     np.testing.assert_array_equal(out5[:, :4], g['a_xyxy'])
     np.testing.assert_array_equal(out5[:, 4], five[:, 4])
     assert tuple(cxcywh_to_x1y1x2y2(torch.empty((0, 4), device=dev)).shape) == (0, 4)
+    # device and dtype of the input are kept, as in the reference: a CPU tensor comes back on the CPU, float64 / int64
+    # boxes come back in their own dtype (computed in float32 on the GPU)
+    cpu_out = cxcywh_to_x1y1x2y2(torch.from_numpy(g['a']))
+    assert cpu_out.device.type == 'cpu' and cpu_out.dtype == torch.float32
+    np.testing.assert_array_equal(cpu_out.numpy(), g['a_xyxy'])
+    d64 = cxcywh_to_x1y1x2y2(torch.from_numpy(g['a']).double().to(dev))
+    assert d64.dtype == torch.float64 and d64.is_cuda
+    np.testing.assert_array_equal(d64.cpu().numpy(), g['a_xyxy'].astype(np.float64))
+    ints = torch.tensor([[10, 20, 4, 8]], dtype=torch.int64)
+    assert cxcywh_to_x1y1x2y2(ints).tolist() == [[8, 16, 12, 24]] and cxcywh_to_x1y1x2y2(ints).dtype == torch.int64
 
 
 def _yolo_cfg():

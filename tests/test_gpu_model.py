@@ -769,13 +769,13 @@ def test_graph_survives_workspace_growth_and_weight_reload(model, monkeypatch):
     first = det._records(small, conf, nms)                     # captured + replayed
     assert len(det._graphs.graphs) == 1
     g = next(iter(det._graphs.graphs.values()))
-    ws_small = ops._WINO4_WS[(dev.type, dev.index, 0)]
+    ws_small = ops._WINO4_WS[ops._scratch_key(dev)]
     assert any(t.data_ptr() == ws_small.data_ptr() for t in g._held[0])
     for k in ('count', 'bbox', 'score', 'class_idx', 'index'):
         assert torch.equal(first[k], eager_small[k]), k
     with torch.no_grad():                                      # a larger input, eagerly: the workspace is replaced
         m.forward_candidates(large)
-    ws_large = ops._WINO4_WS[(dev.type, dev.index, 0)]
+    ws_large = ops._WINO4_WS[ops._scratch_key(dev)]
     assert ws_large.numel() > ws_small.numel() and ws_large.data_ptr() != ws_small.data_ptr()
     ptr_small, n_small = ws_small.data_ptr(), ws_small.numel()
     del ws_small
@@ -808,7 +808,7 @@ def test_graph_survives_workspace_growth_and_weight_reload(model, monkeypatch):
     finally:
         m.load_state_dict(sd, strict=True)
         for k in [k for k in ops._WINO4_WS if k[:2] == (dev.type, dev.index)]:
-            ops._WINO4_WS.pop(k)                              # keys are (type, index, lane)
+            ops._WINO4_WS.pop(k)                              # keys are (type, index, lane, host thread)
 
 
 def test_postprocess_flags_out_of_range_class_ids():
@@ -1101,6 +1101,7 @@ def test_two_lane_replays_repeatable_full_size(name, batch):
     ref = run.eager()
     for k in ('count', 'index', 'class_idx', 'score', 'bbox'):
         assert torch.equal(rec[k], ref[k]), k
+    assert ops.se_tail_timeouts(x.device) == 0            # no finishing workgroup ever gave up its poll (it would write a NaN gate)
     with torch.no_grad():
         full = m.forward_candidates(x)
     # (a lane of B / 2 images and the full batch take different kernels for some layers -- row limits of the split-bf16 forms --, so

@@ -298,6 +298,27 @@ def test_graph_cache_policy_and_workspace_refs():
     assert ops.check_counts([0, 5]) == [0, 5]
 
 
+def test_se_tail_share_buffer_size_is_validated():
+    """mydet_se_tail carries the byte count of its share buffer and every entry point that takes an in-launch
+    squeeze-excite tail rejects an undersized one BEFORE launching anything (MYDET_E_BADARG; no GPU needed: the pointers are
+    never dereferenced on the host) -- 4 * (MYDET_SE_EPOCH_WORDS + 2 * B * groups * Cse) bytes."""
+    import ctypes
+    from mydetection_amd import _lib
+    h = _lib.lib()
+    B, C, Cse, K, Ho = 4, 1152, 48, 5, 20
+    groups = h.mydet_dwconv_se_groups(Ho, Ho, C, K, 1)
+    S = h.mydet_dwconv_slices(Ho, Ho, C, K, 1)
+    assert groups > 0 and S > 0
+    need = 4 * (_lib.SE_EPOCH_WORDS + 2 * B * groups * Cse)
+    fake = 0x10000                                          # aligned, non-null, never touched
+    for nbytes, want in ((need - 8, -1), (0, -1)):
+        t = _lib.SeTail(fake, fake, fake, fake, fake, fake, Cse, nbytes)
+        code = h.mydet_dwconv_f32(fake, C, fake, fake, fake, fake, C, B, Ho, Ho, C, K, 1, 2, 2, Ho, Ho, 2, None, S, ctypes.byref(t), None)
+        assert code == want, (nbytes, code)
+    t = _lib.SeTail(fake, fake, fake, fake, fake, fake, 97, need * 4)         # Cse beyond the kernels' limit: unsupported, not a launch
+    assert h.mydet_dwconv_f32(fake, C, fake, fake, fake, fake, C, B, Ho, Ho, C, K, 1, 2, 2, Ho, Ho, 2, None, S, ctypes.byref(t), None) == -2
+
+
 def test_no_store_data_hazard_in_the_shipped_library():
     """gfx950 store-data hazard (profiles/r03_isa_notes.md): no 12/16-byte buffer store with an SGPR soffset may be followed
     directly by a VALU write of its data registers -- hipcc pads that pattern only for stores WITHOUT an SGPR soffset.
