@@ -201,7 +201,7 @@ int mydet_conv1x1_upcat_f32(const float *x_lo, int64_t ld_lo, int C_lo, const fl
  * activation: the squeeze-excite project convs) multiplies the activations per image and channel before they are split.  Cin % 16 == 0 (1x1 layers: Cin % 4 == 0, the
  * last 16-channel slab of the planes zero-filled by mydet_split_bf16_f32);
  * MYDET_E_UNSUPP otherwise (the caller then uses mydet_conv2d_igemm_f32).  Replaces the same reference lines.
- * Finite tensors only: an infinite operand, or a finite one of magnitude >= 3.39e38 (it rounds to a bfloat16 inf), yields NaN where
+ * Finite tensors only: an infinite operand, or a finite one of magnitude > 3.3962e38 (it rounds to a bfloat16 inf), yields NaN where
  * the float32 kernel and the reference yield inf (the split forms inf - inf); NaN propagates as NaN. */
 int64_t mydet_split_bf16_elems(int Cout, int K);      /* uint16 elements of the operand below (0: K % 4 != 0) */
 int mydet_split_bf16_f32(const float *w, int Cout, int K, uint16_t *planes, void *stream);

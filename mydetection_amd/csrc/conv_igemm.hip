@@ -353,7 +353,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
 // (fragment reads AND staging writes conflict-free); two slab buffers = 48 KB at 128 x 128: two to three workgroups per CU.
 // Cin % 16 == 0 (a slab never straddles taps; 1x1 layers: Cin % 4 == 0, the last slab zero-filled).
 // Non-finite inputs: bf16(inf) = inf and inf - inf = NaN, so an infinite activation or weight becomes NaN (the float32 kernel and
-// the reference propagate inf), and a finite |x| >= 2^127 * (2 - 2^-8) ~ 3.39e38 rounds up to a bfloat16 inf -> NaN as well;
+// the reference propagate inf), and a finite |x| > 2^127 * (2 - 2^-8) ~ 3.3962e38 (the midpoint above the largest bfloat16) rounds up to a bfloat16 inf -> NaN as well;
 // NaN stays NaN.  A deliberate deviation (pinned by test_split_bf16_non_finite_semantics): the kernels are for
 // finite tensors, and guarding the split costs two vector-ALU instructions per element in the loop that bounds these kernels.
 constexpr int B3_COUT_PAD = 256;            // rows of the weight operand are padded to this (split_bf16_kernel)

@@ -168,7 +168,7 @@ def test_conv_p3_vs_fp64(dev, case):
 def test_split_bf16_non_finite_semantics(dev):
     """Deliberate deviation, pinned (include/mydet.h: mydet_conv2d_igemm_b3_f32): the split-bf16
     kernels are for finite tensors.  Where the float32 kernel and the reference propagate an infinite activation as inf, the
-    three-piece split forms inf - inf: NaN; a finite |x| >= ~3.39e38 rounds up to a bfloat16 inf and becomes NaN as well; NaN stays
+    three-piece split forms inf - inf: NaN; a finite |x| > 3.3962e38 rounds up to a bfloat16 inf and becomes NaN as well; NaN stays
     NaN; every output that does not touch the offending element is unaffected and finite."""
     from mydetection_amd import ops
     g = torch.Generator().manual_seed(9)
@@ -177,14 +177,14 @@ def test_split_bf16_non_finite_semantics(dev):
     w = (torch.randn(Cout, 1, 1, Cin, generator=g) / Cin ** 0.5).to(dev)
     sc, sh = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
     x[0, 3, 2, 5] = float('inf')
-    x[0, 7, 9, 1] = 3.395e38                       # finite in float32, beyond the largest bfloat16
+    x[0, 7, 9, 1] = 3.4e38                         # finite in float32, past the midpoint above the largest bfloat16 (3.3962e38): bf16 inf
     x[1, 0, 0, 0] = float('nan')
     xd = x.to(dev).contiguous(memory_format=torch.channels_last)
     w3 = ops.split_bf16(w)
     y3 = ops.conv2d(xd, w, sc, sh, 1, 1, (0, 0, 0, 0), ops.ACT_NONE, b3=w3, b3_min_rows=1)
     y32 = ops.conv2d(xd, w, sc, sh, 1, 1, (0, 0, 0, 0), ops.ACT_NONE)
     assert torch.isinf(y32[0, :, 2, 5]).all() and torch.isnan(y3[0, :, 2, 5]).all()          # inf -> NaN (float32 kernel: inf)
-    assert torch.isfinite(y32[0, :, 9, 1]).all() and torch.isnan(y3[0, :, 9, 1]).all()        # 3.395e38 -> NaN (float32 kernel: finite)
+    assert torch.isfinite(y32[0, :, 9, 1]).all() and torch.isnan(y3[0, :, 9, 1]).all()        # 3.4e38 -> NaN (float32 kernel: finite)
     assert torch.isnan(y32[1, :, 0, 0]).all() and torch.isnan(y3[1, :, 0, 0]).all()           # NaN -> NaN in both
     clean = torch.ones(B, H, H, dtype=torch.bool, device=dev)
     clean[0, 2, 5] = clean[0, 9, 1] = clean[1, 0, 0] = False
@@ -241,18 +241,24 @@ def _split_bf16_case(dev, case):
         kw['out_ld'] = Cout + 12
     args = (xd, wd, scale.to(dev) if scale is not None else None, shift.to(dev), k, s, (p, p, p, p), case['act'])
     ops.TIMER = ops.KernelTimer()
+    p3_was, ops.CONV_P3 = ops.CONV_P3, False            # (conv_igemm_b3_kernel is under test: the patch-resident 3x3 kernel has its own test)
     try:
         y3 = ops.conv2d(*args, b3=w3, b3_min_rows=1, **kw).clone()
     finally:
         timer, ops.TIMER = ops.TIMER, None
+        ops.CONV_P3 = p3_was
     assert 'conv_igemm_b3' in timer.spans and 'conv_igemm' not in timer.spans
     y32 = ops.conv2d(*args, **kw)
     tol = 2e-5 * ref.abs().max().item()
     e3, e32 = (y3.cpu().double() - ref).abs().max().item(), (y32.cpu().double() - ref).abs().max().item()
     assert e3 <= tol, (e3, e32, tol)
     assert e3 <= 4.0 * e32 + 1e-6, f'split-bf16 error {e3:.2e} vs float32-instruction error {e32:.2e}'
-    for _ in range(2):
-        assert torch.equal(ops.conv2d(*args, b3=w3, b3_min_rows=1, **kw), y3)
+    ops.CONV_P3 = False
+    try:
+        for _ in range(2):
+            assert torch.equal(ops.conv2d(*args, b3=w3, b3_min_rows=1, **kw), y3)
+    finally:
+        ops.CONV_P3 = p3_was
 
 
 @pytest.mark.parametrize('shape', [(2, 256, 512, 256, 20, 20),      # 28 x 4 tiles, K = 24 slabs: the small-grid K cut + CAT
