@@ -8,7 +8,10 @@
 // 16-channel slab it loads the tile's input patch (17 x 33 pixels at stride 2, 10 x 18 at stride 1) ONCE, splits it once into
 // three bf16 planes in LDS, and the 9 taps read their MFMA A fragments straight out of that patch at a tap-dependent offset --
 // no im2col tile is ever written.  The weights come pre-split (mydet_split_bf16_f32: the planes conv_igemm_b3_kernel uses,
-// slab kt = tap * Cin/16 + slab) through a small LDS buffer per (slab, tap).
+// slab kt = tap * Cin/16 + slab) and never touch LDS: a wave owns 32 output channels (all 128 rows of the tile at BN = 128), and
+// its MFMA B fragment of a (slab, tap, plane) is ONE coalesced 1 KB load -- the planes store each 32-row block as the 64 16-byte
+// units of exactly that fragment -- requested three taps ahead.  So the only workgroup barriers are the two around the patch
+// refresh of a slab (the first form staged the weights through LDS: two barriers per tap, waves waiting 57 % of their cycles).
 //   global loads + split arithmetic per output pixel and slab: 561 / 128 = 4.4 pixels (stride 2; 9 before), 180 / 128 = 1.4
 //   (stride 1; 9 before).
 // Patch layout (one plane; 32 bytes = 16 bf16 per position, the two 16-byte halves swapped where sigma = 1):
@@ -69,19 +72,18 @@ template <int S> struct P3Geom;
 template <> struct P3Geom<2> { static constexpr int PH = 17, ROWLEN = 36, PJ0 = 17; };
 template <> struct P3Geom<1> { static constexpr int PH = 10, ROWLEN = 24, PJ0 = 0; };
 
-// S: stride.  BN: output channels per workgroup (64 | 128).  NBUF: LDS buffers of the weight tile (1: two barriers per tap).
-template <int S, int BN, int NBUF, int ACT, bool RES>
+// S: stride.  BN: output channels per workgroup (64 | 128): waves = (4 / (BN / 32)) row groups x (BN / 32) column blocks of 32.
+template <int S, int BN, int ACT, bool RES>
 __global__ __launch_bounds__(256, 2) void conv_p3_kernel(const P3Args p) {
-    constexpr int TH = 8, TW = 16, WM = 2, WN = 2, ROWB = 32;
-    constexpr int TM = 2, TN = BN / (WN * 32);
+    constexpr int TH = 8, TW = 16, ROWB = 32;
+    constexpr int WN = BN / 32, WM = 4 / WN, TM = 4 / WM;       // wave (wm, wn): 32 * TM rows x 32 columns
     constexpr int PH = P3Geom<S>::PH, ROWLEN = P3Geom<S>::ROWLEN, PJ0 = P3Geom<S>::PJ0;
     constexpr int PW = S * (TW - 1) + 3;
     constexpr int NPOS = PH * ROWLEN;
-    constexpr int PLANE_P = NPOS * ROWB, PLANE_B = BN * ROWB;
+    constexpr int PLANE_P = NPOS * ROWB;
     constexpr int NCH = (NPOS * 4 + 255) / 256;      // 16-byte float4 chunks of the patch per thread and slab
-    constexpr int BCH = BN * 2;                      // 16-byte units of one weight plane per (slab, tap)
     extern __shared__ __attribute__((aligned(16))) char smem_p3[];
-    char *patch = smem_p3, *bbase = smem_p3 + 3 * PLANE_P;
+    char *patch = smem_p3;
 
     const int tid = threadIdx.x;
     const int id = mydet_xcd_remap(blockIdx.x, p.nblk);
@@ -126,14 +128,6 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(const P3Args p) {
         goff[i] = ok ? (unsigned)((((int64_t)iy * p.W + ix) * p.ldx + sc * 4 + lead) * 4) : OOB;
         ldst[i] = pos < NPOS ? pos * ROWB + (((sc >> 1) ^ sig) * 16) + (sc & 1) * 8 : -1;
     }
-    // ---- weight staging role (as conv_igemm_b3_kernel): 16-byte unit `tid` of the tile's plane-slab
-    const bool bact = tid < BCH;
-    const int bu = tid & 63, brr = bu >> 1;
-    const int br = (tid >> 6) * 32 + brr, bh = (bu & 1) ^ ((brr >> 2) & 1);
-    const unsigned boff = bact ? (unsigned)(n0 * 32 + tid * 16) : OOB;
-    const int bdst = br * ROWB + ((bh ^ ((br >> 3) & 1)) * 16);
-    const unsigned plane_bytes = (unsigned)CoutP * 32u, slab_bytes = 3u * plane_bytes;
-
     // ---- compute role
     const int wave = tid >> 6, lane = tid & 63;
     const int wm = wave / WN, wn = wave % WN;
@@ -145,25 +139,20 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(const P3Args p) {
         const int oyl = wm * (TM * 2) + i * 2 + (fr >> 4);
         apos[i] = S == 2 ? (2 * oyl) * ROWLEN + oxl : oyl * ROWLEN + oxl;
     }
-    const int b_off = (wn * TN * 32 + fr) * ROWB + ((fh ^ ((fr >> 3) & 1)) * 16);
-    f32x16 acc[TM][TN];
+    // weights: the lane's 16-byte unit of the wave's 32-row block in a (slab, plane) piece of the planes (split_bf16_kernel)
+    const unsigned boff = (unsigned)((n0 + wn * 32) * 32 + (2 * fr + (fh ^ ((fr >> 2) & 1))) * 16);
+    const unsigned plane_bytes = (unsigned)CoutP * 32u, slab_bytes = 3u * plane_bytes;
+    f32x16 acc[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float pscl[TN], psft[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * TN * 32 + j * 32 + fr;
-        const int nc = n < p.Cout ? n : 0;
-        pscl[j] = p.scale ? p.scale[nc] : 1.0f;
-        psft[j] = p.shift ? p.shift[nc] : 0.0f;
-    }
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int nch = n0 + wn * 32 + fr;               // the lane's output channel
+    const float pscl = p.scale ? p.scale[nch < p.Cout ? nch : 0] : 1.0f;
+    const float psft = p.shift ? p.shift[nch < p.Cout ? nch : 0] : 0.0f;
 
     f32x4 preg[NCH];
-    u32x4 breg[3][3];                                // ring of three (slab, tap) steps in flight
+    bf16x8 breg[3][3];                               // B fragments of three (slab, tap) steps in flight
     auto load_patch = [&](int cs) {
         const unsigned coff = (unsigned)cs * 64u;    // 16 channels * 4 bytes
 #pragma unroll
@@ -182,23 +171,16 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(const P3Args p) {
             *reinterpret_cast<bf16x4 *>(d + 2 * PLANE_P) = q2;
         }
     };
-    auto load_b = [&](int cs, int tap, u32x4 (&brg)[3]) {              // weights of (slab cs, tap): slab kt = tap * nsl + cs of the planes
+    auto load_b = [&](int cs, int tap, bf16x8 (&brg)[3]) {             // weights of (slab cs, tap): slab kt = tap * nsl + cs of the planes
         const unsigned kt = (unsigned)(tap * nsl + cs);
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
-            brg[pl] = __builtin_amdgcn_raw_buffer_load_b128(wr, cs < nsl ? boff : OOB,
-                                                            __builtin_amdgcn_readfirstlane(kt * slab_bytes + (unsigned)pl * plane_bytes), 0);
+            brg[pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, cs < nsl ? boff : OOB,
+                                                     __builtin_amdgcn_readfirstlane(kt * slab_bytes + (unsigned)pl * plane_bytes), 0));
     };
-    auto store_b = [&](int buf, const u32x4 (&brg)[3]) {
-        if (bact) {
-            char *d = bbase + buf * 3 * PLANE_B + bdst;
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4 *>(d + pl * PLANE_B) = brg[pl];
-        }
-    };
-    auto compute = [&](int tap, int buf) {
+    auto compute = [&](int tap, const bf16x8 (&bf)[3]) {
         const int kh = tap / 3, kw = tap - kh * 3;
-        bf16x8 af[TM][3], bf[TN][3];
+        bf16x8 af[TM][3];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             int pos, sig;
@@ -213,19 +195,12 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(const P3Args p) {
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) af[i][pl] = *reinterpret_cast<const bf16x8 *>(a + pl * PLANE_P);
         }
-        const char *bb = bbase + buf * 3 * PLANE_B + b_off;
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8 *>(bb + pl * PLANE_B + j * 32 * ROWB);
         constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};          // small piece products first
 #pragma unroll
         for (int tt = 0; tt < 6; ++tt)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[tt]], bf[j][PB[tt]], acc[i][j], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[tt]], bf[PB[tt]], acc[i], 0, 0, 0);
     };
 
     load_patch(0);
@@ -233,19 +208,15 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(const P3Args p) {
     load_b(0, 1, breg[1]);
     load_b(0, 2, breg[2]);
     for (int cs = 0; cs < nsl; ++cs) {
-        if (cs > 0) __syncthreads();                 // every wave is done with the previous slab's patch (and its last weight tile)
+        if (cs > 0) __syncthreads();                 // every wave is done with the previous slab's patch
         store_patch();
         load_patch(cs + 1);                          // in flight under the nine taps below
+        __syncthreads();
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int buf = NBUF == 2 ? (tap & 1) : 0;          // (nine taps per slab: with two buffers the parity flips from slab to slab,
-            const int rb = NBUF == 2 ? ((cs & 1) ^ buf) : 0;    //  so the buffer of a step is (cs + tap) & 1)
-            if (NBUF == 1 && tap > 0) __syncthreads();          // the single weight buffer is free again
-            store_b(rb, breg[tap % 3]);
+            compute(tap, breg[tap % 3]);
             const int t3 = tap + 3;
             load_b(cs + t3 / 9, t3 % 9, breg[tap % 3]);
-            __syncthreads();
-            compute(tap, rb);
         }
     }
 
@@ -255,11 +226,10 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(const P3Args p) {
     const __amdgpu_buffer_rsrc_t yr = p3_rsrc(p.y + b * opix * p.ldy, opix * p.ldy * 4);
     const __amdgpu_buffer_rsrc_t rr = p3_rsrc(RES ? p.res + b * opix * p.ldr : p.y, opix * (RES ? p.ldr : p.ldy) * 4);
     const unsigned ldy4 = (unsigned)p.ldy * 4u, ldr4 = (unsigned)p.ldr * 4u;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * TN * 32 + j * 32 + fr;
+    {
+        const int n = nch;
         const bool nok = n < p.Cout;
-        const float scl = pscl[j], sft = psft[j];
+        const float scl = pscl, sft = psft;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int oyb = oy0 + wm * (TM * 2) + i * 2;         // first output row of the block
@@ -277,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(const P3Args p) {
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = acc[i][j][r] * scl + sft;
+                float v = acc[i][r] * scl + sft;
                 if (ACT == MYDET_ACT_LEAKY) v = v > 0.0f ? v : v * 0.1f;
                 if (ACT == MYDET_ACT_SWISH) v = v * mydet_sigmoid_fast(v);
                 if (RES) v += rv[r];
@@ -287,11 +257,10 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(const P3Args p) {
     }
 }
 
-template <int S, int BN, int NBUF, int ACT, bool RES>
+template <int S, int BN, int ACT, bool RES>
 int p3_launch(const P3Args &p, hipStream_t st) {
-    constexpr int PLANE_P = P3Geom<S>::PH * P3Geom<S>::ROWLEN * 32, PLANE_B = BN * 32;
-    constexpr int LDS = 3 * PLANE_P + NBUF * 3 * PLANE_B;
-    auto kern = &conv_p3_kernel<S, BN, NBUF, ACT, RES>;
+    constexpr int LDS = 3 * P3Geom<S>::PH * P3Geom<S>::ROWLEN * 32;
+    auto kern = &conv_p3_kernel<S, BN, ACT, RES>;
     static bool attr = false;
     if (!attr) {
         const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -302,10 +271,10 @@ int p3_launch(const P3Args &p, hipStream_t st) {
     return mydet_launch_status();
 }
 
-template <int S, int BN, int NBUF>
+template <int S, int BN>
 int p3_dispatch(const P3Args &p, int act, bool res, hipStream_t st) {
-    if (act == MYDET_ACT_LEAKY) return res ? p3_launch<S, BN, NBUF, MYDET_ACT_LEAKY, true>(p, st) : p3_launch<S, BN, NBUF, MYDET_ACT_LEAKY, false>(p, st);
-    if (act == MYDET_ACT_NONE) return res ? p3_launch<S, BN, NBUF, MYDET_ACT_NONE, true>(p, st) : p3_launch<S, BN, NBUF, MYDET_ACT_NONE, false>(p, st);
+    if (act == MYDET_ACT_LEAKY) return res ? p3_launch<S, BN, MYDET_ACT_LEAKY, true>(p, st) : p3_launch<S, BN, MYDET_ACT_LEAKY, false>(p, st);
+    if (act == MYDET_ACT_NONE) return res ? p3_launch<S, BN, MYDET_ACT_NONE, true>(p, st) : p3_launch<S, BN, MYDET_ACT_NONE, false>(p, st);
     return MYDET_E_UNSUPP;
 }
 
@@ -324,10 +293,8 @@ extern "C" int mydet_conv3x3_p3_f32(const float *x, int64_t ldx, const uint16_t 
     p.Ho = (H + 2 - 3) / stride + 1; p.Wo = (W + 2 - 3) / stride + 1;
     // 32-bit byte offsets inside the kernel, relative to the workgroup's image: one image's input and output stay below 2 GB
     if ((int64_t)(H + 1) * (W + 1) * ldx * 4 > 0x7FFFFFF0ll || (int64_t)p.Ho * p.Wo * (ldy > ldr ? ldy : ldr) * 4 > 0x7FFFFFF0ll) return MYDET_E_UNSUPP;
-    // MYDET_P3_FORM (experiments): 1 = 64-channel tiles whatever Cout, 2 = 128-channel tiles with two weight buffers (one workgroup per CU at stride 2)
-    const char *fe = getenv("MYDET_P3_FORM");
-    const int form = fe ? atoi(fe) : 0;
-    const bool wide = Cout > 64 && form != 1;
+    const char *fe = getenv("MYDET_P3_FORM");        // (experiments) 1 = 64-channel tiles whatever Cout
+    const bool wide = Cout > 64 && !(fe && atoi(fe) == 1);
     const int BN = wide ? 128 : 64;
     p.tx_n = (p.Wo + 15) / 16; p.ty_n = (p.Ho + 7) / 8; p.ntn = (Cout + BN - 1) / BN;
     const int64_t nblk = (int64_t)B * p.tx_n * p.ty_n * p.ntn;
@@ -335,9 +302,6 @@ extern "C" int mydet_conv3x3_p3_f32(const float *x, int64_t ldx, const uint16_t 
     p.nblk = (int)nblk;
     hipStream_t st = (hipStream_t)stream;
     const bool res = residual != nullptr;
-    if (stride == 2) {
-        if (!wide) return p3_dispatch<2, 64, 2>(p, act, res, st);
-        return form == 2 ? p3_dispatch<2, 128, 2>(p, act, res, st) : p3_dispatch<2, 128, 1>(p, act, res, st);
-    }
-    return wide ? p3_dispatch<1, 128, 2>(p, act, res, st) : p3_dispatch<1, 64, 2>(p, act, res, st);
+    if (stride == 2) return wide ? p3_dispatch<2, 128>(p, act, res, st) : p3_dispatch<2, 64>(p, act, res, st);
+    return wide ? p3_dispatch<1, 128>(p, act, res, st) : p3_dispatch<1, 64>(p, act, res, st);
 }
