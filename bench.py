@@ -742,7 +742,7 @@ def measure(args, ctx):
     # separate passes, corrected per kernel as MI355X_MICROARCH.md prescribes); offline because counters need the profiler
     traffic, traffic_src = None, None
     tag = {'yolov3_80': 'yolov3', 'efficientdet-d1': 'd1', 'd1_fcs2_atss': 'fcos'}.get(args.config, args.config)
-    for rnd in ('r05', 'r04', 'r03', 'r02', 'r01'):
+    for rnd in ('r06', 'r05', 'r04', 'r03', 'r02', 'r01'):
         name = f'{rnd}_pmc_traffic_{tag}_b{batch}_{args.size}.json' if rnd != 'r01' else 'r01_pmc_traffic_b32_640.json'
         path = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(path) and (rnd != 'r01' or (args.config == 'yolov3_80' and batch == 32 and args.size == 640)):
@@ -755,7 +755,7 @@ def measure(args, ctx):
                     pmc = {'hbm_bytes_per_launch': (pmc.get('hbm_bytes_per_launch', 0) * n_a + q.get('hbm_bytes_per_launch', 0) * n_b) / (n_a + n_b)}
             if pmc:
                 traffic = round(pmc.get('hbm_bytes_per_launch', pmc.get('hbm_read_bytes_per_launch_x2corr', 0) + pmc.get('hbm_write_bytes_per_launch', 0)))
-                traffic_src = f'profiles/{name} (offline rocprofv3 --pmc passes' + (', an earlier round' if rnd != 'r05' else '') + ')'
+                traffic_src = f'profiles/{name} (offline rocprofv3 --pmc passes' + (', an earlier round' if rnd != 'r06' else '') + ')'
                 break
     roofline.update({'traffic': traffic, 'traffic_source': traffic_src,
                      'algorithmic_bytes_per_launch': round(timer.bytes.get(dom, 0.0) / n_k) if n_k else None,

@@ -19,7 +19,7 @@ from collections import defaultdict
 # (substring of the kernel name, family, FETCH_SIZE correction or None = uncalibrated: report x1 and x2)
 FAMILIES = [('conv_wino4_kernel', 'conv_wino4_gemm', 2.0), ('wino4_input_kernel', 'wino4_input', 2.0), ('wino4_fixup', 'wino4_fixup', 2.0),
             ('wino4_weights', None, None),
-            ('conv_wino_kernel', 'conv_wino', None), ('conv_igemm_b3_kernel', 'conv_igemm_b3', 2.0), ('split_bf16', None, None),
+            ('conv_wino_kernel', 'conv_wino', None), ('conv_igemm_b3_kernel', 'conv_igemm_b3', 2.0), ('conv_p3_kernel', 'conv_p3', 2.0), ('split_bf16', None, None),
             ('conv_igemm_kernel', 'conv_igemm', 2.0), ('conv_fixup', 'conv_igemm_fixup', 2.0),
             ('conv_stem', 'conv_stem', None), ('stem_dw', 'stem_dw', None), ('upsample_concat', 'upsample_concat', 2.0), ('decode_kernel', 'decode', 2.0),
             ('postprocess', 'postprocess', None), ('dwconv', 'dwconv', 2.0), ('sepconv_decode', 'sepconv_decode', 2.0),
