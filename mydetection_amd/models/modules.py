@@ -117,7 +117,7 @@ class ConvBnLeaky(nn.Module, FusedConvMixin):
         u, u4 = prepare_wino(self, 'wino', w) if self.k == 3 and self.s == 1 else (None, None)
         # the layers that stay on the direct implicit GEMM (1x1, stride-2 3x3) take its split-bf16 form where ops.b3_takes says so
         # ... and the 3x3 layers their patch-resident form where ops.p3_takes says so (stride 2; stride 1 below F(4x4)'s channel limit)
-        b3 = prepare_b3(self, 'b3', w) if (u is None and u4 is None) or (self.k == 3 and u4 is None) else None
+        b3 = prepare_b3(self, 'b3', w) if (u is None and u4 is None) or (self.k == 3 and w.shape[3] <= ops.P3_S1_MAX_CIN) else None
         return ops.conv2d(x, w, scale, shift, self.k, self.s, (p, p, p, p), ops.ACT_LEAKY, residual=residual, wino=u, wino4=u4, b3=b3)
 
 

@@ -326,6 +326,7 @@ def b3_takes(M, Cin, Cout, k, min_rows=None, min_cout=128):
 # profiles/r06_conv_p3.txt.  MYDET_CONV_P3=0 turns it off.
 CONV_P3 = os.environ.get('MYDET_CONV_P3', '1') != '0'
 P3_MIN_ROWS = int(os.environ.get('MYDET_P3_MIN_ROWS', '65536'))
+P3_S1_MAX_CIN = int(os.environ.get('MYDET_P3_S1_MAX_CIN', '32'))      # stride-1 layers up to this many input channels
 
 
 def p3_takes(B, Ho, Wo, Cin, Cout, k, stride, pad):
@@ -334,7 +335,7 @@ def p3_takes(B, Ho, Wo, Cin, Cout, k, stride, pad):
         return False
     if Ho % 8 or Wo % 16 or B * Ho * Wo < P3_MIN_ROWS:
         return False
-    return stride == 2 or Cin < WINO4_MIN_CIN
+    return stride == 2 or Cin <= P3_S1_MAX_CIN
 
 
 def split_bf16(w_ohwi):

@@ -10,6 +10,8 @@ dev = torch.device('cuda:0')
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 B = int(os.environ.get('P3_BATCH', '32'))
 LAYERS = [(32, 64, 2, 640), (64, 128, 2, 320), (128, 256, 2, 160), (256, 512, 2, 80), (512, 1024, 2, 40), (32, 64, 1, 320)]
+if os.environ.get('P3_S1'):
+    LAYERS = [(64, 128, 1, 160), (128, 256, 1, 80), (32, 64, 1, 320)]
 
 
 def timed(fn):
@@ -36,10 +38,11 @@ for Cin, Cout, s, H in LAYERS:
         res = torch.randn(B, Cout, Ho, Ho, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
     w3 = ops.split_bf16(w)
     u = ops.wino_weights(w) if s == 1 else None
+    u4 = ops.wino4_weights(w) if s == 1 and Cin >= 64 else None
     y_p3 = ops.conv3x3_p3(x, w3, sc, sh, s, ops.ACT_LEAKY, residual=res)
     if s == 1:
-        base = lambda: ops.conv2d(x, w, sc, sh, 3, 1, (1, 1, 1, 1), ops.ACT_LEAKY, residual=res, wino=u)
-        what = 'conv_wino F(2x2)'
+        base = lambda: ops.conv2d(x, w, sc, sh, 3, 1, (1, 1, 1, 1), ops.ACT_LEAKY, residual=res, wino=u, wino4=u4)
+        what = 'conv_wino4 F(4x4)' if u4 is not None else 'conv_wino F(2x2)'
     else:
         base = lambda: ops.conv2d(x, w, sc, sh, 3, s, (1, 1, 1, 1), ops.ACT_LEAKY, b3=w3)
         what = 'conv_igemm_b3'
