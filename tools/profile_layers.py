@@ -38,7 +38,7 @@ import re
 print(f'{"kernel":44s} {"n/step":>6s} {"ms/launch":>10s} {"ms/step":>8s} {"%step":>6s} {"TFLOP/s":>8s} {"%peak":>6s} {"GB/s":>8s}')
 for k, (n, ms, work) in sorted(summ.items(), key=lambda kv: -kv[1][1]):
     per = ms / n
-    if k.startswith('conv_igemm') or k.startswith('conv_wino'):
+    if k.startswith('conv_igemm') or k.startswith('conv_wino') or k.startswith('conv_p3'):
         tf = work / n / (per * 1e-3) / 1e12
         m = re.match(r'conv_(?:igemm|wino) (\d+)->(\d+) k(\d)s(\d) (\d+)x(\d+)', k)
         gbs = float('nan')
