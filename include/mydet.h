@@ -122,8 +122,10 @@ int mydet_conv2d_stem_f32(const float *x, int64_t sxb, int64_t sxc, int64_t sxh,
  *   w1 [Cse][C], b1 [Cse], w2t [Cse][C] (the expand conv TRANSPOSED), b2 [C], gate [B][C]  (all 16-byte aligned);
  *   hpart: the share buffer, 8-byte aligned, MYDET_SE_EPOCH_WORDS + 2 * B * groups * Cse 32-bit words (groups =
  *   mydet_dwconv_se_groups / mydet_mbconv_tiles of the layer): a header of MYDET_SE_EPOCH_WORDS words -- word 0 the launch
- *   counter, 1 when the buffer is made; word 1 the count of finished images, 0; the rest unused -- then (value, epoch) pairs,
- *   zero when the buffer is made.  After that only the launches touch it; ONE buffer serves every layer and batch size of a
+ *   counter, 1 when the buffer is made; word 1 the count of finished images, 0; word 2 the number of finishing workgroups that
+ *   ever gave up waiting for a share and wrote a NaN gate (0 in a healthy run; never reset by the launches: a caller may poll it);
+ *   the rest unused -- then (value, epoch) pairs, zero when the buffer is made.  hpart_bytes = the buffer's size: an entry point
+ *   given a smaller one than its layer needs returns MYDET_E_BADARG and launches nothing.  After that only the launches touch it; ONE buffer serves every layer and batch size of a
  *   stream, but never two streams at a time.  Cse <= 96; MYDET_E_UNSUPP beyond.  se_partial may be NULL when the tail is given. */
 #define MYDET_SE_EPOCH_WORDS 1024
 typedef struct {
