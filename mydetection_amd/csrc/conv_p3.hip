@@ -18,7 +18,7 @@
 //   stride 2: position = py * 36 + (px & 1) * 17 + (px >> 1), sigma = ((px >> 1) >> 3) & 1   (columns split by parity: the 16
 //             pixels an MFMA row block reads for one tap are consecutive positions)
 //   stride 1: position = py * 24 + px, sigma = (px >> 3) & 1
-//   found by exhaustive search over (row length, swizzle) against the ds_read_b128 lane groups of MI355X_MICROARCH.md: every
+//   found by exhaustive search (tools/r06/p3_layout_search.py) over (row length, swizzle) against the ds_read_b128 lane groups of MI355X_MICROARCH.md: every
 //   fragment read of every tap touches sixteen distinct 16-byte bank slots per lane group (conflict-free); the staging
 //   writes of 4 consecutive positions are 128 contiguous bytes.
 // Arithmetic: exactly conv_igemm_b3_kernel's (six piece products per k-step, small ones first, float32 accumulation), but
@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(const P3Args p) {
     constexpr int WN = BN / 32, WM = 4 / WN, TM = 4 / WM;       // wave (wm, wn): 32 * TM rows x 32 columns
     constexpr int PH = P3Geom<S>::PH, ROWLEN = P3Geom<S>::ROWLEN, PJ0 = P3Geom<S>::PJ0;
     constexpr int PW = S * (TW - 1) + 3;
+    static_assert(PH == S * (TH - 1) + 3 && PW <= (S == 2 ? 2 * PJ0 - 1 : ROWLEN), "patch geometry");
     constexpr int NPOS = PH * ROWLEN;
     constexpr int PLANE_P = NPOS * ROWB;
     constexpr int NCH = (NPOS * 4 + 255) / 256;      // 16-byte float4 chunks of the patch per thread and slab

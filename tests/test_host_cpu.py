@@ -298,6 +298,29 @@ def test_graph_cache_policy_and_workspace_refs():
     assert ops.check_counts([0, 5]) == [0, 5]
 
 
+def test_conv_p3_patch_layout_is_conflict_free():
+    """The LDS layout of conv_p3_kernel's input patch (csrc/conv_p3.hip: P3Geom, the position / sigma formulas in its header) against
+    the ds_read_b128 lane groups and bank rule of MI355X_MICROARCH.md, replayed on the host (tools/r06/p3_layout_search.py): every
+    A-fragment read of every tap, row block and lane group touches sixteen distinct 16-byte slots -- for both strides.  (On the GPU:
+    SQ_LDS_BANK_CONFLICT = 0, profiles/r06_conv_p3.txt.)  The constants are read from the kernel source so that the two cannot drift."""
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location('p3_layout_search', os.path.join(ROOT, 'tools', 'r06', 'p3_layout_search.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    src = open(os.path.join(ROOT, 'mydetection_amd', 'csrc', 'conv_p3.hip')).read()
+    geo = {int(m.group(1)): tuple(int(v) for v in m.group(2, 3, 4))
+           for m in re.finditer(r'P3Geom<(\d)> \{ static constexpr int PH = (\d+), ROWLEN = (\d+), PJ0 = (\d+); \}', src)}
+    assert geo == {2: (17, 36, 17), 1: (10, 24, 0)}, geo
+    assert 'sig = (j >> 3) & 1;' in src and 'sig = (px >> 3) & 1;' in src              # the staging side of the swizzle
+    ph2, row2, pj0 = geo[2]
+    assert ph2 == 2 * 7 + 3 and mod.worst_conflict(lambda py, px: py * row2 + (px & 1) * pj0 + (px >> 1), lambda py, px: ((px >> 1) >> 3) & 1, 2, 8, 16) == 1
+    ph1, row1, _ = geo[1]
+    assert ph1 == 7 + 3 and mod.worst_conflict(lambda py, px: py * row1 + px, lambda py, px: (px >> 3) & 1, 1, 8, 16) == 1
+    # ... and the check can fail: the unswizzled layout is 2-way conflicted
+    assert mod.worst_conflict(lambda py, px: py * row1 + px, lambda py, px: 0, 1, 8, 16) > 1
+
+
 def test_se_tail_share_buffer_size_is_validated():
     """mydet_se_tail carries the byte count of its share buffer and every entry point that takes an in-launch
     squeeze-excite tail rejects an undersized one BEFORE launching anything (MYDET_E_BADARG; no GPU needed: the pointers are
