@@ -654,6 +654,28 @@ def test_wino4_tail_plan_covers_every_item_once():
     assert lib.mydet_wino4_tail_plan(32, 80, 80, 128, 256, 512, out) == 0          # six whole rounds: no tail
 
 
+def test_conv_p3_dispatch_rule():
+    """ops.p3_takes: which 3x3 layers run on the patch-resident split-bf16 kernel (mydetection_amd/ops.py; measured in
+    profiles/r06_conv_p3.txt): whole 8 x 16-pixel output tiles, a production-sized launch, stride 2 or a stride-1 layer below the
+    F(4x4) channel limit."""
+    from mydetection_amd import ops
+    if not (ops.SPLIT_BF16 and ops.CONV_P3):
+        return
+    pad = (1, 1, 1, 1)
+    # the headline (batch 32, 640^2): the first three stride-2 layers and the 32 -> 64 layer of the first DarkBlock ...
+    for B, Ho, Cin, Cout, s in ((32, 320, 32, 64, 2), (32, 160, 64, 128, 2), (32, 80, 128, 256, 2), (32, 320, 32, 64, 1)):
+        assert ops.p3_takes(B, Ho, Ho, Cin, Cout, 3, s, pad), (B, Ho, Cin, Cout, s)
+    # ... not the two stride-2 layers with ragged tiles (40 and 20 output columns), not stride-1 layers F(4x4) takes, not small launches
+    for B, Ho, Cin, Cout, s in ((32, 40, 256, 512, 2), (32, 20, 512, 1024, 2), (32, 160, 64, 128, 1), (32, 80, 128, 256, 1),
+                                (1, 128, 64, 128, 2), (2, 64, 128, 256, 2)):
+        assert not ops.p3_takes(B, Ho, Ho, Cin, Cout, 3, s, pad), (B, Ho, Cin, Cout, s)
+    # batch 1 at 512^2 (configs[0] shape): the first stride-2 layer and the 32 -> 64 layer pass the 65 536-row limit
+    assert ops.p3_takes(1, 256, 256, 32, 64, 3, 2, pad) and ops.p3_takes(1, 256, 256, 32, 64, 3, 1, pad)
+    # only 3x3, pad 1, stride 1 | 2, Cin % 16 == 0
+    assert not ops.p3_takes(32, 320, 320, 32, 64, 1, 1, (0, 0, 0, 0)) and not ops.p3_takes(32, 320, 320, 32, 64, 3, 2, (0, 0, 1, 1))
+    assert not ops.p3_takes(32, 320, 320, 24, 64, 3, 2, pad) and not ops.p3_takes(32, 320, 320, 32, 64, 3, 3, pad)
+
+
 def test_split_bf16_dispatch_rule():
     """ops.b3_takes: which direct-conv layers run on the split-bf16 kernel (mydetection_amd/ops.py: measured thresholds)."""
     from mydetection_amd import ops
