@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MYDET_ABI_VERSION 1
+#define MYDET_ABI_VERSION 2      /* 2 (round 6): mydet_se_tail gained hpart_bytes; mydet_conv3x3_p3_f32 added */
 
 #define MYDET_E_BADARG   (-1)   /* shape/stride/alignment precondition violated */
 #define MYDET_E_UNSUPP   (-2)   /* valid request this build has no kernel for   */

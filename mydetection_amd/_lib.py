@@ -96,6 +96,7 @@ class SeTail(ctypes.Structure):
 
 
 SE_EPOCH_WORDS = 1024               # MYDET_SE_EPOCH_WORDS of include/mydet.h
+ABI_VERSION = 2                     # MYDET_ABI_VERSION of include/mydet.h (2: mydet_se_tail.hpart_bytes, mydet_conv3x3_p3_f32)
 
 
 class SepconvNode(ctypes.Structure):
@@ -136,8 +137,9 @@ def lib():
             fn = getattr(handle, name)          # AttributeError here = ABI mismatch, also loud
             fn.argtypes = argtypes
             fn.restype = c_i64 if name in RETURNS_I64 else c_int
-        if handle.mydet_abi_version() != 1:
-            raise MissingHipLibrary('libmydet_hip.so ABI version mismatch; rebuild it')
+        if handle.mydet_abi_version() != ABI_VERSION:
+            raise MissingHipLibrary(f'libmydet_hip.so has ABI version {handle.mydet_abi_version()}, this package binds version {ABI_VERSION}; rebuild it '
+                                    '(make -C mydetection_amd/csrc)')
         _lib = handle
     return _lib
 

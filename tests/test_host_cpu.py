@@ -18,7 +18,8 @@ def test_library_exports_every_declared_symbol():
     handle = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(handle, name), name
-    assert _lib.lib().mydet_abi_version() == 1
+    assert _lib.lib().mydet_abi_version() == _lib.ABI_VERSION == 2
+    assert f'#define MYDET_ABI_VERSION {_lib.ABI_VERSION} ' in open(os.path.join(ROOT, 'include', 'mydet.h')).read()
 
 
 def test_argument_errors_are_reported_before_launch():
