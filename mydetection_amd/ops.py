@@ -320,12 +320,12 @@ def b3_takes(M, Cin, Cout, k, min_rows=None, min_cout=128):
 
 # conv_p3_kernel (csrc/conv_p3.hip: 3x3 conv with the workgroup's input patch resident in LDS, split-bf16 operands) takes a 3x3 pad-1
 # layer when its 8 x 16-pixel output tiles are whole (Ho % 8 == 0, Wo % 16 == 0: ragged tiles waste their rows -- 256->512 @80->40
-# runs 0.67 vs 0.64 ms, 512->1024 @40->20 0.94 vs 0.69), the launch is production-sized (P3_MIN_ROWS output pixels) and
+# runs 0.65 vs 0.61 ms, 512->1024 @40->20 0.92 vs 0.69), the launch is production-sized (P3_MIN_ROWS output pixels) and
 #   stride 2: always (the first three stride-2 layers of Darknet-53 at 640^2: 1.07-1.11 x over conv_igemm_b3_kernel);
 #   stride 1: only below WINO4_MIN_CIN input channels, where F(4x4) does not go (32->64 @320^2: 1.16-1.18 x over F(2x2)).
 # profiles/r06_conv_p3.txt.  MYDET_CONV_P3=0 turns it off.
 CONV_P3 = os.environ.get('MYDET_CONV_P3', '1') != '0'
-P3_MIN_ROWS = int(os.environ.get('MYDET_P3_MIN_ROWS', '65536'))
+P3_MIN_ROWS = int(os.environ.get('MYDET_P3_MIN_ROWS', '32768'))         # (512^2 batch 32: the 256->512 stride-2 layer @64->32 has whole tiles too: 2 601-2 622 vs 2 597-2 601 images/s)
 P3_S1_MAX_CIN = int(os.environ.get('MYDET_P3_S1_MAX_CIN', '32'))      # stride-1 layers up to this many input channels
 
 

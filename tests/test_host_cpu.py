@@ -670,7 +670,7 @@ def test_conv_p3_dispatch_rule():
     for B, Ho, Cin, Cout, s in ((32, 40, 256, 512, 2), (32, 20, 512, 1024, 2), (32, 160, 64, 128, 1), (32, 80, 128, 256, 1),
                                 (1, 128, 64, 128, 2), (2, 64, 128, 256, 2)):
         assert not ops.p3_takes(B, Ho, Ho, Cin, Cout, 3, s, pad), (B, Ho, Cin, Cout, s)
-    # batch 1 at 512^2 (configs[0] shape): the first stride-2 layer and the 32 -> 64 layer pass the 65 536-row limit
+    # batch 1 at 512^2 (configs[0] shape): the first stride-2 layer and the 32 -> 64 layer pass the 32 768-row limit
     assert ops.p3_takes(1, 256, 256, 32, 64, 3, 2, pad) and ops.p3_takes(1, 256, 256, 32, 64, 3, 1, pad)
     # only 3x3, pad 1, stride 1 | 2, Cin % 16 == 0
     assert not ops.p3_takes(32, 320, 320, 32, 64, 1, 1, (0, 0, 0, 0)) and not ops.p3_takes(32, 320, 320, 32, 64, 3, 2, (0, 0, 1, 1))
