@@ -213,7 +213,8 @@ int mydet_conv2d_igemm_b3_f32(const float *x, int64_t ldx, const uint16_t *w_pla
                               int pad_l, int Ho, int Wo, int act, void *stream);
 /* 3x3 convolution, pad 1, stride 1 or 2, on the bfloat16 matrix instructions with the float32-exact split operands of
  * mydet_conv2d_igemm_b3_f32 -- same w_planes, same six piece products, float32 accumulation -- but with the workgroup's INPUT
- * PATCH resident in LDS (csrc/conv_p3.hip): a workgroup owns 8 x 16 output pixels x (64 | 128) output channels, loads and
+ * PATCH resident in LDS (csrc/conv_p3.hip): a workgroup owns 8 x 16 output pixels (stride 2: 16 x 8 / 32 x 4 for a remainder of 8 / 4
+ * columns) x (64 | 128) output channels, loads and
  * splits the patch of a 16-channel slab once and the nine taps read their matrix operands out of it at tap offsets, instead of
  * gathering and splitting every input element once per tap (2.25 x at stride 2, 9 x at stride 1).  K order (slab, tap) instead of
  * (tap, slab): results equal the other kernels' to float32 round-off (tests: 2e-5 * max|y| against float64).

@@ -4,7 +4,8 @@
 // memory, cuts them into three bfloat16 pieces and stages them: every input element is loaded and split once per tap that
 // uses it -- 2.25 times for a stride-2 layer, 9 times for a stride-1 layer -- and that staging, not the matrix pipe, bounds
 // the launch (stride-2 128->256 @160^2: 0.36 ms of 0.66 are staging alone; profiles/HISTORY.md, round 5).
-// Here a workgroup owns a SPATIAL tile of TH x TW = 8 x 16 output pixels (128 MFMA rows) x BN output channels.  Per
+// Here a workgroup owns a SPATIAL tile of TH x TW = 8 x 16 output pixels (128 MFMA rows; 16 x 8 / 32 x 4 strip tiles for the remainder
+// columns of maps that are 16 n + 8 / + 4 pixels wide, same launch) x BN output channels.  Per
 // 16-channel slab it loads the tile's input patch (17 x 33 pixels at stride 2, 10 x 18 at stride 1) ONCE, splits it once into
 // three bf16 planes in LDS, and the 9 taps read their MFMA A fragments straight out of that patch at a tap-dependent offset --
 // no im2col tile is ever written.  The weights come pre-split (mydet_split_bf16_f32: the planes conv_igemm_b3_kernel uses,
@@ -41,7 +42,8 @@ struct P3Args {
     float *y;
     int64_t ldx, ldr, ldy;
     int B, H, W, Cin, Cout, Ho, Wo;
-    int tx_n, ty_n, ntn, nblk;                   // spatial tiles per image row / column, channel tiles, workgroups
+    int tx_n, ty_n, ntn, nblk;                   // 8 x 16 tiles per image row / column, channel tiles, workgroups
+    int main_tiles, tiles_img;                   // tx_n * ty_n; + the strip tiles of the remainder columns (STRIP != 0)
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -68,32 +70,33 @@ __device__ __forceinline__ void p3_split3(const f32x4 v, bf16x4 &p0, bf16x4 &p1,
     }
 }
 
-template <int S> struct P3Geom;
-template <> struct P3Geom<2> { static constexpr int PH = 17, ROWLEN = 36, PJ0 = 17; };
-template <> struct P3Geom<1> { static constexpr int PH = 10, ROWLEN = 24, PJ0 = 0; };
+// Tile shapes.  SHAPE 0: 8 rows x 16 columns of output pixels (both strides).  SHAPE 1 / 2 (stride 2): 16 x 8 and 32 x 4 STRIP tiles for
+// the remainder columns of a map whose width is 16 n + 8 / 16 n + 4 (Darknet-53 at 640^2: the 40- and 20-pixel maps), run by the
+// last workgroups of the same launch.  TWL = log2(tile width); PH = patch rows; ROWLEN = positions per patch row; PJ0 = positions
+// of the even columns (stride 2: the odd columns follow them).  sigma (the 16-byte half swap of a position) = bit 3 of the column
+// index j, plus bit 1 of the patch row for the strip shapes: each found conflict-free by tools/r06/p3_layout_search.py.
+template <int S, int SHAPE> struct P3Geom;
+template <> struct P3Geom<2, 0> { static constexpr int TH = 8, TWL = 4, PH = 17, ROWLEN = 36, PJ0 = 17; };
+template <> struct P3Geom<1, 0> { static constexpr int TH = 8, TWL = 4, PH = 10, ROWLEN = 24, PJ0 = 0; };
+template <> struct P3Geom<2, 1> { static constexpr int TH = 16, TWL = 3, PH = 33, ROWLEN = 20, PJ0 = 9; };
+template <> struct P3Geom<2, 2> { static constexpr int TH = 32, TWL = 2, PH = 65, ROWLEN = 9, PJ0 = 5; };
+template <int SHAPE> __device__ __forceinline__ int p3_sigma(int py, int j) { return SHAPE == 0 ? (j >> 3) & 1 : ((j >> 3) + (py >> 1)) & 1; }
 
-// S: stride.  BN: output channels per workgroup (64 | 128): waves = (4 / (BN / 32)) row groups x (BN / 32) column blocks of 32.
-template <int S, int BN, int ACT, bool RES>
-__global__ __launch_bounds__(256, 2) void conv_p3_kernel(const P3Args p) {
-    constexpr int TH = 8, TW = 16, ROWB = 32;
+// One tile: image b, output rows oy0.., columns ox0.., output channels n0...  S: stride.  BN: output channels per workgroup
+// (64 | 128): waves = (4 / (BN / 32)) row groups x (BN / 32) column blocks of 32.
+template <int S, int BN, int SHAPE, int ACT, bool RES>
+__device__ __forceinline__ void p3_tile(const P3Args &p, char *patch, const int b, const int oy0, const int ox0, const int n0) {
+    typedef P3Geom<S, SHAPE> G;
+    constexpr int TH = G::TH, TWL = G::TWL, TW = 1 << TWL, RPB = 32 / TW, ROWB = 32;        // RPB: output rows per 32-row MFMA block
     constexpr int WN = BN / 32, WM = 4 / WN, TM = 4 / WM;       // wave (wm, wn): 32 * TM rows x 32 columns
-    constexpr int PH = P3Geom<S>::PH, ROWLEN = P3Geom<S>::ROWLEN, PJ0 = P3Geom<S>::PJ0;
+    constexpr int PH = G::PH, ROWLEN = G::ROWLEN, PJ0 = G::PJ0;
     constexpr int PW = S * (TW - 1) + 3;
-    static_assert(PH == S * (TH - 1) + 3 && PW <= (S == 2 ? 2 * PJ0 - 1 : ROWLEN), "patch geometry");
+    static_assert(TH * TW == 128 && PH == S * (TH - 1) + 3 && PW <= (S == 2 ? 2 * PJ0 - 1 : ROWLEN), "patch geometry");
     constexpr int NPOS = PH * ROWLEN;
     constexpr int PLANE_P = NPOS * ROWB;
     constexpr int NCH = (NPOS * 4 + 255) / 256;      // 16-byte float4 chunks of the patch per thread and slab
-    extern __shared__ __attribute__((aligned(16))) char smem_p3[];
-    char *patch = smem_p3;
 
     const int tid = threadIdx.x;
-    const int id = mydet_xcd_remap(blockIdx.x, p.nblk);
-    const int nt = id % p.ntn;                       // channel tiles of one spatial tile run together: the patch is shared through L2
-    int t = id / p.ntn;
-    const int tx = t % p.tx_n; t /= p.tx_n;
-    const int ty = t % p.ty_n;
-    const int b = t / p.ty_n;
-    const int oy0 = ty * TH, ox0 = tx * TW, n0 = nt * BN;
     const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
 
     // ---- descriptors.  x: the buffer starts one row + one pixel before image b, so that a patch origin of (-1, -1) is a
@@ -117,11 +120,11 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(const P3Args p) {
         if (S == 2) {
             const int par = rem >= PJ0 ? 1 : 0, j = rem - par * PJ0;
             px = 2 * j + par;
-            sig = (j >> 3) & 1;
-            ok = ok && px < PW && j < (par ? 16 : 17);
+            sig = p3_sigma<SHAPE>(py, j);
+            ok = ok && px < PW && j < (par ? PJ0 - 1 : PJ0);
         } else {
             px = rem;
-            sig = (px >> 3) & 1;
+            sig = p3_sigma<SHAPE>(py, px);
             ok = ok && px < PW;
         }
         const int iy = iy0 + py, ix = ix0 + px;
@@ -133,12 +136,13 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(const P3Args p) {
     const int wave = tid >> 6, lane = tid & 63;
     const int wm = wave / WN, wn = wave % WN;
     const int fr = lane & 31, fh = lane >> 5;
-    const int oxl = fr & 15;
-    int apos[TM];                                    // patch position of the lane's row for tap (0, 0)
+    const int oxl = fr & (TW - 1);
+    int apos[TM], apy[TM];                           // patch position / patch row of the lane's row for tap (0, 0)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int oyl = wm * (TM * 2) + i * 2 + (fr >> 4);
-        apos[i] = S == 2 ? (2 * oyl) * ROWLEN + oxl : oyl * ROWLEN + oxl;
+        const int oyl = wm * (TM * RPB) + i * RPB + (fr >> TWL);
+        apy[i] = S * oyl;
+        apos[i] = apy[i] * ROWLEN + oxl;
     }
     // weights: the lane's 16-byte unit of the wave's 32-row block in a (slab, plane) piece of the planes (split_bf16_kernel)
     const unsigned boff = (unsigned)((n0 + wn * 32) * 32 + (2 * fr + (fh ^ ((fr >> 2) & 1))) * 16);
@@ -187,10 +191,10 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(const P3Args p) {
             int pos, sig;
             if (S == 2) {
                 pos = apos[i] + kh * ROWLEN + (kw & 1) * PJ0 + (kw >> 1);
-                sig = ((oxl + (kw >> 1)) >> 3) & 1;
+                sig = p3_sigma<SHAPE>(apy[i] + kh, oxl + (kw >> 1));
             } else {
                 pos = apos[i] + kh * ROWLEN + kw;
-                sig = ((oxl + kw) >> 3) & 1;
+                sig = p3_sigma<SHAPE>(apy[i] + kh, oxl + kw);
             }
             const char *a = patch + pos * ROWB + ((fh ^ sig) * 16);
 #pragma unroll
@@ -221,8 +225,8 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(const P3Args p) {
         }
     }
 
-    // ---- epilogue: lane = output channel, register = output pixel of the 2-row x 16-column block (row r of the block:
-    // (r >> 4, r & 15)); scale / shift / activation / residual as conv_igemm's
+    // ---- epilogue: lane = output channel, register = output pixel of the RPB-row x TW-column block (row r of the block:
+    // (r >> TWL, r & (TW - 1))); scale / shift / activation / residual as conv_igemm's
     const int64_t opix = (int64_t)p.Ho * p.Wo;       // (descriptors per image: byte offsets stay inside one image's output)
     const __amdgpu_buffer_rsrc_t yr = p3_rsrc(p.y + b * opix * p.ldy, opix * p.ldy * 4);
     const __amdgpu_buffer_rsrc_t rr = p3_rsrc(RES ? p.res + b * opix * p.ldr : p.y, opix * (RES ? p.ldr : p.ldy) * 4);
@@ -233,13 +237,13 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(const P3Args p) {
         const float scl = pscl, sft = psft;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int oyb = oy0 + wm * (TM * 2) + i * 2;         // first output row of the block
+            const int oyb = oy0 + wm * (TM * RPB) + i * RPB;     // first output row of the block
             float rv[16];
             unsigned off_y[16], off_r[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int dr = (r & 3) + 8 * (r >> 2) + 4 * fh;
-                const int oy = oyb + (dr >> 4), ox = ox0 + (dr & 15);
+                const int oy = oyb + (dr >> TWL), ox = ox0 + (dr & (TW - 1));
                 const bool ok = nok && oy < p.Ho && ox < p.Wo;
                 const unsigned pix = (unsigned)(oy * p.Wo + ox);
                 off_y[r] = ok ? pix * ldy4 + (unsigned)n * 4u : OOB;
@@ -258,10 +262,30 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(const P3Args p) {
     }
 }
 
-template <int S, int BN, int ACT, bool RES>
+// The launch: workgroup id -> (channel tile, image, tile of the image); ids of one spatial tile are neighbours (the patch is shared
+// through L2).  STRIP != 0: the image's last tiles are strip tiles (shape STRIP) over the columns behind the tx_n * 16 whole ones.
+template <int S, int BN, int STRIP, int ACT, bool RES>
+__global__ __launch_bounds__(256, 2) void conv_p3_kernel(const P3Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_p3[];
+    const int id = mydet_xcd_remap(blockIdx.x, p.nblk);
+    const int nt = id % p.ntn, t = id / p.ntn;
+    const int b = t / p.tiles_img, r = t - b * p.tiles_img;
+    if constexpr (STRIP != 0) {
+        if (r >= p.main_tiles) {                     // (uniform per workgroup)
+            p3_tile<S, BN, STRIP, ACT, RES>(p, smem_p3, b, (r - p.main_tiles) * P3Geom<S, STRIP>::TH, p.tx_n * 16, nt * BN);
+            return;
+        }
+    }
+    const int ty = r / p.tx_n, tx = r - ty * p.tx_n;
+    p3_tile<S, BN, 0, ACT, RES>(p, smem_p3, b, ty * 8, tx * 16, nt * BN);
+}
+
+template <int S, int SHAPE> constexpr int p3_lds() { return 3 * P3Geom<S, SHAPE>::PH * P3Geom<S, SHAPE>::ROWLEN * 32; }
+
+template <int S, int BN, int STRIP, int ACT, bool RES>
 int p3_launch(const P3Args &p, hipStream_t st) {
-    constexpr int LDS = 3 * P3Geom<S>::PH * P3Geom<S>::ROWLEN * 32;
-    auto kern = &conv_p3_kernel<S, BN, ACT, RES>;
+    constexpr int L0 = p3_lds<S, 0>(), L1 = p3_lds<S, STRIP>(), LDS = L0 > L1 ? L0 : L1;
+    auto kern = &conv_p3_kernel<S, BN, STRIP, ACT, RES>;
     static bool attr = false;
     if (!attr) {
         const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -272,10 +296,10 @@ int p3_launch(const P3Args &p, hipStream_t st) {
     return mydet_launch_status();
 }
 
-template <int S, int BN>
+template <int S, int BN, int STRIP>
 int p3_dispatch(const P3Args &p, int act, bool res, hipStream_t st) {
-    if (act == MYDET_ACT_LEAKY) return res ? p3_launch<S, BN, MYDET_ACT_LEAKY, true>(p, st) : p3_launch<S, BN, MYDET_ACT_LEAKY, false>(p, st);
-    if (act == MYDET_ACT_NONE) return res ? p3_launch<S, BN, MYDET_ACT_NONE, true>(p, st) : p3_launch<S, BN, MYDET_ACT_NONE, false>(p, st);
+    if (act == MYDET_ACT_LEAKY) return res ? p3_launch<S, BN, STRIP, MYDET_ACT_LEAKY, true>(p, st) : p3_launch<S, BN, STRIP, MYDET_ACT_LEAKY, false>(p, st);
+    if (act == MYDET_ACT_NONE) return res ? p3_launch<S, BN, STRIP, MYDET_ACT_NONE, true>(p, st) : p3_launch<S, BN, STRIP, MYDET_ACT_NONE, false>(p, st);
     return MYDET_E_UNSUPP;
 }
 
@@ -297,12 +321,24 @@ extern "C" int mydet_conv3x3_p3_f32(const float *x, int64_t ldx, const uint16_t 
     const char *fe = getenv("MYDET_P3_FORM");        // (experiments) 1 = 64-channel tiles whatever Cout
     const bool wide = Cout > 64 && !(fe && atoi(fe) == 1);
     const int BN = wide ? 128 : 64;
-    p.tx_n = (p.Wo + 15) / 16; p.ty_n = (p.Ho + 7) / 8; p.ntn = (Cout + BN - 1) / BN;
-    const int64_t nblk = (int64_t)B * p.tx_n * p.ty_n * p.ntn;
-    if (nblk > 0x7FFFFFFF) return MYDET_E_UNSUPP;
+    // tile plan: whole 8 x 16 tiles; a remainder of 8 / 4 columns (stride 2) goes to 16 x 8 / 32 x 4 strip tiles of the same launch,
+    // any other remainder to a ragged last column of 8 x 16 tiles.  MYDET_P3_STRIP=0: always the ragged column (A/B)
+    const int rem = p.Wo & 15;
+    const char *se = getenv("MYDET_P3_STRIP");
+    const int strip = (stride == 2 && !(se && atoi(se) == 0)) ? (rem == 8 ? 1 : rem == 4 ? 2 : 0) : 0;
+    p.tx_n = strip ? p.Wo / 16 : (p.Wo + 15) / 16;
+    p.ty_n = (p.Ho + 7) / 8; p.ntn = (Cout + BN - 1) / BN;
+    p.main_tiles = p.tx_n * p.ty_n;
+    p.tiles_img = p.main_tiles + (strip == 1 ? (p.Ho + 15) / 16 : strip == 2 ? (p.Ho + 31) / 32 : 0);
+    const int64_t nblk = (int64_t)B * p.tiles_img * p.ntn;
+    if (nblk > 0x7FFFFFFF || nblk <= 0) return MYDET_E_UNSUPP;
     p.nblk = (int)nblk;
     hipStream_t st = (hipStream_t)stream;
     const bool res = residual != nullptr;
-    if (stride == 2) return wide ? p3_dispatch<2, 128>(p, act, res, st) : p3_dispatch<2, 64>(p, act, res, st);
-    return wide ? p3_dispatch<1, 128>(p, act, res, st) : p3_dispatch<1, 64>(p, act, res, st);
+    if (stride == 2) {
+        if (strip == 1) return wide ? p3_dispatch<2, 128, 1>(p, act, res, st) : p3_dispatch<2, 64, 1>(p, act, res, st);
+        if (strip == 2) return wide ? p3_dispatch<2, 128, 2>(p, act, res, st) : p3_dispatch<2, 64, 2>(p, act, res, st);
+        return wide ? p3_dispatch<2, 128, 0>(p, act, res, st) : p3_dispatch<2, 64, 0>(p, act, res, st);
+    }
+    return wide ? p3_dispatch<1, 128, 0>(p, act, res, st) : p3_dispatch<1, 64, 0>(p, act, res, st);
 }

@@ -319,21 +319,38 @@ def b3_takes(M, Cin, Cout, k, min_rows=None, min_cout=128):
 
 
 # conv_p3_kernel (csrc/conv_p3.hip: 3x3 conv with the workgroup's input patch resident in LDS, split-bf16 operands) takes a 3x3 pad-1
-# layer when its 8 x 16-pixel output tiles are whole (Ho % 8 == 0, Wo % 16 == 0: ragged tiles waste their rows -- 256->512 @80->40
-# runs 0.65 vs 0.61 ms, 512->1024 @40->20 0.92 vs 0.69), the launch is production-sized (P3_MIN_ROWS output pixels) and
+# layer when its 128-pixel tiles are mostly real pixels (P3_MIN_FILL; ragged 8 x 16 tiles waste their rows -- without strip tiles
+# 256->512 @80->40 ran 0.65 vs 0.61 ms, 512->1024 @40->20 0.92 vs 0.69), the launch fills the chip (P3_MIN_WGS workgroups) and
 #   stride 2: always (the first three stride-2 layers of Darknet-53 at 640^2: 1.07-1.11 x over conv_igemm_b3_kernel);
 #   stride 1: only below WINO4_MIN_CIN input channels, where F(4x4) does not go (32->64 @320^2: 1.16-1.18 x over F(2x2)).
 # profiles/r06_conv_p3.txt.  MYDET_CONV_P3=0 turns it off.
 CONV_P3 = os.environ.get('MYDET_CONV_P3', '1') != '0'
-P3_MIN_ROWS = int(os.environ.get('MYDET_P3_MIN_ROWS', '32768'))         # (512^2 batch 32: the 256->512 stride-2 layer @64->32 has whole tiles too: 2 601-2 622 vs 2 597-2 601 images/s)
+P3_MIN_WGS = int(os.environ.get('MYDET_P3_MIN_WGS', '512'))             # a full round of the chip (two workgroups per CU); 512^2 batch 32: the 256->512
+                                                                        # stride-2 layer @64->32 (1 024 workgroups) joins: 2 601-2 622 vs 2 597-2 601 images/s
 P3_S1_MAX_CIN = int(os.environ.get('MYDET_P3_S1_MAX_CIN', '32'))      # stride-1 layers up to this many input channels
+# tiles must be mostly real pixels: 0.75 admits the 40-wide (13 tiles for 1 600 pixels: 0.96) and 20-wide (4 for 400: 0.78) maps of Darknet-53 at
+# 640^2 with their strip tiles, not a ragged 8 x 16 column on a 20-wide map (0.52).  MYDET_P3_STRIP=0: no strip tiles (the library reads it too)
+P3_MIN_FILL = float(os.environ.get('MYDET_P3_MIN_FILL', '0.75'))
+P3_STRIP = os.environ.get('MYDET_P3_STRIP', '1') != '0'
+
+
+def p3_tiles(Ho, Wo, stride):
+    """Workgroup tiles of 128 output pixels per image and channel tile that mydet_conv3x3_p3_f32 launches (csrc/conv_p3.hip): 8 x 16
+    tiles; at stride 2 a remainder of 8 / 4 columns goes to 16 x 8 / 32 x 4 strip tiles, any other remainder to a ragged column."""
+    rem = Wo % 16
+    strip = stride == 2 and rem in (4, 8) and P3_STRIP
+    tiles = (Wo // 16 if strip else -(-Wo // 16)) * -(-Ho // 8)
+    if strip:
+        tiles += -(-Ho // 16) if rem == 8 else -(-Ho // 32)
+    return tiles
 
 
 def p3_takes(B, Ho, Wo, Cin, Cout, k, stride, pad):
     """True when conv2d(..., b3=) hands the layer to conv3x3_p3."""
     if not (CONV_P3 and SPLIT_BF16) or k != 3 or stride not in (1, 2) or tuple(pad) != (1, 1, 1, 1) or Cin % 16:
         return False
-    if Ho % 8 or Wo % 16 or B * Ho * Wo < P3_MIN_ROWS:
+    tiles = p3_tiles(Ho, Wo, stride)
+    if B * tiles * -(-Cout // (128 if Cout > 64 else 64)) < P3_MIN_WGS or Ho * Wo < P3_MIN_FILL * 128 * tiles:
         return False
     return stride == 2 or Cin <= P3_S1_MAX_CIN
 

@@ -121,6 +121,10 @@ def test_conv_split_bf16_vs_fp64(dev, case, monkeypatch):
     dict(B=2, Cin=64, Cout=160, s=1, H=21, W=35, act=1, strided=True),          # stride 1, BN = 128, ragged, input a channel slice / padded output rows
     dict(B=5, Cin=16, Cout=40, s=2, H=30, W=18, act=1, residual=True, strided=True),   # one slab, ragged channels (40 of 64), residual
     dict(B=32, Cin=64, Cout=128, s=2, H=64, W=64, act=1),                       # 4 096 workgroups (XCD remap, several rounds)
+    dict(B=3, Cin=64, Cout=128, s=2, H=80, W=80, act=1),                        # 40 x 40 outputs: two 8 x 16 columns + 16 x 8 STRIP tiles (the last one half empty)
+    dict(B=3, Cin=32, Cout=192, s=2, H=40, W=40, act=1, residual=True),         # 20 x 20 outputs: one column + ONE 32 x 4 strip tile per image, ragged channels
+    dict(B=2, Cin=48, Cout=64, s=2, H=47, W=48, act=0, strided=True),           # 24 x 24: 64-channel tiles with a 16 x 8 strip, odd height
+    dict(B=2, Cin=16, Cout=40, s=2, H=70, W=8, act=1),                          # 4 columns only: no whole tile at all, 32 x 4 strips over 35 rows
 ])
 def test_conv_p3_vs_fp64(dev, case):
     """conv_p3_kernel (csrc/conv_p3.hip: 3x3 conv with the workgroup's input patch resident in LDS, split-bf16 operands): held to the

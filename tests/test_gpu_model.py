@@ -860,7 +860,7 @@ def test_full_size_properties_batch32_640(model):
         assert ops.WINOGRAD
         # (the patch-resident 3x3 kernel is live in this batch: the first stride-2 layers and the 32 -> 64 layer of the first DarkBlock)
         assert ops.p3_takes(32, 320, 320, 32, 64, 3, 2, (1, 1, 1, 1)) and ops.p3_takes(32, 320, 320, 32, 64, 3, 1, (1, 1, 1, 1))
-        assert not ops.p3_takes(32, 40, 40, 256, 512, 3, 2, (1, 1, 1, 1))            # ragged tiles stay on conv_igemm_b3_kernel
+        assert ops.p3_takes(32, 40, 40, 256, 512, 3, 2, (1, 1, 1, 1)) and ops.p3_takes(32, 20, 20, 512, 1024, 3, 2, (1, 1, 1, 1))     # with strip tiles
         ops.WINOGRAD = False
         try:
             bd, cd, sd_ = m.forward_candidates(x)

@@ -666,11 +666,15 @@ def test_conv_p3_dispatch_rule():
     # the headline (batch 32, 640^2): the first three stride-2 layers and the 32 -> 64 layer of the first DarkBlock ...
     for B, Ho, Cin, Cout, s in ((32, 320, 32, 64, 2), (32, 160, 64, 128, 2), (32, 80, 128, 256, 2), (32, 320, 32, 64, 1)):
         assert ops.p3_takes(B, Ho, Ho, Cin, Cout, 3, s, pad), (B, Ho, Cin, Cout, s)
-    # ... not the two stride-2 layers with ragged tiles (40 and 20 output columns), not stride-1 layers F(4x4) takes, not small launches
-    for B, Ho, Cin, Cout, s in ((32, 40, 256, 512, 2), (32, 20, 512, 1024, 2), (32, 160, 64, 128, 1), (32, 80, 128, 256, 1),
-                                (1, 128, 64, 128, 2), (2, 64, 128, 256, 2)):
+    # ... and, with strip tiles for their remainder columns, the 40- and 20-pixel maps (13 / 4 tiles for 1 600 / 400 pixels)
+    assert ops.p3_tiles(40, 40, 2) == 13 and ops.p3_tiles(20, 20, 2) == 4 and ops.p3_tiles(80, 80, 2) == 50 and ops.p3_tiles(20, 20, 1) == 6
+    for B, Ho, Cin, Cout, s in ((32, 40, 256, 512, 2), (32, 20, 512, 1024, 2)):
+        assert ops.p3_takes(B, Ho, Ho, Cin, Cout, 3, s, pad), (B, Ho, Cin, Cout, s)
+    # not stride-1 layers F(4x4) takes, not small launches, not maps whose tiles would be mostly padding
+    for B, Ho, Cin, Cout, s in ((32, 160, 64, 128, 1), (32, 80, 128, 256, 1), (1, 128, 64, 128, 2), (2, 64, 128, 256, 2), (64, 20, 32, 64, 1),
+                                (400, 10, 64, 128, 2)):
         assert not ops.p3_takes(B, Ho, Ho, Cin, Cout, 3, s, pad), (B, Ho, Cin, Cout, s)
-    # batch 1 at 512^2 (configs[0] shape): the first stride-2 layer and the 32 -> 64 layer pass the 32 768-row limit
+    # batch 1 at 512^2 (configs[0] shape): the first stride-2 layer and the 32 -> 64 layer fill a round of 512 workgroups
     assert ops.p3_takes(1, 256, 256, 32, 64, 3, 2, pad) and ops.p3_takes(1, 256, 256, 32, 64, 3, 1, pad)
     # only 3x3, pad 1, stride 1 | 2, Cin % 16 == 0
     assert not ops.p3_takes(32, 320, 320, 32, 64, 1, 1, (0, 0, 0, 0)) and not ops.p3_takes(32, 320, 320, 32, 64, 3, 2, (0, 0, 1, 1))

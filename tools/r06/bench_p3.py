@@ -10,6 +10,8 @@ dev = torch.device('cuda:0')
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 B = int(os.environ.get('P3_BATCH', '32'))
 LAYERS = [(32, 64, 2, 640), (64, 128, 2, 320), (128, 256, 2, 160), (256, 512, 2, 80), (512, 1024, 2, 40), (32, 64, 1, 320)]
+if os.environ.get('P3_STRIPS'):
+    LAYERS = [(256, 512, 2, 80), (512, 1024, 2, 40), (128, 256, 2, 160)]
 if os.environ.get('P3_S1'):
     LAYERS = [(64, 128, 1, 160), (128, 256, 1, 80), (32, 64, 1, 320)]
 
