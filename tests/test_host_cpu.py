@@ -310,16 +310,27 @@ def test_conv_p3_patch_layout_is_conflict_free():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     src = open(os.path.join(ROOT, 'mydetection_amd', 'csrc', 'conv_p3.hip')).read()
-    geo = {int(m.group(1)): tuple(int(v) for v in m.group(2, 3, 4))
-           for m in re.finditer(r'P3Geom<(\d)> \{ static constexpr int PH = (\d+), ROWLEN = (\d+), PJ0 = (\d+); \}', src)}
-    assert geo == {2: (17, 36, 17), 1: (10, 24, 0)}, geo
-    assert 'sig = (j >> 3) & 1;' in src and 'sig = (px >> 3) & 1;' in src              # the staging side of the swizzle
-    ph2, row2, pj0 = geo[2]
-    assert ph2 == 2 * 7 + 3 and mod.worst_conflict(lambda py, px: py * row2 + (px & 1) * pj0 + (px >> 1), lambda py, px: ((px >> 1) >> 3) & 1, 2, 8, 16) == 1
-    ph1, row1, _ = geo[1]
-    assert ph1 == 7 + 3 and mod.worst_conflict(lambda py, px: py * row1 + px, lambda py, px: (px >> 3) & 1, 1, 8, 16) == 1
-    # ... and the check can fail: the unswizzled layout is 2-way conflicted
-    assert mod.worst_conflict(lambda py, px: py * row1 + px, lambda py, px: 0, 1, 8, 16) > 1
+    geo = {(int(m.group(1)), int(m.group(2))): tuple(int(v) for v in m.group(3, 4, 5, 6, 7))
+           for m in re.finditer(r'P3Geom<(\d), (\d)> \{ static constexpr int TH = (\d+), TWL = (\d+), PH = (\d+), ROWLEN = (\d+), PJ0 = (\d+); \}', src)}
+    # (stride, shape) -> (tile rows, log2 tile columns, patch rows, positions per patch row, positions of the even columns)
+    assert geo == {(2, 0): (8, 4, 17, 36, 17), (1, 0): (8, 4, 10, 24, 0), (2, 1): (16, 3, 33, 20, 9), (2, 2): (32, 2, 65, 9, 5)}, geo
+    assert 'return SHAPE == 0 ? (j >> 3) & 1 : ((j >> 3) + (py >> 1)) & 1;' in src            # the swizzle bit, staging and fragment reads alike
+    for (S, shape), (TH, TWL, PH, ROWLEN, PJ0) in geo.items():
+        TW = 1 << TWL
+        assert TH * TW == 128 and PH == S * (TH - 1) + 3
+        sig = (lambda py, j: (j >> 3) & 1) if shape == 0 else (lambda py, j: ((j >> 3) + (py >> 1)) & 1)
+        if S == 2:
+            pos = lambda py, px, R=ROWLEN, P=PJ0: py * R + (px & 1) * P + (px >> 1)          # noqa: E731
+            sg = lambda py, px, f=sig: f(py, px >> 1)                                       # noqa: E731
+        else:
+            pos = lambda py, px, R=ROWLEN: py * R + px                                      # noqa: E731
+            sg = lambda py, px, f=sig: f(py, px)                                            # noqa: E731
+        assert mod.worst_conflict(pos, sg, S, TH, TW) == 1, (S, shape)
+        # the positions of one patch row are distinct and inside the row
+        cols = S * (TW - 1) + 3
+        assert len({pos(0, px) for px in range(cols)}) == cols and max(pos(0, px) for px in range(cols)) < ROWLEN
+    # ... and the check can fail: the unswizzled stride-1 layout is conflicted
+    assert mod.worst_conflict(lambda py, px: py * 24 + px, lambda py, px: 0, 1, 8, 16) > 1
 
 
 def test_se_tail_share_buffer_size_is_validated():
